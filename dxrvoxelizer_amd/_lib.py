@@ -1,0 +1,78 @@
+"""ctypes loader for libdxv.so.  Fails loudly when the HIP library is missing: no fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class DxvError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libdxv.so")
+
+
+class Stats(C.Structure):
+    _fields_ = [("num_tris", C.c_uint32), ("num_verts", C.c_uint32), ("num_nodes", C.c_uint32),
+                ("tree_height", C.c_uint32), ("bound", C.c_float * 4), ("upload_ms", C.c_float),
+                ("prep_ms", C.c_float), ("sort_ms", C.c_float), ("hierarchy_ms", C.c_float),
+                ("refit_ms", C.c_float), ("build_ms", C.c_float), ("voxelize_ms", C.c_float),
+                ("grid_dim", C.c_uint32), ("z0", C.c_uint32), ("nz", C.c_uint32),
+                ("stack_entries", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("bound", "reserved")}
+        d["bound"] = list(self.bound)
+        return d
+
+
+# name -> (restype, argtypes); every symbol include/dxv.h declares
+_F32P = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_U32P = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+SYMBOLS = {
+    "dxv_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "dxv_destroy": (None, [C.c_void_p]),
+    "dxv_last_error": (C.c_char_p, [C.c_void_p]),
+    "dxv_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dxv_obj_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32),
+                               C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32), _F32P]),
+    "dxv_free": (None, [C.c_void_p]),
+    "dxv_set_mesh": (C.c_int, [C.c_void_p, _F32P, C.c_uint32, _U32P, C.c_uint32]),
+    "dxv_build": (C.c_int, [C.c_void_p]),
+    "dxv_voxelize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]),
+    "dxv_voxelize_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]),
+    "dxv_sync": (C.c_int, [C.c_void_p]),
+    "dxv_grid_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "dxv_grid_bytes": (C.c_size_t, [C.c_void_p]),
+    "dxv_grid_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dxv_grid_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "dxv_enable_texels": (C.c_int, [C.c_void_p, C.c_int]),
+    "dxv_texels_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dxv_scene_bytes": (C.c_size_t, [C.c_void_p]),
+    "dxv_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dxv_scene_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dxv_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "dxv_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "dxv_debug_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+}
+
+
+def load_library():
+    """Load libdxv.so and bind every C-ABI symbol.  Raises DxvError when it is not built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise DxvError(f"{path} is missing: build it with `python -m dxrvoxelizer_amd.build` "
+                           "(the voxelizer has no CPU fallback)")
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB

@@ -1,0 +1,71 @@
+"""Build libdxv.so (HIP kernels + C-ABI) in-tree for gfx950.
+
+    python -m dxrvoxelizer_amd.build [--force] [--save-temps]
+
+hipcc cross-compiles without a GPU; the resulting dxrvoxelizer_amd/libdxv.so travels with the
+repository snapshot to the GPU box.
+"""
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libdxv.so")
+
+SOURCES = ["dxv_api.hip", "lbvh.hip", "radix_sort.hip", "traverse.hip", "obj_ingest.cpp"]
+HEADERS = ["dxv_device.h", "dxv_math.h", "dxv_trace.h", "dxv_types.h", os.path.join("..", "..", "include", "dxv.h")]
+
+# -ffp-contract=off: the arithmetic of the path has a fixed operation order; the only fused
+# operations are the explicit fmaf calls in dxv_math.h (hipcc contracts by default).
+# Correctly rounded f32 divide/sqrt is hipcc's default and is stated explicitly.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def _compile(src, extra):
+    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+    cmd = [hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if src.endswith(".cpp"):
+        cmd = [c for c in cmd if not c.startswith("--offload-arch") and not c.startswith("-fhip")]
+        cmd.insert(1, "-x"), cmd.insert(2, "c++")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("compile failed: %s\n%s%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return obj, r.stderr
+
+
+def build(force=False, save_temps=False, verbose=False):
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] + [__file__]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
+        return LIB
+    os.makedirs(OBJDIR, exist_ok=True)
+    extra = ["-save-temps=obj"] if save_temps else []
+    with cf.ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(lambda s: _compile(s, extra), SOURCES))
+    for _, err in results:
+        if verbose and err.strip():
+            print(err, file=sys.stderr)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in results]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("link failed: %s\n%s%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))

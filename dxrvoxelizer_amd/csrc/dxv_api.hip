@@ -1,0 +1,481 @@
+// dxv_api.hip -- the C-ABI of libdxv.so (include/dxv.h): context, device memory, build and
+// voxelize orchestration on one HIP stream.  There is no CPU fallback anywhere in this file:
+// without a HIP device dxv_create fails.
+#include "../../include/dxv.h"
+#include "dxv_device.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+using namespace dxv;
+
+namespace {
+thread_local std::string g_createError;
+
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+}
+
+struct dxv_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // mesh (caller's layout)
+    float* dVb = nullptr;
+    uint32_t* dIb = nullptr;
+    uint32_t T = 0, V = 0;
+    float bound[4] = {0, 0, 0, 0};
+    bool haveMesh = false;
+
+    // scene blob
+    uint8_t* dScene = nullptr;
+    size_t sceneBytes = 0;
+    SceneHeader hdr{};
+    bool haveScene = false;
+
+    // build scratch
+    uint64_t* dKeys = nullptr;
+    uint64_t* dKeysTmp = nullptr;
+    uint32_t* dHist = nullptr;
+    uint32_t* dParents = nullptr;
+    uint32_t* dFlags = nullptr;
+    uint32_t* dFlags2 = nullptr;
+    uint32_t* dRootInfo = nullptr;
+    uint32_t scratchT = 0;
+
+    // outputs
+    uint8_t* dGrid = nullptr;
+    size_t gridCap = 0, gridBytes = 0;
+    uint32_t* dTexels = nullptr;
+    size_t texelCap = 0;
+    bool texels = false;
+    uint32_t* dStatus = nullptr;
+    unsigned long long* dCount = nullptr;
+
+    hipEvent_t ev[10] = {};
+    dxv_stats stats{};
+
+    // options
+    int optBrick = 1;
+    int optStack = 0;
+    int optRefit = 0;
+};
+
+namespace {
+
+int fail(dxv_ctx* c, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_createError = buf;
+    return 1;
+}
+
+#define DXV_HIP(c, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail((c), "%s failed: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+Node* scene_nodes(dxv_ctx* c) { return reinterpret_cast<Node*>(c->dScene + c->hdr.offNodes); }
+TriPos* scene_tripos(dxv_ctx* c) { return reinterpret_cast<TriPos*>(c->dScene + c->hdr.offTriPos); }
+TriNrm* scene_trinrm(dxv_ctx* c) { return reinterpret_cast<TriNrm*>(c->dScene + c->hdr.offTriNrm); }
+
+void layout_scene(SceneHeader& h, uint32_t T, uint32_t V)
+{
+    memset(&h, 0, sizeof(h));
+    h.magic = kSceneMagic;
+    h.version = kSceneVersion;
+    h.numTris = T;
+    h.numVerts = V;
+    h.numNodes = T > 1 ? T - 1 : 1;
+    h.offNodes = align256(sizeof(SceneHeader));
+    h.offTriPos = align256(h.offNodes + sizeof(Node) * (size_t)h.numNodes);
+    h.offTriNrm = align256(h.offTriPos + sizeof(TriPos) * (size_t)T);
+    h.totalBytes = align256(h.offTriNrm + sizeof(TriNrm) * (size_t)T);
+}
+
+int alloc_scene(dxv_ctx* c, uint32_t T, uint32_t V)
+{
+    SceneHeader h;
+    layout_scene(h, T, V);
+    if (c->dScene && c->sceneBytes != h.totalBytes) { (void)hipFree(c->dScene); c->dScene = nullptr; }
+    if (!c->dScene) DXV_HIP(c, hipMalloc(&c->dScene, h.totalBytes));
+    c->sceneBytes = h.totalBytes;
+    c->hdr = h;
+    return 0;
+}
+
+void free_scratch(dxv_ctx* c)
+{
+    (void)hipFree(c->dKeys); (void)hipFree(c->dKeysTmp); (void)hipFree(c->dHist); (void)hipFree(c->dParents);
+    (void)hipFree(c->dFlags); (void)hipFree(c->dFlags2);
+    c->dKeys = c->dKeysTmp = nullptr; c->dHist = c->dParents = c->dFlags = c->dFlags2 = nullptr;
+    c->scratchT = 0;
+}
+
+int alloc_scratch(dxv_ctx* c, uint32_t T)
+{
+    if (c->scratchT == T) return 0;
+    free_scratch(c);
+    DXV_HIP(c, hipMalloc(&c->dKeys, sizeof(uint64_t) * (size_t)T));
+    DXV_HIP(c, hipMalloc(&c->dKeysTmp, sizeof(uint64_t) * (size_t)T));
+    DXV_HIP(c, hipMalloc(&c->dHist, sizeof(uint32_t) * (size_t)radix_sort_hist_words(T)));
+    DXV_HIP(c, hipMalloc(&c->dParents, sizeof(uint32_t) * (2 * (size_t)T)));
+    DXV_HIP(c, hipMalloc(&c->dFlags, sizeof(uint32_t) * (size_t)T));
+    DXV_HIP(c, hipMalloc(&c->dFlags2, sizeof(uint32_t) * (size_t)T));
+    c->scratchT = T;
+    return 0;
+}
+
+float elapsed(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+} // namespace
+
+extern "C" {
+
+int dxv_create(dxv_ctx** out, int device)
+{
+    if (!out) return fail(nullptr, "dxv_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, "dxv_create: no HIP device available (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(nullptr, "dxv_create: device %d out of range [0,%d)", device, n);
+    dxv_ctx* c = new dxv_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, "dxv_create: cannot initialise device %d", device);
+    }
+    c->stream = c->ownStream;
+    for (auto& ev : c->ev) {
+        if (hipEventCreate(&ev) != hipSuccess) { delete c; return fail(nullptr, "dxv_create: hipEventCreate failed"); }
+    }
+    if (hipMalloc(&c->dStatus, 256) != hipSuccess || hipMalloc(&c->dCount, 256) != hipSuccess ||
+        hipMalloc(&c->dRootInfo, 256) != hipSuccess) {
+        delete c;
+        return fail(nullptr, "dxv_create: hipMalloc failed");
+    }
+    (void)hipMemset(c->dStatus, 0, 256);
+    *out = c;
+    return 0;
+}
+
+void dxv_destroy(dxv_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scratch(c);
+    (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene); (void)hipFree(c->dGrid);
+    (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dCount); (void)hipFree(c->dRootInfo);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+const char* dxv_last_error(const dxv_ctx* c) { return c ? c->err.c_str() : g_createError.c_str(); }
+
+int dxv_set_stream(dxv_ctx* c, void* s)
+{
+    if (!c) return 1;
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? static_cast<hipStream_t>(s) : c->ownStream;
+    return 0;
+}
+
+int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, uint32_t T)
+{
+    if (!c) return 1;
+    if (!vb || !ib || !V || !T) return fail(c, "dxv_set_mesh: empty mesh (V=%u, T=%u)", V, T);
+    if (T > 0x7fffffffu / 2) return fail(c, "dxv_set_mesh: too many triangles (%u)", T);
+    for (size_t i = 0; i < 3 * (size_t)T; ++i)
+        if (ib[i] >= V) return fail(c, "dxv_set_mesh: index %u at position %zu out of range (V=%u)", ib[i], i, V);
+    // bound: AABB over every VB position (XUSGObjLoader.cpp:386-416), centre and half max extent
+    // (Content/Voxelizer.cpp:52-57)
+    float mn[3] = {vb[0], vb[1], vb[2]}, mx[3] = {vb[0], vb[1], vb[2]};
+    for (uint32_t i = 1; i < V; ++i) {
+        const float* p = vb + 6 * (size_t)i;
+        for (int a = 0; a < 3; ++a) {
+            if (p[a] < mn[a]) mn[a] = p[a];
+            else if (p[a] > mx[a]) mx[a] = p[a];
+        }
+    }
+    const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    c->bound[0] = (mx[0] + mn[0]) / 2.0f;
+    c->bound[1] = (mx[1] + mn[1]) / 2.0f;
+    c->bound[2] = (mx[2] + mn[2]) / 2.0f;
+    const float eyz = ey > ez ? ey : ez;
+    c->bound[3] = (ex > eyz ? ex : eyz) / 2.0f;
+    if (!(c->bound[3] > 0.0f) || !std::isfinite(c->bound[3]) || !std::isfinite(c->bound[0]) ||
+        !std::isfinite(c->bound[1]) || !std::isfinite(c->bound[2]))
+        return fail(c, "dxv_set_mesh: degenerate or non-finite bound (half extent %g)", (double)c->bound[3]);
+
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->dVb); (void)hipFree(c->dIb);
+    c->dVb = nullptr; c->dIb = nullptr;
+    c->haveMesh = false; c->haveScene = false;
+    DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
+    DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
+    DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
+    DXV_HIP(c, hipMemcpyAsync(c->dVb, vb, sizeof(float) * 6 * (size_t)V, hipMemcpyHostToDevice, c->stream));
+    DXV_HIP(c, hipMemcpyAsync(c->dIb, ib, sizeof(uint32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, c->stream));
+    DXV_HIP(c, hipEventRecord(c->ev[9], c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    c->T = T; c->V = V;
+    c->haveMesh = true;
+    c->stats.num_tris = T; c->stats.num_verts = V;
+    memcpy(c->stats.bound, c->bound, sizeof(c->bound));
+    c->stats.upload_ms = elapsed(c->ev[8], c->ev[9]);
+    return 0;
+}
+
+int dxv_build(dxv_ctx* c)
+{
+    if (!c) return 1;
+    if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
+    DXV_HIP(c, hipSetDevice(c->device));
+    c->haveScene = false;
+    if (alloc_scene(c, c->T, c->V)) return 1;
+    if (alloc_scratch(c, c->T)) return 1;
+    memcpy(c->hdr.bound, c->bound, sizeof(c->bound));
+
+    BuildBuffers b{};
+    b.vb = c->dVb; b.ib = c->dIb; b.T = c->T; b.V = c->V;
+    memcpy(b.bound, c->bound, sizeof(c->bound));
+    b.keys = c->dKeys; b.keysTmp = c->dKeysTmp; b.hist = c->dHist; b.parents = c->dParents;
+    b.flags = c->dFlags; b.flags2 = c->dFlags2; b.rootInfo = c->dRootInfo;
+    b.nodes = scene_nodes(c); b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
+    DXV_HIP(c, lbvh_build(b, c->optRefit, c->stream, c->ev));
+    uint32_t rootInfo[8];
+    DXV_HIP(c, hipMemcpyAsync(rootInfo, c->dRootInfo, sizeof(rootInfo), hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    if (rootInfo[7] != 1) return fail(c, "dxv_build: build did not complete");
+    memcpy(c->hdr.rootLo, &rootInfo[0], 12);
+    memcpy(c->hdr.rootHi, &rootInfo[3], 12);
+    c->hdr.treeHeight = rootInfo[6];
+    for (int a = 0; a < 3; ++a)
+        if (!(c->hdr.rootLo[a] <= c->hdr.rootHi[a]))
+            return fail(c, "dxv_build: refit produced an invalid root box (axis %d: %g > %g)", a,
+                        (double)c->hdr.rootLo[a], (double)c->hdr.rootHi[a]);
+    if (c->hdr.treeHeight == 0 || c->hdr.treeHeight > 64)
+        return fail(c, "dxv_build: implausible tree height %u", c->hdr.treeHeight);
+    DXV_HIP(c, hipMemcpyAsync(c->dScene, &c->hdr, sizeof(SceneHeader), hipMemcpyHostToDevice, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    c->haveScene = true;
+    c->stats.num_nodes = c->hdr.numNodes;
+    c->stats.tree_height = c->hdr.treeHeight;
+    c->stats.prep_ms = elapsed(c->ev[0], c->ev[1]);
+    c->stats.sort_ms = elapsed(c->ev[1], c->ev[2]);
+    c->stats.hierarchy_ms = elapsed(c->ev[2], c->ev[3]);
+    c->stats.refit_ms = elapsed(c->ev[3], c->ev[4]);
+    c->stats.build_ms = elapsed(c->ev[0], c->ev[4]);
+    return 0;
+}
+
+int dxv_voxelize_async(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nz)
+{
+    if (!c) return 1;
+    if (!c->haveScene) return fail(c, "dxv_voxelize: no scene (call dxv_build or dxv_scene_import first)");
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_voxelize: grid_dim must be even and in [2, 2048], got %u", N);
+    if (nz == 0 || z0 >= N || nz > N - z0) return fail(c, "dxv_voxelize: slab [%u, %u+%u) outside the grid (N=%u)", z0, z0, nz, N);
+    if (mode != DXV_MODE_REFERENCE && mode != DXV_MODE_PARITY) return fail(c, "dxv_voxelize: unknown mode %d", mode);
+    if (c->texels && mode != DXV_MODE_REFERENCE) return fail(c, "dxv_voxelize: texel output exists in reference mode only");
+    DXV_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)N * N * nz;
+    if (bytes > c->gridCap) {
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dGrid); c->dGrid = nullptr; c->gridCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dGrid, align256(bytes)));
+        c->gridCap = bytes;
+    }
+    if (c->texels && bytes > c->texelCap) {
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dTexels); c->dTexels = nullptr; c->texelCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dTexels, align256(bytes * 4)));
+        c->texelCap = bytes;
+    }
+    c->gridBytes = bytes;
+    VoxelizeParams p{};
+    p.nodes = scene_nodes(c); p.triPos = scene_tripos(c); p.triNrm = scene_trinrm(c);
+    p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
+    p.N = N; p.z0 = z0; p.nz = nz; p.mode = mode; p.treeHeight = c->hdr.treeHeight;
+    DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
+    DXV_HIP(c, launch_voxelize(p, c->optBrick, c->optStack, c->stream, &c->stats.stack_entries));
+    DXV_HIP(c, hipEventRecord(c->ev[6], c->stream));
+    c->stats.grid_dim = N; c->stats.z0 = z0; c->stats.nz = nz;
+    return 0;
+}
+
+int dxv_sync(dxv_ctx* c)
+{
+    if (!c) return 1;
+    DXV_HIP(c, hipSetDevice(c->device));
+    uint32_t status = 0;
+    DXV_HIP(c, hipMemcpyAsync(&status, c->dStatus, sizeof(status), hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->stats.grid_dim) c->stats.voxelize_ms = elapsed(c->ev[5], c->ev[6]);
+    if (status) {
+        (void)hipMemsetAsync(c->dStatus, 0, sizeof(uint32_t), c->stream);
+        return fail(c, "voxelize kernel reported status 0x%x (traversal stack overflow: tree height %u, stack %u)",
+                    status, c->hdr.treeHeight, c->stats.stack_entries);
+    }
+    return 0;
+}
+
+int dxv_voxelize(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nz)
+{
+    if (dxv_voxelize_async(c, N, mode, z0, nz)) return 1;
+    return dxv_sync(c);
+}
+
+void* dxv_grid_device_ptr(dxv_ctx* c) { return c ? c->dGrid : nullptr; }
+size_t dxv_grid_bytes(const dxv_ctx* c) { return c ? c->gridBytes : 0; }
+
+int dxv_grid_download(dxv_ctx* c, uint8_t* host, size_t bytes)
+{
+    if (!c) return 1;
+    if (!host || bytes != c->gridBytes || !c->gridBytes) return fail(c, "dxv_grid_download: expected %zu bytes, got %zu", c->gridBytes, bytes);
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, hipMemcpyAsync(host, c->dGrid, bytes, hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dxv_grid_count(dxv_ctx* c, uint64_t* solid)
+{
+    if (!c) return 1;
+    if (!solid || !c->gridBytes) return fail(c, "dxv_grid_count: no grid");
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, launch_count(c->dGrid, c->gridBytes, c->dCount, c->stream));
+    unsigned long long v = 0;
+    DXV_HIP(c, hipMemcpyAsync(&v, c->dCount, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    *solid = v;
+    return 0;
+}
+
+int dxv_enable_texels(dxv_ctx* c, int enable)
+{
+    if (!c) return 1;
+    c->texels = enable != 0;
+    return 0;
+}
+
+int dxv_texels_download(dxv_ctx* c, uint32_t* host, size_t bytes)
+{
+    if (!c) return 1;
+    if (!c->texels || !c->dTexels) return fail(c, "dxv_texels_download: texel output not enabled");
+    if (!host || bytes != c->gridBytes * 4) return fail(c, "dxv_texels_download: expected %zu bytes, got %zu", c->gridBytes * 4, bytes);
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, hipMemcpyAsync(host, c->dTexels, bytes, hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+size_t dxv_scene_bytes(const dxv_ctx* c) { return c && c->haveScene ? c->sceneBytes : 0; }
+
+int dxv_scene_export(dxv_ctx* c, void* dst, size_t bytes)
+{
+    if (!c) return 1;
+    if (!c->haveScene) return fail(c, "dxv_scene_export: no scene");
+    if (!dst || bytes != c->sceneBytes) return fail(c, "dxv_scene_export: expected %zu bytes, got %zu", c->sceneBytes, bytes);
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, hipMemcpyAsync(dst, c->dScene, bytes, hipMemcpyDeviceToDevice, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
+{
+    if (!c) return 1;
+    if (!src || bytes < sizeof(SceneHeader)) return fail(c, "dxv_scene_import: blob too small (%zu bytes)", bytes);
+    DXV_HIP(c, hipSetDevice(c->device));
+    SceneHeader h;
+    DXV_HIP(c, hipMemcpyAsync(&h, src, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    if (h.magic != kSceneMagic || h.version != kSceneVersion) return fail(c, "dxv_scene_import: bad magic/version");
+    SceneHeader want;
+    layout_scene(want, h.numTris, h.numVerts);
+    if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
+        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.treeHeight == 0 || h.treeHeight > 64)
+        return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
+    c->haveScene = false;
+    if (alloc_scene(c, h.numTris, h.numVerts)) return 1;
+    DXV_HIP(c, hipMemcpyAsync(c->dScene, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    c->hdr = h;
+    c->T = h.numTris; c->V = h.numVerts;
+    memcpy(c->bound, h.bound, sizeof(c->bound));
+    c->haveScene = true;
+    c->stats.num_tris = h.numTris; c->stats.num_verts = h.numVerts; c->stats.num_nodes = h.numNodes;
+    c->stats.tree_height = h.treeHeight;
+    memcpy(c->stats.bound, h.bound, sizeof(h.bound));
+    return 0;
+}
+
+int dxv_get_stats(const dxv_ctx* c, dxv_stats* out)
+{
+    if (!c || !out) return 1;
+    *out = c->stats;
+    return 0;
+}
+
+int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
+{
+    if (!c || !key) return 1;
+    if (!strcmp(key, "brick")) {
+        if (value < 0 || value >= num_brick_shapes()) return fail(c, "option brick: %lld out of range", (long long)value);
+        c->optBrick = (int)value;
+    } else if (!strcmp(key, "stack")) {
+        if (value != 0 && value != 16 && value != 24 && value != 32 && value != 48 && value != 64)
+            return fail(c, "option stack: %lld not in {0,16,24,32,48,64}", (long long)value);
+        c->optStack = (int)value;
+    } else if (!strcmp(key, "refit")) {
+        if (value != 0 && value != 1) return fail(c, "option refit: %lld not in {0,1}", (long long)value);
+        c->optRefit = (int)value;
+    } else return fail(c, "unknown option '%s'", key);
+    return 0;
+}
+
+int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
+{
+    if (!c || !host) return 1;
+    const void* src = nullptr;
+    size_t want = 0;
+    const size_t T = c->T;
+    switch (what) {
+    case DXV_DBG_SORTED_KEYS: src = c->dKeys; want = sizeof(uint64_t) * T; if (c->scratchT != c->T) src = nullptr; break;
+    case DXV_DBG_PARENTS: src = c->dParents; want = sizeof(uint32_t) * (2 * T - 1); if (c->scratchT != c->T) src = nullptr; break;
+    case DXV_DBG_NODES: if (c->haveScene) { src = scene_nodes(c); want = sizeof(Node) * (size_t)c->hdr.numNodes; } break;
+    case DXV_DBG_TRI_POS: if (c->haveScene) { src = scene_tripos(c); want = sizeof(TriPos) * T; } break;
+    case DXV_DBG_TRI_NRM: if (c->haveScene) { src = scene_trinrm(c); want = sizeof(TriNrm) * T; } break;
+    default: return fail(c, "dxv_debug_download: unknown selector %d", what);
+    }
+    if (!src) return fail(c, "dxv_debug_download: selector %d not available", what);
+    if (bytes != want) return fail(c, "dxv_debug_download: expected %zu bytes, got %zu", want, bytes);
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+} // extern "C"

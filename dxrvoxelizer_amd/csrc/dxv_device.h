@@ -1,0 +1,51 @@
+// dxv_device.h -- declarations shared by the HIP translation units of libdxv.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dxv_types.h"
+
+namespace dxv {
+
+// radix_sort.hip
+hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, hipStream_t s);
+uint32_t radix_sort_hist_words(uint32_t n);
+
+// lbvh.hip -- device-side build of the scene blob.
+struct BuildBuffers {
+    const float* vb;        // V x 6
+    const uint32_t* ib;     // 3T
+    uint32_t T, V;
+    float bound[4];
+    uint64_t* keys;         // T
+    uint64_t* keysTmp;      // T
+    uint32_t* hist;         // radix_sort_hist_words(T)
+    uint32_t* parents;      // (T-1) internal + T leaf words: (parent << 1) | side
+    uint32_t* flags;        // T-1 arrival counters (atomic refit) / ready flags (sweep refit)
+    uint32_t* flags2;       // T-1 (sweep refit ping-pong)
+    uint32_t* rootInfo;     // 8 words: rootLo[3], rootHi[3] (float bits), height, done
+    Node* nodes;            // max(T-1,1)
+    TriPos* triPos;         // T
+    TriNrm* triNrm;         // T
+};
+struct BuildTimes { float prep, sort, hierarchy, refit; };
+// refitMode: 0 = one pass, bottom-up with per-node arrival counters; 1 = level-synchronous sweeps
+hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[5]);
+
+// traverse.hip
+struct VoxelizeParams {
+    const Node* nodes;
+    const TriPos* triPos;
+    const TriNrm* triNrm;
+    uint8_t* grid;          // N*N*nz bytes
+    uint32_t* texels;       // optional N*N*nz words
+    uint32_t* status;       // status word (bit 0: traversal stack overflow)
+    uint32_t N, z0, nz;
+    int mode;
+    uint32_t treeHeight;
+};
+struct KernelChoice { int brick; int stackEntries; }; // brick: index into the brick-shape table
+hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int forceStack, hipStream_t s, uint32_t* stackUsed);
+hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
+int num_brick_shapes();
+
+} // namespace dxv

@@ -1,0 +1,267 @@
+// dxv_math.h -- the arithmetic of the hot path: ray generation, slab test, watertight
+// ray/triangle test, occupancy predicate, Morton keys and the Karras hierarchy rule.
+//
+// Everything is float32 with a FIXED operation order and no compiler contraction (the only
+// fused operations are the explicit fmaf calls); the translation units that include this file are
+// built with -ffp-contract=off.  Results therefore do not depend on BVH topology or traversal
+// order and are reproducible bit for bit on any IEEE-754 machine.
+//
+// Functions are __host__ __device__ so that tests can drive the very same code on the CPU
+// (tests/hostcheck); the shipped library only instantiates them in device kernels.
+//
+// Reference citations are relative to /root/reference/DXRVoxelizer/.
+#pragma once
+#include "dxv_types.h"
+
+#pragma clang fp contract(off)
+
+namespace dxv {
+
+DXV_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DXV_HD float min_(float a, float b) { return __builtin_fminf(a, b); }
+DXV_HD float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+DXV_HD float abs_(float a) { return __builtin_fabsf(a); }
+DXV_HD float sel3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
+
+// ------------------------------------------------------------------------------------------
+// Ray generation: Content/Shaders/DXRVoxelizer.hlsl:44-53 (generateRay), :64-67 (un-flatten).
+// ------------------------------------------------------------------------------------------
+struct Ray {
+    float ox, oy, oz;     // origin = voxel centre in [-1,1]^3, y flipped (hlsl:46,49)
+    float dx, dy, dz;     // direction
+    float ivx, ivy, ivz;  // 1/d
+    float nox, noy, noz;  // -(o * 1/d)
+    float Sx, Sy, Sz;     // watertight shear
+    int kx, ky, kz;       // watertight axis permutation
+};
+
+DXV_HD void ray_origin(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, float& ox, float& oy, float& oz)
+{
+    const float fn = (float)N;
+    ox = ((float)ix + 0.5f) / fn * 2.0f - 1.0f;          // hlsl:46
+    oy = -(((float)iy + 0.5f) / fn * 2.0f - 1.0f);       // hlsl:49
+    oz = ((float)iz + 0.5f) / fn * 2.0f - 1.0f;
+}
+
+DXV_HD void ray_shear(Ray& r)
+{
+    int kz = 0;
+    float m = abs_(r.dx);
+    if (abs_(r.dy) > m) { kz = 1; m = abs_(r.dy); }
+    if (abs_(r.dz) > m) { kz = 2; }
+    int kx = kz == 2 ? 0 : kz + 1;
+    int ky = kx == 2 ? 0 : kx + 1;
+    const float dkz = sel3(r.dx, r.dy, r.dz, kz);
+    if (dkz < 0.0f) { const int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = sel3(r.dx, r.dy, r.dz, kx) / dkz;
+    r.Sy = sel3(r.dx, r.dy, r.dz, ky) / dkz;
+    r.Sz = 1.0f / dkz;
+}
+
+// Reference mode: direction = normalize(pos) (hlsl:52); canonical form p / sqrtf((xx+yy)+zz).
+DXV_HD Ray make_ray_reference(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz)
+{
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    const float len = __builtin_sqrtf((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz);
+    r.dx = r.ox / len; r.dy = r.oy / len; r.dz = r.oz / len;
+    r.ivx = 1.0f / r.dx; r.ivy = 1.0f / r.dy; r.ivz = 1.0f / r.dz;
+    r.nox = -(r.ox * r.ivx); r.noy = -(r.oy * r.ivy); r.noz = -(r.oz * r.ivz);
+    ray_shear(r);
+    return r;
+}
+
+// Parity mode: +X axis ray from the same origin.
+DXV_HD Ray make_ray_parity(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz)
+{
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    r.dx = 1.0f; r.dy = 0.0f; r.dz = 0.0f;
+    r.ivx = 1.0f; r.ivy = 0.0f; r.ivz = 0.0f;   // unused in parity mode
+    r.nox = r.noy = r.noz = 0.0f;
+    r.kz = 0; r.kx = 1; r.ky = 2;
+    r.Sx = 0.0f; r.Sy = 0.0f; r.Sz = 1.0f;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Slab test.  t(plane) = fma(plane, 1/d, -(o/d)) is monotone in `plane`, so a box that contains
+// another never fails where the inner one passes and never reports a later entry: the LBVH can
+// not cull a triangle whose own box passes (BVH-topology independence).
+// ------------------------------------------------------------------------------------------
+DXV_HD bool slab(const Ray& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn)
+{
+    const float t0x = fma_(lox, r.ivx, r.nox), t1x = fma_(hix, r.ivx, r.nox);
+    const float t0y = fma_(loy, r.ivy, r.noy), t1y = fma_(hiy, r.ivy, r.noy);
+    const float t0z = fma_(loz, r.ivz, r.noz), t1z = fma_(hiz, r.ivz, r.noz);
+    tn = max_(max_(min_(t0x, t1x), min_(t0y, t1y)), max_(min_(t0z, t1z), 0.0f));
+    const float tf = min_(min_(max_(t0x, t1x), max_(t0y, t1y)), max_(t0z, t1z));
+    return tn <= tf;
+}
+
+// +X axis ray against a box (parity mode): origin inside the box's y/z extent and box not behind.
+DXV_HD bool slab_parity(const Ray& r, float loy, float loz, float hix, float hiy, float hiz)
+{
+    return loy <= r.oy && r.oy <= hiy && loz <= r.oz && r.oz <= hiz && hix >= r.ox;
+}
+
+// ------------------------------------------------------------------------------------------
+// Watertight ray/triangle test (Woop, Benthin, Wald: "Watertight Ray/Triangle Intersection",
+// JCGT 2013), both faces, strict 0 < t < TMax (DXR triangle rule; hlsl:76-77).  Edge functions
+// are rounded products subtracted without fusion, so the value an edge gets from its two
+// incident triangles is exactly antisymmetric; exact zeros are re-evaluated in double.
+// Barycentrics as DXR reports them: b1 = weight of vertex 1, b2 = weight of vertex 2
+// (hlsl:110-116).
+// FILL (parity mode): an edge function that is exactly zero takes the sign it has at the
+// symbolically perturbed origin o + (eps, eps^2), so a ray through a shared edge or vertex is
+// counted for exactly one incident triangle.
+// ------------------------------------------------------------------------------------------
+template <bool FILL>
+DXV_HD bool tri_test(const Ray& r, const F4& v0, const F4& v1, const F4& v2, float& t, float& b1, float& b2)
+{
+    const float ax = v0.x - r.ox, ay = v0.y - r.oy, az = v0.z - r.oz;
+    const float bx = v1.x - r.ox, by = v1.y - r.oy, bz = v1.z - r.oz;
+    const float cx = v2.x - r.ox, cy = v2.y - r.oy, cz = v2.z - r.oz;
+    const float akz = sel3(ax, ay, az, r.kz), bkz = sel3(bx, by, bz, r.kz), ckz = sel3(cx, cy, cz, r.kz);
+    const float nSx = -r.Sx, nSy = -r.Sy;
+    const float Ax = fma_(nSx, akz, sel3(ax, ay, az, r.kx)), Ay = fma_(nSy, akz, sel3(ax, ay, az, r.ky));
+    const float Bx = fma_(nSx, bkz, sel3(bx, by, bz, r.kx)), By = fma_(nSy, bkz, sel3(bx, by, bz, r.ky));
+    const float Cx = fma_(nSx, ckz, sel3(cx, cy, cz, r.kx)), Cy = fma_(nSy, ckz, sel3(cx, cy, cz, r.ky));
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    float su = U, sv = V, sw = W;
+    if (FILL) {
+        // U's edge runs C->B, V's A->C, W's B->A; perturbed sign = (ey != 0) ? -ey : ex
+        if (su == 0.0f) { const float ey = By - Cy, ex = Bx - Cx; su = ey != 0.0f ? -ey : ex; }
+        if (sv == 0.0f) { const float ey = Cy - Ay, ex = Cx - Ax; sv = ey != 0.0f ? -ey : ex; }
+        if (sw == 0.0f) { const float ey = Ay - By, ex = Ax - Bx; sw = ey != 0.0f ? -ey : ex; }
+        if (su == 0.0f || sv == 0.0f || sw == 0.0f) return false;
+    }
+    if ((su < 0.0f || sv < 0.0f || sw < 0.0f) && (su > 0.0f || sv > 0.0f || sw > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (det == 0.0f) return false;
+    const float Az = r.Sz * akz, Bz = r.Sz * bkz, Cz = r.Sz * ckz;
+    const float T = (U * Az + V * Bz) + W * Cz;
+    t = T / det;
+    if (!(t > 0.0f && t < kTMax)) return false;
+    b1 = V / det;
+    b2 = W / det;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Closest-hit predicate: hlsl:110-116 (normal interpolation), :137-138 (test), :5 (threshold).
+// ------------------------------------------------------------------------------------------
+DXV_HD bool predicate(const Ray& r, const F4& n0, const F4& n1, const F4& n2, float b1, float b2,
+                      float& nx, float& ny, float& nz)
+{
+    nx = (n0.x + b1 * (n1.x - n0.x)) + b2 * (n2.x - n0.x);
+    ny = (n0.y + b1 * (n1.y - n0.y)) + b2 * (n2.y - n0.y);
+    nz = (n0.z + b1 * (n1.z - n0.z)) + b2 * (n2.z - n0.z);
+    const float l = __builtin_sqrtf((nx * nx + ny * ny) + nz * nz);
+    nx = nx / l; ny = ny / l; nz = nz / l;
+    return ((nx * r.dx + ny * r.dy) + nz * r.dz) > kThreshold;
+}
+
+// float4(Normal, 1) stored to R10G10B10A2_UNORM (hlsl:84, Content/Voxelizer.cpp:65):
+// D3D float->UNORM = clamp to [0,1] (NaN -> 0), scale, round to nearest.
+DXV_HD uint32_t unorm10(float v)
+{
+    if (!(v > 0.0f)) v = 0.0f;
+    if (v > 1.0f) v = 1.0f;
+    return (uint32_t)(v * 1023.0f + 0.5f);
+}
+DXV_HD uint32_t pack_texel(float nx, float ny, float nz)
+{
+    return unorm10(nx) | (unorm10(ny) << 10) | (unorm10(nz) << 20) | (3u << 30);
+}
+
+// ------------------------------------------------------------------------------------------
+// Triangle preparation: normalising transform (Content/Voxelizer.cpp:52-57, :304-306) and the
+// canonical padded box.
+// ------------------------------------------------------------------------------------------
+DXV_HD F4 normalise_pos(const float* p, const float* bound)
+{
+    F4 q;
+    q.x = (p[0] - bound[0]) / bound[3];
+    q.y = (p[1] - bound[1]) / bound[3];
+    q.z = (p[2] - bound[2]) / bound[3];
+    q.w = 0.0f;
+    return q;
+}
+
+DXV_HD void tri_box(const F4& a, const F4& b, const F4& c, float lo[3], float hi[3])
+{
+    lo[0] = min_(min_(a.x, b.x), c.x) - kPad; hi[0] = max_(max_(a.x, b.x), c.x) + kPad;
+    lo[1] = min_(min_(a.y, b.y), c.y) - kPad; hi[1] = max_(max_(a.y, b.y), c.y) + kPad;
+    lo[2] = min_(min_(a.z, b.z), c.z) - kPad; hi[2] = max_(max_(a.z, b.z), c.z) + kPad;
+}
+
+// ------------------------------------------------------------------------------------------
+// Morton keys (30 bits over the centre of the padded box) and the Karras 2012 hierarchy rule.
+// Keys are (morton << 32) | triangle index: unique, so the tree is deterministic.
+// ------------------------------------------------------------------------------------------
+DXV_HD uint32_t expand_bits10(uint32_t v)
+{
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+DXV_HD uint32_t quant10(float c)
+{
+    float u = (c * 0.5f + 0.5f) * 1024.0f;
+    if (!(u > 0.0f)) u = 0.0f;
+    if (u > 1023.0f) u = 1023.0f;
+    return (uint32_t)u;
+}
+
+DXV_HD uint64_t morton_key(const float lo[3], const float hi[3], uint32_t k)
+{
+    const uint32_t qx = quant10((lo[0] + hi[0]) * 0.5f);
+    const uint32_t qy = quant10((lo[1] + hi[1]) * 0.5f);
+    const uint32_t qz = quant10((lo[2] + hi[2]) * 0.5f);
+    const uint32_t m = (expand_bits10(qx) << 2) | (expand_bits10(qy) << 1) | expand_bits10(qz);
+    return ((uint64_t)m << 32) | (uint64_t)k;
+}
+
+DXV_HD int key_delta(const uint64_t* keys, int64_t T, int64_t i, int64_t j)
+{
+    if (j < 0 || j >= T) return -1;
+    return __builtin_clzll(keys[i] ^ keys[j]);
+}
+
+// Internal node i of T-1 (T >= 2): children as links (>= 0 internal, < 0 ~leaf).
+DXV_HD void karras_node(const uint64_t* keys, int64_t T, int64_t i, int32_t& left, int32_t& right)
+{
+    const int d = key_delta(keys, T, i, i + 1) - key_delta(keys, T, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = key_delta(keys, T, i, i - d);
+    int64_t lmax = 2;
+    while (key_delta(keys, T, i, i + lmax * d) > dmin) lmax *= 2;
+    int64_t l = 0;
+    for (int64_t t = lmax / 2; t >= 1; t /= 2)
+        if (key_delta(keys, T, i, i + (l + t) * d) > dmin) l += t;
+    const int64_t j = i + l * d;
+    const int dnode = key_delta(keys, T, i, j);
+    int64_t s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (key_delta(keys, T, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+    left = lo == gamma ? ~(int32_t)gamma : (int32_t)gamma;
+    right = hi == gamma + 1 ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
+}
+
+} // namespace dxv

@@ -1,0 +1,124 @@
+// dxv_trace.h -- per-ray traversal of the LBVH (one ray = one voxel = one thread).
+//
+// Replaces TraceRay(g_scene, RAY_FLAG_NONE, ~0, 0, 1, 0, ray, payload)
+// (Content/Shaders/DXRVoxelizer.hlsl:80) and the driver traversal behind it.
+//
+// Canonical acceptance of triangle k for a ray (topology independent):
+//   reference mode: the triangle's own padded box passes slab() with entry tn, the watertight
+//     test reports 0 < t < TMax, and tn <= t.  Closest hit = lexicographic min of (t, k).
+//   parity mode: the box passes slab_parity() and the watertight test with fill rule reports
+//     t > 0; every accepted triangle counts once.
+// Because slab() is monotone under box inclusion, culling a node whose entry distance exceeds
+// the current closest t can never drop an acceptable triangle.
+//
+// Leaves never enter the stack: a hit leaf child is intersected while its parent is visited
+// (its entry distance is at hand there), so the stack holds internal nodes only and its depth
+// is bounded by the tree height.
+#pragma once
+#include "dxv_math.h"
+
+namespace dxv {
+
+struct Hit {
+    float t, b1, b2;
+    uint32_t k;     // triangle index in the caller's index buffer; 0xffffffff = miss
+    int32_t leaf;   // position in Morton order
+};
+
+// Stack policy: entry e of this thread lives at base[e * stride] (LDS column on the device).
+struct StridedStack {
+    int32_t* base;
+    int stride;
+    DXV_HD void put(int e, int32_t v) const { base[e * stride] = v; }
+    DXV_HD int32_t get(int e) const { return base[e * stride]; }
+};
+
+DXV_HD void load_node(const Node* nodes, int32_t i, F4& q0, F4& q1, F4& q2, int32_t& c0, int32_t& c1)
+{
+    const F4* p = reinterpret_cast<const F4*>(nodes + i);
+    q0 = p[0]; q1 = p[1]; q2 = p[2];
+    const F4 q3 = p[3];
+    c0 = __builtin_bit_cast(int32_t, q3.x);
+    c1 = __builtin_bit_cast(int32_t, q3.y);
+}
+
+DXV_HD void leaf_reference(const Ray& r, const TriPos* tris, int32_t leaf, float tn, Hit& best)
+{
+    const TriPos tp = tris[leaf];
+    float t, b1, b2;
+    if (!tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2)) return;
+    if (tn > t) return;
+    const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
+    if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = b1; best.b2 = b2; best.k = k; best.leaf = leaf; }
+}
+
+// Returns false when the stack capacity was exceeded (caller reports the error).
+template <class Stack>
+DXV_HD bool trace_reference(const Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best)
+{
+    best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
+    int sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        F4 q0, q1, q2;
+        int32_t c0, c1;
+        load_node(nodes, node, q0, q1, q2, c0, c1);
+        float tn0, tn1;
+        bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= best.t;
+        bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= best.t;
+        if (h0 && c0 < 0) { leaf_reference(r, tris, ~c0, tn0, best); h0 = false; }
+        if (h1 && c1 < 0) { leaf_reference(r, tris, ~c1, tn1, best); h1 = false; }
+        h0 = h0 && tn0 <= best.t;
+        h1 = h1 && tn1 <= best.t;
+        if (h0 && h1) {
+            const bool swap = tn1 < tn0;
+            const int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+            if (sp >= cap) return false;
+            stk.put(sp++, farc);
+            node = nearc;
+        } else if (h0) node = c0;
+        else if (h1) node = c1;
+        else {
+            if (sp == 0) break;
+            node = stk.get(--sp);
+        }
+    }
+    return true;
+}
+
+DXV_HD uint32_t leaf_parity(const Ray& r, const TriPos* tris, int32_t leaf)
+{
+    const TriPos tp = tris[leaf];
+    float t, b1, b2;
+    return tri_test<true>(r, tp.v0, tp.v1, tp.v2, t, b1, b2) ? 1u : 0u;
+}
+
+template <class Stack>
+DXV_HD bool trace_parity(const Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, uint32_t& count)
+{
+    count = 0;
+    int sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        F4 q0, q1, q2;
+        int32_t c0, c1;
+        load_node(nodes, node, q0, q1, q2, c0, c1);
+        bool h0 = slab_parity(r, q0.y, q0.z, q0.w, q1.x, q1.y);
+        bool h1 = slab_parity(r, q1.w, q2.x, q2.y, q2.z, q2.w);
+        if (h0 && c0 < 0) { count += leaf_parity(r, tris, ~c0); h0 = false; }
+        if (h1 && c1 < 0) { count += leaf_parity(r, tris, ~c1); h1 = false; }
+        if (h0 && h1) {
+            if (sp >= cap) return false;
+            stk.put(sp++, c1);
+            node = c0;
+        } else if (h0) node = c0;
+        else if (h1) node = c1;
+        else {
+            if (sp == 0) break;
+            node = stk.get(--sp);
+        }
+    }
+    return true;
+}
+
+} // namespace dxv

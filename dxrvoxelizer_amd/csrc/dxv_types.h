@@ -1,0 +1,59 @@
+// dxv_types.h -- device data layout of the scene (HBM resident) shared by the build kernels,
+// the traversal kernels and the host-side API.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DXV_HD __host__ __device__ __forceinline__
+#else
+#define DXV_HD inline
+#endif
+
+namespace dxv {
+
+struct alignas(16) F4 { float x, y, z, w; };
+
+// Internal LBVH node, 64 B = four 16-B loads.  Aila/Laine-style: a node carries the boxes of
+// BOTH children, so one fetch decides both descents.  Child link >= 0: internal node index;
+// < 0: ~leaf, leaf = position in Morton order (index into TriPos/TriNrm).
+struct alignas(64) Node {
+    float lo0x, lo0y, lo0z, hi0x;   // q0
+    float hi0y, hi0z, lo1x, lo1y;   // q1
+    float lo1z, hi1x, hi1y, hi1z;   // q2
+    int32_t c0, c1;                 // q3.x, q3.y
+    uint32_t h0, h1;                // q3.z, q3.w: heights of the child subtrees (leaf = 0)
+};
+static_assert(sizeof(Node) == 64, "node is 64 B");
+
+// Leaf payload in Morton order.  Positions are pre-mapped to the reference's normalised space
+// p' = (p - c) / w (Content/Voxelizer.cpp:304-306).  v0.w carries the triangle's index in the
+// caller's index buffer (PrimitiveIndex(), hlsl:93) as raw bits.
+struct alignas(16) TriPos { F4 v0, v1, v2; };
+// Vertex normals of the same triangle (hlsl:102-107, :114-116), fetched once per ray at the end.
+struct alignas(16) TriNrm { F4 n0, n1, n2; };
+
+// Relocatable scene blob: [SceneHeader | nodes | triPos | triNrm], every section 256-B aligned.
+struct SceneHeader {
+    uint32_t magic;       // 'DXVS'
+    uint32_t version;
+    uint32_t numTris;
+    uint32_t numVerts;
+    uint32_t numNodes;    // max(T-1, 1)
+    uint32_t treeHeight;  // height of the root (levels of internal nodes)
+    float bound[4];
+    float rootLo[3], rootHi[3];
+    uint64_t offNodes, offTriPos, offTriNrm, totalBytes;
+    uint32_t pad[32];
+};
+static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
+
+constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
+constexpr uint32_t kSceneVersion = 1;
+
+// canonical constants (hlsl:5, :76-77)
+constexpr float kThreshold = 0.12f;
+constexpr float kTMax = 10000.0f;
+constexpr float kPad = 1.52587890625e-05f; // 2^-16, outward pad of every per-triangle box
+
+} // namespace dxv

@@ -1,0 +1,242 @@
+// lbvh.hip -- on-device LBVH build: replaces the driver BLAS/TLAS build behind
+// Voxelizer::buildAccelerationStructures (Content/Voxelizer.cpp:264-326).
+//
+//   K1  k_tri_keys     per triangle: gather 3 positions through the index buffer, map to the
+//                      reference's normalised space, padded box, 30-bit Morton key | index
+//   K2  radix sort     radix_sort.hip
+//   K2b k_tri_gather   per Morton slot: write the 48-B position and normal records
+//   K3  k_hierarchy    Karras 2012, one thread per internal node, parent links
+//   K4  k_refit_*      bottom-up box merge; a node stores the boxes of BOTH children
+//
+// All kernels are HBM-streaming integer/float work: one thread per element, 16-B accesses where
+// the layout allows, no LDS needed outside the sort.
+#include "dxv_device.h"
+#include "dxv_math.h"
+
+namespace dxv {
+
+constexpr int kThreads = 256;
+static inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kThreads - 1) / kThreads); }
+
+struct Bound4 { float c[4]; };
+
+__device__ __forceinline__ void gather_tri(const float* __restrict__ vb, const uint32_t* __restrict__ ib, uint32_t k,
+                                           const Bound4& bnd, F4& a, F4& b, F4& c, uint32_t idx[3])
+{
+    idx[0] = ib[3ull * k]; idx[1] = ib[3ull * k + 1]; idx[2] = ib[3ull * k + 2];
+    a = normalise_pos(vb + 6ull * idx[0], bnd.c);
+    b = normalise_pos(vb + 6ull * idx[1], bnd.c);
+    c = normalise_pos(vb + 6ull * idx[2], bnd.c);
+}
+
+__global__ __launch_bounds__(kThreads) void k_tri_keys(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
+                                                       uint32_t T, Bound4 bnd, uint64_t* __restrict__ keys)
+{
+    const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= T) return;
+    F4 a, b, c;
+    uint32_t idx[3];
+    gather_tri(vb, ib, k, bnd, a, b, c, idx);
+    float lo[3], hi[3];
+    tri_box(a, b, c, lo, hi);
+    keys[k] = morton_key(lo, hi, k);
+}
+
+__global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
+                                                         uint32_t T, Bound4 bnd, const uint64_t* __restrict__ keys,
+                                                         TriPos* __restrict__ triPos, TriNrm* __restrict__ triNrm)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= T) return;
+    const uint32_t k = (uint32_t)(keys[i] & 0xffffffffull);
+    F4 a, b, c;
+    uint32_t idx[3];
+    gather_tri(vb, ib, k, bnd, a, b, c, idx);
+    a.w = __builtin_bit_cast(float, k);
+    TriPos tp; tp.v0 = a; tp.v1 = b; tp.v2 = c;
+    triPos[i] = tp;
+    TriNrm tn;
+    const float* n0 = vb + 6ull * idx[0] + 3;
+    const float* n1 = vb + 6ull * idx[1] + 3;
+    const float* n2 = vb + 6ull * idx[2] + 3;
+    tn.n0 = F4{n0[0], n0[1], n0[2], 0.0f};
+    tn.n1 = F4{n1[0], n1[1], n1[2], 0.0f};
+    tn.n2 = F4{n2[0], n2[1], n2[2], 0.0f};
+    triNrm[i] = tn;
+}
+
+// parents[0 .. T-2]: internal nodes, parents[T-1 .. 2T-2]: leaves; word = (parent << 1) | side.
+__global__ __launch_bounds__(kThreads) void k_hierarchy(const uint64_t* __restrict__ keys, uint32_t T,
+                                                        Node* __restrict__ nodes, uint32_t* __restrict__ parents)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= T - 1) return;
+    int32_t l, r;
+    karras_node(keys, (int64_t)T, (int64_t)i, l, r);
+    nodes[i].c0 = l;
+    nodes[i].c1 = r;
+    parents[l >= 0 ? (uint32_t)l : (T - 1) + (uint32_t)~l] = (i << 1);
+    parents[r >= 0 ? (uint32_t)r : (T - 1) + (uint32_t)~r] = (i << 1) | 1u;
+    if (i == 0) parents[0] = 0xffffffffu;
+}
+
+__device__ __forceinline__ void store_child(Node* node, uint32_t side, const float lo[3], const float hi[3], uint32_t h)
+{
+    float* w = reinterpret_cast<float*>(node) + 6 * side; // words 0..5: child 0 box, 6..11: child 1 box
+    w[0] = lo[0]; w[1] = lo[1]; w[2] = lo[2]; w[3] = hi[0]; w[4] = hi[1]; w[5] = hi[2];
+    if (side) node->h1 = h; else node->h0 = h;
+}
+
+__device__ __forceinline__ void load_child(const Node* node, uint32_t side, float lo[3], float hi[3], uint32_t& h)
+{
+    const float* w = reinterpret_cast<const float*>(node) + 6 * side;
+    lo[0] = w[0]; lo[1] = w[1]; lo[2] = w[2]; hi[0] = w[3]; hi[1] = w[4]; hi[2] = w[5];
+    h = side ? node->h1 : node->h0;
+}
+
+// K4, one pass: each leaf thread climbs; at every node the first arrival stops, the second
+// merges.  Inter-workgroup hand-off follows the agent-scope release/acquire recipe: plain
+// stores -> release fence -> drained -> relaxed agent atomic; the consumer fences (acquire)
+// before its plain loads.  Results are order independent (min/max).
+__global__ __launch_bounds__(kThreads) void k_refit_atomic(const TriPos* __restrict__ triPos, uint32_t T,
+                                                           Node* __restrict__ nodes, const uint32_t* __restrict__ parents,
+                                                           uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= T) return;
+    float lo[3], hi[3];
+    {
+        const TriPos tp = triPos[i];
+        tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+    }
+    uint32_t h = 0;
+    uint32_t word = parents[(T - 1) + i];
+    for (;;) {
+        const uint32_t p = word >> 1, side = word & 1u;
+        store_child(&nodes[p], side, lo, hi, h);
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t old = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __threadfence();
+        float slo[3], shi[3];
+        uint32_t sh;
+        load_child(&nodes[p], side ^ 1u, slo, shi, sh);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = min_(lo[a], slo[a]); hi[a] = max_(hi[a], shi[a]); }
+        h = (h > sh ? h : sh) + 1;
+        if (p == 0) return;
+        word = parents[p];
+    }
+}
+
+// K4, level-synchronous alternative: a node is finished in the sweep after both children are.
+// `ready` of the previous sweep is read-only; kernel boundaries give the visibility.
+__global__ __launch_bounds__(kThreads) void k_refit_sweep(const TriPos* __restrict__ triPos, uint32_t T,
+                                                          Node* __restrict__ nodes, const uint32_t* __restrict__ readyPrev,
+                                                          uint32_t* __restrict__ readyNext)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= T - 1) return;
+    if (readyPrev[i]) { readyNext[i] = 1; return; }
+    const int32_t c[2] = {nodes[i].c0, nodes[i].c1};
+    if ((c[0] >= 0 && !readyPrev[c[0]]) || (c[1] >= 0 && !readyPrev[c[1]])) { readyNext[i] = 0; return; }
+#pragma unroll
+    for (uint32_t side = 0; side < 2; ++side) {
+        float lo[3], hi[3];
+        uint32_t h = 0;
+        if (c[side] < 0) {
+            const TriPos tp = triPos[~c[side]];
+            tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+        } else {
+            float lo1[3], hi1[3];
+            uint32_t h0, h1;
+            load_child(&nodes[c[side]], 0, lo, hi, h0);
+            load_child(&nodes[c[side]], 1, lo1, hi1, h1);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = min_(lo[a], lo1[a]); hi[a] = max_(hi[a], hi1[a]); }
+            h = (h0 > h1 ? h0 : h1) + 1;
+        }
+        store_child(&nodes[i], side, lo, hi, h);
+    }
+    readyNext[i] = 1;
+}
+
+// T == 1: one node, the second child is a far-away dummy that no ray accepts.
+__global__ void k_single_tri(const TriPos* __restrict__ triPos, Node* __restrict__ nodes)
+{
+    float lo[3], hi[3];
+    const TriPos tp = triPos[0];
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+    store_child(&nodes[0], 0, lo, hi, 0);
+    const float far[3] = {1e30f, 1e30f, 1e30f};
+    store_child(&nodes[0], 1, far, far, 0);
+    nodes[0].c0 = ~0;
+    nodes[0].c1 = ~0;
+}
+
+// rootInfo: lo[3], hi[3] (float bits), height of the root, 1
+__global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict__ rootInfo)
+{
+    float lo[3], hi[3], lo1[3], hi1[3];
+    uint32_t h0, h1;
+    load_child(&nodes[0], 0, lo, hi, h0);
+    load_child(&nodes[0], 1, lo1, hi1, h1);
+    for (int a = 0; a < 3; ++a) {
+        rootInfo[a] = __builtin_bit_cast(uint32_t, min_(lo[a], lo1[a]));
+        rootInfo[3 + a] = __builtin_bit_cast(uint32_t, max_(hi[a], hi1[a]));
+    }
+    rootInfo[6] = (h0 > h1 ? h0 : h1) + 1;
+    rootInfo[7] = 1;
+}
+
+hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[5])
+{
+    const uint32_t T = b.T;
+    Bound4 bnd;
+    for (int a = 0; a < 4; ++a) bnd.c[a] = b.bound[a];
+    const uint32_t numNodes = T > 1 ? T - 1 : 1;
+    hipError_t e;
+    // poison the nodes (all-ones = NaN boxes): a box that was never merged cannot pass a slab test
+    if ((e = hipMemsetAsync(b.nodes, 0xff, sizeof(Node) * (size_t)numNodes, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
+
+    (void)hipEventRecord(ev[0], s);
+    k_tri_keys<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys);
+    (void)hipEventRecord(ev[1], s);
+    if (T > 1) {
+        if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;
+    }
+    (void)hipEventRecord(ev[2], s);
+    k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm);
+    if (T == 1) {
+        k_single_tri<<<1, 1, 0, s>>>(b.triPos, b.nodes);
+        (void)hipEventRecord(ev[3], s);
+    } else {
+        k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents);
+        (void)hipEventRecord(ev[3], s);
+        if ((e = hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * (size_t)(T - 1), s)) != hipSuccess) return e;
+        if (refitMode == 0) {
+            k_refit_atomic<<<blocks_for(T), kThreads, 0, s>>>(b.triPos, T, b.nodes, b.parents, b.flags);
+        } else {
+            // tree height <= 62 (distinct 62-bit keys); sweep in batches until the root is ready
+            uint32_t* prev = b.flags;
+            uint32_t* next = b.flags2;
+            uint32_t rootReady = 0;
+            for (int batch = 0; batch < 16 && !rootReady; ++batch) {
+                for (int it = 0; it < 8; ++it) {
+                    k_refit_sweep<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, b.nodes, prev, next);
+                    uint32_t* t = prev; prev = next; next = t;
+                }
+                if ((e = hipMemcpyAsync(&rootReady, prev, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+                if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+            }
+            if (!rootReady) return hipErrorUnknown;
+        }
+    }
+    k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo);
+    (void)hipEventRecord(ev[4], s);
+    return hipGetLastError();
+}
+
+} // namespace dxv

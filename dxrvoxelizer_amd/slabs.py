@@ -1,0 +1,65 @@
+"""Multi-GPU host logic: Z-slab partition of the grid and the one-off scene broadcast.
+
+The path shards without any per-frame exchange: every voxel is an independent ray against a
+read-only scene (Content/Shaders/DXRVoxelizer.hlsl:58-85, each thread writes only its own
+texel, :84) and Z is the slowest grid axis (iz = dyz / N, :66), so rank r of W owns slices
+[z0, z0 + nz) = one contiguous N*N*nz-byte block of the output.  The only collective is one
+broadcast of the built scene blob (rank 0 builds the LBVH; RCCL over xGMI when the backend is
+nccl), once per mesh.  One process per GPU.
+"""
+import numpy as np
+
+
+def slab_range(N, rank, world):
+    """Contiguous, near-equal split of N slices over `world` ranks: (z0, nz), nz may be 0."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(int(N), int(world))
+    nz = base + (1 if rank < rem else 0)
+    z0 = rank * base + min(rank, rem)
+    return z0, nz
+
+
+def interleaved_blocks(N, rank, world, block):
+    """Load-balanced alternative (SURVEY section 8(e) caveat): blocks of `block` slices dealt
+    round-robin; returns the list of (z0, nz) this rank owns. Still no collective."""
+    out = []
+    for b, z0 in enumerate(range(0, int(N), int(block))):
+        if b % world == rank:
+            out.append((z0, min(int(block), int(N) - z0)))
+    return out
+
+
+def broadcast_scene(engine, dist, device, src=0):
+    """Broadcast the built scene from rank `src` to every rank of the default process group.
+
+    engine: object with scene_bytes() / scene_export(ptr, n) / scene_import(ptr, n) working on
+    memory of `device` (dxrvoxelizer_amd.Voxelizer for 'cuda', a host stand-in in the gloo tests).
+    dist: torch.distributed (initialised).  Returns the blob size in bytes."""
+    import torch
+
+    rank = dist.get_rank()
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        n[0] = engine.scene_bytes()
+    dist.broadcast(n, src=src)
+    nbytes = int(n.item())
+    if nbytes <= 0:
+        raise RuntimeError("broadcast_scene: source rank has no built scene")
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if rank == src:
+        engine.scene_export(blob.data_ptr(), nbytes)
+        if device != "cpu" and str(device) != "cpu":
+            torch.cuda.synchronize()
+    dist.broadcast(blob, src=src)
+    if rank != src:
+        if str(device) != "cpu":
+            torch.cuda.synchronize()
+        engine.scene_import(blob.data_ptr(), nbytes)
+    return nbytes
+
+
+def gather_slabs(parts):
+    """Concatenate per-rank slabs [(z0, grid[nz,N,N]), ...] into the full grid (host side)."""
+    parts = sorted(parts, key=lambda p: p[0])
+    return np.concatenate([g for _, g in parts if g.shape[0]], axis=0)

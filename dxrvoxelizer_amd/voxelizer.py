@@ -1,0 +1,146 @@
+"""Python mirror of the reference's Voxelizer component (Content/Voxelizer.h:10-24) over the
+C-ABI, used by tests and bench.py.  Same call order as the reference: Init (load, upload, bound,
+build acceleration structure) then Voxelize per frame."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._lib import DxvError, Stats, load_library
+
+MODE_REFERENCE, MODE_PARITY = 0, 1
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS = range(5)
+
+
+def obj_load(path):
+    """(vb [V,6] f32, ib [3T] u32, aabb [6] f32) exactly as XUSG::ObjLoader::Import(path, true, true)
+    (XUSG/Optional/XUSGObjLoader.cpp:18-40) -- the product's own loader (csrc/obj_ingest.cpp)."""
+    lib = load_library()
+    vb, ib = C.POINTER(C.c_float)(), C.POINTER(C.c_uint32)()
+    nv, ni = C.c_uint32(), C.c_uint32()
+    aabb = np.zeros(6, np.float32)
+    rc = lib.dxv_obj_load(os.fsencode(path), C.byref(vb), C.byref(nv), C.byref(ib), C.byref(ni), aabb)
+    if rc:
+        raise DxvError(f"dxv_obj_load({path!r}) failed with code {rc}")
+    try:
+        return (np.ctypeslib.as_array(vb, (nv.value, 6)).copy(), np.ctypeslib.as_array(ib, (ni.value,)).copy(), aabb)
+    finally:
+        lib.dxv_free(vb)
+        lib.dxv_free(ib)
+
+
+class Voxelizer:
+    """bool-returning calls of the reference become exceptions (DxvError) here."""
+
+    FrameCount = 3  # Content/Voxelizer.h:24
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        if self._lib.dxv_create(C.byref(self._ctx), int(device)):
+            raise DxvError(self._lib.dxv_last_error(None).decode())
+        self.device = int(device)
+        self._last = None
+
+    # ---- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.dxv_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise DxvError(self._lib.dxv_last_error(self._ctx).decode())
+
+    # ---- reference surface ------------------------------------------------------------------
+    def Init(self, fileName, posScale=(0.0, 0.0, 0.0, 1.0)):
+        """Voxelizer::Init (Content/Voxelizer.cpp:30-79) minus the D3D12 arguments."""
+        vb, ib, _ = obj_load(fileName)
+        return self.InitFromArrays(vb, ib, posScale)
+
+    def InitFromArrays(self, vb, ib, posScale=(0.0, 0.0, 0.0, 1.0)):
+        self.posScale = tuple(posScale)  # display only in the reference (Voxelizer.cpp:84-87)
+        vb = np.ascontiguousarray(vb, np.float32).reshape(-1, 6)
+        ib = np.ascontiguousarray(ib, np.uint32).reshape(-1)
+        if ib.size % 3:
+            raise DxvError("index count is not a multiple of 3")
+        self._check(self._lib.dxv_set_mesh(self._ctx, vb, len(vb), ib, ib.size // 3))
+        self._check(self._lib.dxv_build(self._ctx))
+        return True
+
+    def Voxelize(self, gridDim, mode=MODE_REFERENCE, z0=0, nz=None, sync=True):
+        """Voxelizer::voxelize (Content/Voxelizer.cpp:351-369) with gridDim as a parameter."""
+        nz = gridDim - z0 if nz is None else nz
+        fn = self._lib.dxv_voxelize if sync else self._lib.dxv_voxelize_async
+        self._check(fn(self._ctx, int(gridDim), int(mode), int(z0), int(nz)))
+        self._last = (int(gridDim), int(nz))
+        return True
+
+    def Sync(self):
+        self._check(self._lib.dxv_sync(self._ctx))
+
+    # ---- results ----------------------------------------------------------------------------
+    def Grid(self):
+        """uint8 [nz, N, N] (z, y top->bottom, x) copy of the device grid."""
+        n, nz = self._last
+        out = np.empty((nz, n, n), np.uint8)
+        self._check(self._lib.dxv_grid_download(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def Texels(self):
+        n, nz = self._last
+        out = np.empty((nz, n, n), np.uint32)
+        self._check(self._lib.dxv_texels_download(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def EnableTexels(self, on=True):
+        self._check(self._lib.dxv_enable_texels(self._ctx, int(bool(on))))
+
+    def CountSolid(self):
+        v = C.c_uint64()
+        self._check(self._lib.dxv_grid_count(self._ctx, C.byref(v)))
+        return v.value
+
+    def grid_device_ptr(self):
+        return self._lib.dxv_grid_device_ptr(self._ctx)
+
+    def grid_bytes(self):
+        return self._lib.dxv_grid_bytes(self._ctx)
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        self._check(self._lib.dxv_set_stream(self._ctx, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_option(self, key, value):
+        self._check(self._lib.dxv_set_option(self._ctx, key.encode(), int(value)))
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.dxv_get_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    def scene_bytes(self):
+        return self._lib.dxv_scene_bytes(self._ctx)
+
+    def scene_export(self, device_ptr, nbytes):
+        self._check(self._lib.dxv_scene_export(self._ctx, C.c_void_p(device_ptr), nbytes))
+
+    def scene_import(self, device_ptr, nbytes):
+        self._check(self._lib.dxv_scene_import(self._ctx, C.c_void_p(device_ptr), nbytes))
+
+    def debug(self, what):
+        st = self.stats()
+        T = st["num_tris"]
+        shapes = {DBG_SORTED_KEYS: ((T,), np.uint64), DBG_NODES: ((st["num_nodes"], 16), np.uint32),
+                  DBG_TRI_POS: ((T, 12), np.float32), DBG_TRI_NRM: ((T, 12), np.float32),
+                  DBG_PARENTS: ((2 * T - 1,), np.uint32)}
+        shape, dt = shapes[what]
+        out = np.empty(shape, dt)
+        self._check(self._lib.dxv_debug_download(self._ctx, what, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out

@@ -1,0 +1,136 @@
+/*
+ * dxv.h -- C-ABI of the MI355X-native DXRVoxelizer hot path (libdxv.so).
+ *
+ * Plain C: opaque context, plain pointers and sizes, int return codes (0 = ok, message through
+ * dxv_last_error).  No HIP, torch or C++ types cross this boundary.  Each entry point names the
+ * reference interface it replaces; paths are relative to /root/reference/DXRVoxelizer/.
+ *
+ * One context drives one GPU (one process per GPU; see INTEGRATION.md for the multi-GPU slab
+ * scheme and the cgo/ctypes/C++ bindings a maintainer of the reference would add).
+ */
+#ifndef DXV_H
+#define DXV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DXV_API __attribute__((visibility("default")))
+
+typedef struct dxv_ctx dxv_ctx;
+
+/* Occupancy rule. */
+enum {
+    /* The reference's rule: one radial ray from the voxel centre, closest hit,
+     * dot(normalize(interpolated vertex normal), rayDir) > 0.12
+     * (Content/Shaders/DXRVoxelizer.hlsl:44-53, :58-85, :132-140, :5). */
+    DXV_MODE_REFERENCE = 0,
+    /* north_star's second mode on the same traversal engine: +X axis ray, watertight hit count,
+     * occupancy = count & 1 (no reference counterpart). */
+    DXV_MODE_PARITY = 1
+};
+
+/* What dxv_debug_download copies (tests only; layouts in dxrvoxelizer_amd/csrc/dxv_types.h). */
+enum {
+    DXV_DBG_SORTED_KEYS = 0, /* T x uint64: (morton30 << 32) | triangle index, ascending   */
+    DXV_DBG_NODES = 1,       /* max(T-1,1) x 64 B internal nodes                              */
+    DXV_DBG_TRI_POS = 2,     /* T x 48 B: 3 x {x,y,z,w}; w of vertex 0 = triangle index bits  */
+    DXV_DBG_TRI_NRM = 3,     /* T x 48 B: 3 x {nx,ny,nz,0}                                    */
+    DXV_DBG_PARENTS = 4      /* (T-1) internal + T leaf parent words: (parent << 1) | side    */
+};
+
+typedef struct dxv_stats {
+    uint32_t num_tris, num_verts, num_nodes, tree_height;
+    float bound[4];          /* centre.xyz, half extent (Content/Voxelizer.cpp:52-57)          */
+    float upload_ms;         /* dxv_set_mesh H2D                                               */
+    float prep_ms, sort_ms, hierarchy_ms, refit_ms, build_ms; /* last dxv_build, HIP events   */
+    float voxelize_ms;       /* last dxv_voxelize kernel, HIP events on the ctx stream         */
+    uint32_t grid_dim, z0, nz; /* last dxv_voxelize                                            */
+    uint32_t stack_entries;  /* LDS traversal stack entries per thread of the last launch      */
+    uint32_t reserved[7];
+} dxv_stats;
+
+/* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that
+ * Voxelizer::Init receives from its caller, Content/Voxelizer.cpp:19-42).  Fails when no HIP
+ * device is present: there is no CPU fallback. */
+DXV_API int dxv_create(dxv_ctx** out, int device);
+DXV_API void dxv_destroy(dxv_ctx* ctx);
+
+/* Last error text of this context ("" when none); with ctx == NULL the last dxv_create error.
+ * Mirrors the reference's bool-return convention (XUSG/Core/XUSG.h:12-15) plus a message. */
+DXV_API const char* dxv_last_error(const dxv_ctx* ctx);
+
+/* Run all work of this context on an existing hipStream_t (e.g. torch's current stream).  NULL
+ * restores the context's own stream.  Replaces the caller-owned command list every reference
+ * entry point receives (Content/Voxelizer.h:16-22). */
+DXV_API int dxv_set_stream(dxv_ctx* ctx, void* hip_stream);
+
+/* Mesh ingest: replaces XUSG::ObjLoader::Import(file, needNorm=true, needAABB=true)
+ * (XUSG/Optional/XUSGObjLoader.cpp:18-40, called at Content/Voxelizer.cpp:46-47).  Output layout
+ * is the reference's: vb = numVerts x {float3 pos, float3 nrm} (stride 24), ib = numIndices
+ * uint32 (already z-negated / reversed), aabb = {min.xyz, max.xyz}.  Free both with dxv_free. */
+DXV_API int dxv_obj_load(const char* path, float** vb, uint32_t* num_verts, uint32_t** ib,
+                         uint32_t* num_indices, float aabb[6]);
+DXV_API void dxv_free(void* p);
+
+/* Upload vertex/index buffers and derive the normalising bound: replaces createVB/createIB and
+ * the bound extraction (Content/Voxelizer.cpp:48-57, :115-138).  The arrays are copied; the
+ * caller keeps ownership.  vb: num_verts x 6 floats, ib: 3*num_tris uint32 < num_verts. */
+DXV_API int dxv_set_mesh(dxv_ctx* ctx, const float* vb, uint32_t num_verts, const uint32_t* ib,
+                         uint32_t num_tris);
+
+/* Build the acceleration structure on the device: replaces Voxelizer::buildAccelerationStructures
+ * (BLAS + TLAS with the mesh -> [-1,1]^3 instance transform, Content/Voxelizer.cpp:264-326) with
+ * an LBVH: Morton keys -> radix sort -> Karras hierarchy -> bottom-up refit. */
+DXV_API int dxv_build(dxv_ctx* ctx);
+
+/* Voxelize slices [z0, z0+nz) of a grid_dim^3 grid: replaces Voxelizer::voxelize =
+ * DispatchRays(GRID_SIZE, GRID_SIZE*GRID_SIZE, 1) (Content/Voxelizer.cpp:351-369) with grid_dim
+ * promoted from the GRID_SIZE macro (:8) to a parameter.  grid_dim must be even (an odd grid has
+ * a NaN ray at its centre voxel, hlsl:52).  Output: uint8 {0,1}, id = ((iz-z0)*N + iy)*N + ix
+ * (hlsl:64-67), i.e. the alpha channel the only consumer reads (Shaders/PSRayCast.hlsl:108).
+ * Synchronous: returns after the kernel has finished and its status word was checked. */
+DXV_API int dxv_voxelize(dxv_ctx* ctx, uint32_t grid_dim, int mode, uint32_t z0, uint32_t nz);
+
+/* Same launch without the host synchronisation (for back-to-back timing); pair with dxv_sync,
+ * which waits for the stream and reports any deferred kernel error. */
+DXV_API int dxv_voxelize_async(dxv_ctx* ctx, uint32_t grid_dim, int mode, uint32_t z0, uint32_t nz);
+DXV_API int dxv_sync(dxv_ctx* ctx);
+
+/* Result access.  The grid stays resident on the device (the reference never reads it back,
+ * it is consumed by the ray-cast pass on the GPU); download is for callers that want it. */
+DXV_API void* dxv_grid_device_ptr(dxv_ctx* ctx);
+DXV_API size_t dxv_grid_bytes(const dxv_ctx* ctx);
+DXV_API int dxv_grid_download(dxv_ctx* ctx, uint8_t* host, size_t bytes);
+/* Number of solid voxels of the last grid, reduced on the device. */
+DXV_API int dxv_grid_count(dxv_ctx* ctx, uint64_t* solid);
+
+/* The same grid as the reference's R10G10B10A2_UNORM texels (float4(Normal, 1), hlsl:83-84,
+ * Content/Voxelizer.cpp:65): enable before dxv_voxelize to also fill a uint32 texel per voxel
+ * (0 where the shader writes nothing).  Reference mode only. */
+DXV_API int dxv_enable_texels(dxv_ctx* ctx, int enable);
+DXV_API int dxv_texels_download(dxv_ctx* ctx, uint32_t* host, size_t bytes);
+
+/* Multi-GPU: the built scene (nodes + triangle data) as one relocatable device blob, so that
+ * rank 0 builds once and the host layer broadcasts it (RCCL over xGMI) to the other ranks.
+ * export copies the blob into caller-provided DEVICE memory; import adopts a blob from DEVICE
+ * memory as if dxv_set_mesh + dxv_build had run here. */
+DXV_API size_t dxv_scene_bytes(const dxv_ctx* ctx);
+DXV_API int dxv_scene_export(dxv_ctx* ctx, void* device_dst, size_t bytes);
+DXV_API int dxv_scene_import(dxv_ctx* ctx, const void* device_src, size_t bytes);
+
+DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
+
+/* Tuning knobs (kernel variant selection etc.); unknown keys fail.  See DESIGN.md. */
+DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
+
+/* Test hook: copy an internal device array to the host (enum above). */
+DXV_API int dxv_debug_download(dxv_ctx* ctx, int what, void* host, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DXV_H */

@@ -1,0 +1,85 @@
+// dxv_voxelizer.hpp -- host-side C++ mirror of the reference's Voxelizer component over the
+// C-ABI (include/dxv.h).  Header only; link with libdxv.so.
+//
+// Reference surface (Content/Voxelizer.h:10-24):
+//   bool Init(pCommandList, descriptorTableLib, width, height, rtFormat, dsFormat, uploaders,
+//             pGeometry, fileName, posScale);
+//   void UpdateFrame(frameIndex, eyePt, viewProj);  void Render(pCommandList, frameIndex, rtv, dsv);
+//   protected: void voxelize(pCommandList, frameIndex);   // the hot call, GRID_SIZE = 64 macro
+//
+// Here: the D3D12-only parameters are gone; `voxelize` is public as Voxelize(gridDim) with the
+// grid size promoted from the GRID_SIZE macro (Content/Voxelizer.cpp:8) to a parameter; every
+// fallible call returns bool like the reference (XUSG/Core/XUSG.h:12-15) and never throws.
+// posScale is accepted and, exactly as in the reference, does not affect voxelisation
+// (Content/Voxelizer.cpp:84-87 uses it for display matrices only).
+#pragma once
+#include "dxv.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+class Voxelizer
+{
+public:
+	enum Mode : int { REFERENCE = DXV_MODE_REFERENCE, PARITY = DXV_MODE_PARITY };
+
+	explicit Voxelizer(int device = 0) : m_device(device) {}
+	virtual ~Voxelizer() { dxv_destroy(m_ctx); }
+	Voxelizer(const Voxelizer&) = delete;
+	Voxelizer& operator=(const Voxelizer&) = delete;
+
+	// Load the OBJ, upload VB/IB, extract the bound, build the acceleration structure
+	// (Content/Voxelizer.cpp:30-79).
+	bool Init(const char* fileName, const float posScale[4] = nullptr)
+	{
+		float* vb = nullptr; uint32_t* ib = nullptr; uint32_t numVerts = 0, numIndices = 0; float aabb[6];
+		if (dxv_obj_load(fileName, &vb, &numVerts, &ib, &numIndices, aabb)) return setError("cannot load OBJ file");
+		const bool ok = InitFromArrays(vb, numVerts, ib, numIndices / 3, posScale);
+		dxv_free(vb); dxv_free(ib);
+		return ok;
+	}
+
+	// Same from memory: vb = numVerts x {pos.xyz, nrm.xyz}, ib = 3*numTris indices, both in the
+	// layout ObjLoader produces (createVB/createIB, Content/Voxelizer.cpp:115-138).
+	bool InitFromArrays(const float* vb, uint32_t numVerts, const uint32_t* ib, uint32_t numTris,
+		const float posScale[4] = nullptr)
+	{
+		for (int i = 0; i < 4; ++i) m_posScale[i] = posScale ? posScale[i] : (i == 3 ? 1.0f : 0.0f);
+		if (!m_ctx && dxv_create(&m_ctx, m_device)) return setError(dxv_last_error(nullptr));
+		if (dxv_set_mesh(m_ctx, vb, numVerts, ib, numTris)) return false;
+		return dxv_build(m_ctx) == 0;
+	}
+
+	// The hot call (Content/Voxelizer.cpp:351-369): whole grid, or slices [z0, z0+nz).
+	bool Voxelize(uint32_t gridDim, Mode mode = REFERENCE) { return Voxelize(gridDim, mode, 0, gridDim); }
+	bool Voxelize(uint32_t gridDim, Mode mode, uint32_t z0, uint32_t nz)
+	{
+		if (!m_ctx) return setError("Voxelize before Init");
+		return dxv_voxelize(m_ctx, gridDim, mode, z0, nz) == 0;
+	}
+
+	// Result: uint8 occupancy, x fastest, then y (top to bottom), then z.
+	bool Download(std::vector<uint8_t>& grid)
+	{
+		if (!m_ctx) return setError("Download before Init");
+		grid.resize(dxv_grid_bytes(m_ctx));
+		return dxv_grid_download(m_ctx, grid.data(), grid.size()) == 0;
+	}
+	const void* DeviceGrid() const { return m_ctx ? dxv_grid_device_ptr(m_ctx) : nullptr; }
+	bool CountSolid(uint64_t& solid) { return m_ctx && dxv_grid_count(m_ctx, &solid) == 0; }
+
+	bool GetStats(dxv_stats& s) const { return m_ctx && dxv_get_stats(m_ctx, &s) == 0; }
+	const char* LastError() const { return m_ctx && *dxv_last_error(m_ctx) ? dxv_last_error(m_ctx) : m_err.c_str(); }
+	dxv_ctx* Context() { return m_ctx; }
+
+	static const uint8_t FrameCount = 3; // Content/Voxelizer.h:24 (kept for source compatibility)
+
+protected:
+	bool setError(const char* msg) { m_err = msg ? msg : ""; return false; }
+
+	dxv_ctx*	m_ctx = nullptr;
+	int			m_device;
+	float		m_posScale[4] = { 0.0f, 0.0f, 0.0f, 1.0f };
+	std::string	m_err;
+};

@@ -1,0 +1,142 @@
+// hostcheck.cpp -- TEST-ONLY harness: drives the product's own __host__ __device__ code
+// (dxrvoxelizer_amd/csrc/dxv_math.h, dxv_trace.h) on the CPU so that the arithmetic, the Karras
+// hierarchy rule and the traversal can be checked against the oracle without a GPU.
+// Never linked into libdxv.so; the shipped library has no CPU path.
+#include "../../dxrvoxelizer_amd/csrc/dxv_trace.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+using namespace dxv;
+
+struct HcScene {
+    uint32_t T = 0;
+    float bound[4];
+    std::vector<uint64_t> keys;
+    std::vector<Node> nodes;
+    std::vector<TriPos> triPos;
+    std::vector<TriNrm> triNrm;
+    uint32_t height = 0;
+};
+
+static void set_child(Node& n, int side, const float lo[3], const float hi[3], uint32_t h)
+{
+    float* w = reinterpret_cast<float*>(&n) + 6 * side;
+    w[0] = lo[0]; w[1] = lo[1]; w[2] = lo[2]; w[3] = hi[0]; w[4] = hi[1]; w[5] = hi[2];
+    (side ? n.h1 : n.h0) = h;
+}
+
+static uint32_t refit(HcScene& s, int32_t link, float lo[3], float hi[3])
+{
+    if (link < 0) {
+        const TriPos& tp = s.triPos[~link];
+        tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+        return 0;
+    }
+    Node& n = s.nodes[link];
+    float l0[3], h0[3], l1[3], h1[3];
+    const uint32_t a = refit(s, n.c0, l0, h0), b = refit(s, n.c1, l1, h1);
+    set_child(n, 0, l0, h0, a);
+    set_child(n, 1, l1, h1, b);
+    for (int k = 0; k < 3; ++k) { lo[k] = min_(l0[k], l1[k]); hi[k] = max_(h0[k], h1[k]); }
+    return (a > b ? a : b) + 1;
+}
+
+extern "C" {
+
+__attribute__((visibility("default"))) void* hc_scene_create(const float* vb, uint32_t V, const uint32_t* ib, uint32_t T,
+                                                               const float bound[4])
+{
+    (void)V;
+    HcScene* s = new HcScene();
+    s->T = T;
+    memcpy(s->bound, bound, 16);
+    s->keys.resize(T);
+    auto gather = [&](uint32_t k, F4& a, F4& b, F4& c) {
+        a = normalise_pos(vb + 6ull * ib[3ull * k], bound);
+        b = normalise_pos(vb + 6ull * ib[3ull * k + 1], bound);
+        c = normalise_pos(vb + 6ull * ib[3ull * k + 2], bound);
+    };
+    for (uint32_t k = 0; k < T; ++k) {
+        F4 a, b, c;
+        gather(k, a, b, c);
+        float lo[3], hi[3];
+        tri_box(a, b, c, lo, hi);
+        s->keys[k] = morton_key(lo, hi, k);
+    }
+    std::sort(s->keys.begin(), s->keys.end());
+    s->triPos.resize(T);
+    s->triNrm.resize(T);
+    for (uint32_t i = 0; i < T; ++i) {
+        const uint32_t k = (uint32_t)(s->keys[i] & 0xffffffffull);
+        F4 a, b, c;
+        gather(k, a, b, c);
+        a.w = __builtin_bit_cast(float, k);
+        s->triPos[i] = TriPos{a, b, c};
+        const float* n0 = vb + 6ull * ib[3ull * k] + 3;
+        const float* n1 = vb + 6ull * ib[3ull * k + 1] + 3;
+        const float* n2 = vb + 6ull * ib[3ull * k + 2] + 3;
+        s->triNrm[i] = TriNrm{F4{n0[0], n0[1], n0[2], 0}, F4{n1[0], n1[1], n1[2], 0}, F4{n2[0], n2[1], n2[2], 0}};
+    }
+    s->nodes.resize(T > 1 ? T - 1 : 1);
+    memset(s->nodes.data(), 0xff, s->nodes.size() * sizeof(Node));
+    if (T == 1) {
+        float lo[3], hi[3];
+        tri_box(s->triPos[0].v0, s->triPos[0].v1, s->triPos[0].v2, lo, hi);
+        set_child(s->nodes[0], 0, lo, hi, 0);
+        const float far[3] = {1e30f, 1e30f, 1e30f};
+        set_child(s->nodes[0], 1, far, far, 0);
+        s->nodes[0].c0 = ~0; s->nodes[0].c1 = ~0;
+        s->height = 1;
+    } else {
+        for (uint32_t i = 0; i + 1 < T; ++i) karras_node(s->keys.data(), T, i, s->nodes[i].c0, s->nodes[i].c1);
+        float lo[3], hi[3];
+        s->height = refit(*s, 0, lo, hi);
+    }
+    return s;
+}
+
+__attribute__((visibility("default"))) void hc_scene_destroy(void* p) { delete static_cast<HcScene*>(p); }
+__attribute__((visibility("default"))) uint32_t hc_scene_height(void* p) { return static_cast<HcScene*>(p)->height; }
+__attribute__((visibility("default"))) void hc_scene_nodes(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes.data(), s->nodes.size() * sizeof(Node)); }
+__attribute__((visibility("default"))) void hc_scene_keys(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->keys.data(), s->keys.size() * 8); }
+
+__attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int mode, uint32_t z0, uint32_t nz, int stackCap,
+                                                         uint8_t* out, uint32_t* texels)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    int overflow = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(| : overflow)
+    for (int64_t row = 0; row < (int64_t)nz * N; ++row) {
+        const uint32_t lz = (uint32_t)(row / N), iy = (uint32_t)(row % N), iz = z0 + lz;
+        int32_t stack[128];
+        StridedStack stk{stack, 1};
+        for (uint32_t ix = 0; ix < N; ++ix) {
+            const size_t id = ((size_t)lz * N + iy) * N + ix;
+            uint8_t occ = 0;
+            if (mode == 0) {
+                const Ray r = make_ray_reference(N, ix, iy, iz);
+                Hit best;
+                if (!trace_reference(r, s->nodes.data(), s->triPos.data(), stk, stackCap, best)) overflow |= 1;
+                uint32_t texel = 0;
+                if (best.k != 0xffffffffu) {
+                    const TriNrm& tn = s->triNrm[best.leaf];
+                    float nx, ny, nz_;
+                    occ = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz_) ? 1 : 0;
+                    if (occ) texel = pack_texel(nx, ny, nz_);
+                }
+                if (texels) texels[id] = texel;
+            } else {
+                const Ray r = make_ray_parity(N, ix, iy, iz);
+                uint32_t count;
+                if (!trace_parity(r, s->nodes.data(), s->triPos.data(), stk, stackCap, count)) overflow |= 1;
+                occ = (uint8_t)(count & 1u);
+            }
+            out[id] = occ;
+        }
+    }
+    return overflow;
+}
+
+} // extern "C"

@@ -1,0 +1,64 @@
+"""The drop-in boundary: libdxv.so loads, exports every symbol include/dxv.h declares, and fails
+loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dxv.h")).read()
+    return sorted(set(re.findall(r"DXV_API\s+[\w\s\*]+?\b(dxv_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_symbols()
+    for must in ("dxv_create", "dxv_destroy", "dxv_set_mesh", "dxv_build", "dxv_voxelize", "dxv_grid_download",
+                 "dxv_obj_load", "dxv_scene_export", "dxv_scene_import", "dxv_last_error"):
+        assert must in names
+    assert len(names) >= 20
+
+
+def test_library_exports_every_declared_symbol(dxvlib):
+    from dxrvoxelizer_amd import _lib
+    names = declared_symbols()
+    for n in names:
+        assert hasattr(dxvlib, n), f"libdxv.so does not export {n}"
+    assert sorted(_lib.SYMBOLS) == names          # the Python binding covers the whole header
+
+
+def test_no_oracle_in_product():
+    """The product never routes through the oracle: no source of the package mentions it and the
+    library does not link it."""
+    pkg = os.path.join(ROOT, "dxrvoxelizer_amd")
+    for base, _, files in os.walk(pkg):
+        if os.path.basename(base) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "liboracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libdxv.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "amdhip64" in out
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure path")
+def test_create_fails_loudly_without_gpu(dxvlib):
+    import dxrvoxelizer_amd as dxv
+    with pytest.raises(dxv.DxvError) as e:
+        dxv.Voxelizer()
+    assert "no CPU path" in str(e.value) or "no HIP device" in str(e.value)
+    ctx = C.c_void_p()
+    assert dxvlib.dxv_create(C.byref(ctx), 0) != 0 and not ctx.value
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from dxrvoxelizer_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "library_path", lambda: str(tmp_path / "libdxv.so"))
+    with pytest.raises(_lib.DxvError):
+        _lib.load_library()

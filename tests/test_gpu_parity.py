@@ -1,0 +1,281 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle
+on the same inputs, against the committed golden vectors, and at BASELINE.json's full sizes
+through size-independent properties.  Bar: bit-exact (uint8 occupancy, uint32 texels, uint64
+keys, node words)."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from dxrvoxelizer_amd import meshes
+from dxrvoxelizer_amd.slabs import gather_slabs, slab_range
+
+pytestmark = pytest.mark.gpu
+
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS = range(5)
+
+
+@pytest.fixture(scope="module")
+def dxv(dxvlib):
+    import dxrvoxelizer_amd
+    return dxrvoxelizer_amd
+
+
+@pytest.fixture()
+def vox(dxv):
+    v = dxv.Voxelizer(0)
+    yield v
+    v.close()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---------------------------------------------------------------------------------------------
+# build stages
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
+def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
+    vb, ib, _ = request.getfixturevalue(name)
+    vox.InitFromArrays(vb, ib)
+    st = vox.stats()
+    s = orc.Scene(vb, ib)
+    assert np.array_equal(np.asarray(st["bound"], np.float32), s.bound)     # A2
+    h = hostcheck(vb, ib, s.bound)
+    keys = vox.debug(DBG_SORTED_KEYS)
+    assert np.array_equal(keys, np.sort(keys)), "radix sort output is not sorted"
+    assert np.array_equal(keys, h.keys()), "device Morton keys / sort differ from the host run of the same code"
+    nodes, want = vox.debug(DBG_NODES), h.nodes()
+    assert np.array_equal(nodes[:, 12:14], want[:, 12:14]), "Karras hierarchy differs"
+    assert np.array_equal(nodes[:, :12], want[:, :12]), "refit boxes differ"
+    assert np.array_equal(nodes[:, 14:16], want[:, 14:16]), "subtree heights differ"
+    assert st["tree_height"] == h.height
+    tp = vox.debug(DBG_TRI_POS)
+    k = tp[:, 3].view(np.uint32)
+    assert np.array_equal(np.sort(k), np.arange(len(k), dtype=np.uint32))
+    for i in (0, len(k) // 2, len(k) - 1):                                    # tri prep == oracle
+        p, _ = s.tri(int(k[i]))
+        assert np.array_equal(tp[i].reshape(3, 4)[:, :3], p)
+    tn = vox.debug(DBG_TRI_NRM)
+    i = len(k) // 3
+    assert np.array_equal(tn[i].reshape(3, 4)[:, :3], vb[ib[3 * int(k[i]):3 * int(k[i]) + 3], 3:])
+
+
+def test_refit_variants_identical(dxv, dragon):
+    vb, ib, _ = dragon
+    a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
+    b.set_option("refit", 1)
+    a.InitFromArrays(vb, ib)
+    b.InitFromArrays(vb, ib)
+    assert np.array_equal(a.debug(DBG_NODES), b.debug(DBG_NODES))
+    for _ in range(3):                       # rebuilds are deterministic
+        a.InitFromArrays(vb, ib)
+        assert np.array_equal(a.debug(DBG_NODES), b.debug(DBG_NODES))
+    a.close(), b.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# grids vs oracle / golden vectors
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_64_equals_oracle_and_golden(vox, orc, request, grids_json, grids64, name, mode):
+    vb, ib, _ = request.getfixturevalue(name)
+    vox.InitFromArrays(vb, ib)
+    vox.Voxelize(64, mode)
+    g = vox.Grid()
+    tag = "reference" if mode == 0 else "parity"
+    want = np.unpackbits(grids64[f"{name}_64_{tag}"])[: 64 ** 3].reshape(64, 64, 64)   # brute-force oracle for mode 0
+    assert int(g.sum()) == grids_json[f"{name}/64/{tag}"]["solid"]
+    assert np.array_equal(g, want), f"{int((g != want).sum())} voxels differ from the golden grid"
+    assert np.array_equal(g, orc.Scene(vb, ib).voxelize(64, mode=mode))
+    assert vox.CountSolid() == int(g.sum())
+
+
+@pytest.mark.parametrize("name", ["bunny", "dragon"])
+def test_grid_256_golden(vox, request, grids_json, name):
+    """config 2: bunny at 256^3 on one MI355X, bit-exact (hash + per-slice popcounts)."""
+    vb, ib, _ = request.getfixturevalue(name)
+    vox.InitFromArrays(vb, ib)
+    for mode, tag in ((0, "reference"), (1, "parity")):
+        vox.Voxelize(256, mode)
+        g = vox.Grid()
+        want = grids_json[f"{name}/256/{tag}"]
+        assert [int(x) for x in g.reshape(256, -1).sum(1)] == want["slices"]
+        assert sha(g) == want["sha256"]
+
+
+def test_texels_equal_oracle(vox, orc, bunny, grids_json):
+    vb, ib, _ = bunny
+    vox.InitFromArrays(vb, ib)
+    vox.EnableTexels(True)
+    vox.Voxelize(64)
+    g, tex = vox.Grid(), vox.Texels()
+    og, otex = orc.Scene(vb, ib).voxelize(64, texels=True)
+    assert np.array_equal(g, og) and np.array_equal(tex, otex)
+    assert sha(tex) == grids_json["bunny/64/texels"]["sha256"]
+
+
+@pytest.mark.parametrize("gen,args", [("cube", ()), ("tetrahedron", ()), ("uv_sphere", (24, 12)), ("torus", (60, 30)),
+                                      ("soup", (3000,))])
+def test_synthetic_equals_brute_force_oracle(vox, orc, gen, args):
+    vb, ib = getattr(meshes, gen)(*args)
+    vox.InitFromArrays(vb, ib)
+    s = orc.Scene(vb, ib)
+    for mode in ((0,) if gen == "soup" else (0, 1)):
+        vox.Voxelize(16, mode)
+        assert np.array_equal(vox.Grid(), s.voxelize(16, mode=mode, algo=orc.ALGO_BRUTE))
+
+
+def test_single_triangle_and_duplicates(vox, orc):
+    vb = np.zeros((5, 6), np.float32)
+    vb[:3, :3] = [[-0.9, -0.9, 0.4], [0.9, -0.9, 0.4], [0.0, 0.9, 0.4]]
+    vb[:3, 3:] = [0.57735, 0.57735, 0.57735]
+    vb[3, :3], vb[4, :3] = [-1, -1, -1], [1, 1, 1]
+    one = np.arange(3, dtype=np.uint32)
+    for ib in (one, np.tile(one, 37), np.tile(one, 5000)):
+        vox.InitFromArrays(vb, ib)
+        s = orc.Scene(vb, ib)
+        for mode in (0, 1):
+            vox.Voxelize(16, mode)
+            assert np.array_equal(vox.Grid(), s.voxelize(16, mode=mode))
+
+
+def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
+    vb, ib, _ = dragon
+    vox.InitFromArrays(vb, ib)
+    want = orc.Scene(vb, ib).voxelize(64)
+    for brick in range(4):
+        for stack in (0, 32, 48, 64):
+            vox.set_option("brick", brick)
+            vox.set_option("stack", stack)
+            vox.Voxelize(64)
+            assert np.array_equal(vox.Grid(), want), (brick, stack)
+    for n in (2, 6, 30, 66):                 # grids that do not fill whole bricks
+        vox.set_option("brick", 1)
+        vox.set_option("stack", 0)
+        vox.Voxelize(n)
+        assert np.array_equal(vox.Grid(), orc.Scene(vb, ib).voxelize(n)), n
+
+
+def test_slabs_concatenate_to_the_full_grid(vox, bunny):
+    """config 4's scheme on one GPU: 8 Z-slabs looped == the single-pass grid."""
+    vb, ib, _ = bunny
+    vox.InitFromArrays(vb, ib)
+    vox.Voxelize(128)
+    full = vox.Grid()
+    parts = []
+    for r in range(8):
+        z0, nz = slab_range(128, r, 8)
+        vox.Voxelize(128, 0, z0, nz)
+        parts.append((z0, vox.Grid()))
+    assert np.array_equal(gather_slabs(parts), full)
+    vox.Voxelize(128, 0, 100, 28)
+    assert np.array_equal(vox.Grid(), full[100:])
+
+
+def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
+    """What rank 0 broadcasts: export -> (device buffer) -> import into a second context."""
+    import torch
+    vb, ib, _ = dragon
+    a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
+    a.InitFromArrays(vb, ib)
+    n = a.scene_bytes()
+    blob = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.scene_export(blob.data_ptr(), n)
+    torch.cuda.synchronize()
+    b.scene_import(blob.data_ptr(), n)
+    assert b.stats()["tree_height"] == a.stats()["tree_height"]
+    a.Voxelize(64), b.Voxelize(64)
+    assert np.array_equal(a.Grid(), b.Grid())
+    bad = blob.clone()
+    bad[:4] = 0
+    with pytest.raises(dxv.DxvError):
+        b.scene_import(bad.data_ptr(), n)
+    a.close(), b.close()
+
+
+def test_errors_are_loud(dxv, bunny):
+    vb, ib, _ = bunny
+    v = dxv.Voxelizer(0)
+    with pytest.raises(dxv.DxvError):
+        v.Voxelize(64)                                    # before Init
+    v.InitFromArrays(vb, ib)
+    for bad in ((63, 0, 63), (64, 60, 8), (64, 0, 0), (4096, 0, 1)):
+        with pytest.raises(dxv.DxvError):
+            v.Voxelize(bad[0], 0, bad[1], bad[2])
+    with pytest.raises(dxv.DxvError):
+        v.InitFromArrays(vb, np.array([0, 1, 10 ** 6], np.uint32))
+    with pytest.raises(dxv.DxvError):
+        v.InitFromArrays(np.zeros((3, 6), np.float32), np.arange(3, dtype=np.uint32))   # zero extent
+    v.InitFromArrays(vb, ib)
+    v.set_option("stack", 16)                             # bunny's tree is deeper than 16
+    if v.stats()["tree_height"] > 17:
+        with pytest.raises(dxv.DxvError) as e:
+            v.Voxelize(64)
+        assert "stack" in str(e.value)
+    v.set_option("stack", 0)
+    v.Voxelize(64)                                        # and the context recovers
+    v.close()
+
+
+def test_cpp_voxelizer_mirror(orc, tmp_path):
+    """The C++ host mirror (include/dxv_voxelizer.hpp): Init(file) + Voxelize(N) from a C++ program."""
+    vb, ib = meshes.uv_sphere(48, 24, 0.8, (0.1, -0.2, 0.05))
+    obj = tmp_path / "sphere.obj"
+    with open(obj, "w") as fh:                             # positions only: normals are recomputed
+        for p in vb[:, :3]:
+            fh.write("v %.6f %.6f %.6f\n" % tuple(p))
+        for t in ib.reshape(-1, 3) + 1:
+            fh.write("f %d %d %d\n" % tuple(t))
+    exe = tmp_path / "voxelize_obj"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "voxelize_obj.cpp"),
+                           "-o", str(exe), "-L" + os.path.join(ROOT, "dxrvoxelizer_amd"), "-ldxv",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dxrvoxelizer_amd")])
+    out = tmp_path / "grid.bin"
+    r = subprocess.run([str(exe), str(obj), "64", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    g = np.fromfile(out, np.uint8).reshape(64, 64, 64)
+    ovb, oib, _ = orc.obj_load(str(obj))
+    want = orc.Scene(ovb, oib).voxelize(64)
+    assert np.array_equal(g, want) and int(r.stdout.strip()) == int(want.sum())
+
+
+# ---------------------------------------------------------------------------------------------
+# full size (BASELINE.json: 1 M-triangle mesh at 512^3)
+# ---------------------------------------------------------------------------------------------
+def test_full_size_properties_torus_1m_512(vox, orc):
+    vb, ib = meshes.torus()                                # exactly 1,000,000 triangles
+    assert len(ib) // 3 == 1_000_000
+    vox.InitFromArrays(vb, ib)
+    N = 512
+    vox.Voxelize(N)
+    g = vox.Grid()
+    n1 = vox.CountSolid()
+    assert n1 == int(g.sum(dtype=np.uint64))               # device count == host count
+    h1 = sha(g)
+    vox.Voxelize(N)                                        # idempotence
+    assert sha(vox.Grid()) == h1
+    parts = []                                             # slab concatenation == whole grid
+    for r in range(4):
+        z0, nz = slab_range(N, r, 4)
+        vox.Voxelize(N, 0, z0, nz)
+        parts.append((z0, vox.Grid()))
+    assert sha(gather_slabs(parts)) == h1
+    # spot slices against the oracle (bit-exact), incl. the first, a grazing and a central one
+    s = orc.Scene(vb, ib)
+    for z in (0, 90, 255, 256, 400):
+        assert np.array_equal(g[z], s.voxelize(N, z0=z, nz=1)[0]), z
+    # parity mode = exact interior: analytic torus volume, bound half extent 0.9
+    vox.Voxelize(N, 1)
+    p = vox.Grid()
+    vol = 2 * np.pi ** 2 * 0.6 * 0.3 ** 2 / (2 * 0.9) ** 3 * N ** 3
+    assert abs(int(p.sum(dtype=np.uint64)) - vol) < 0.002 * vol
+    for z in (90, 256):
+        assert np.array_equal(p[z], s.voxelize(N, mode=1, z0=z, nz=1)[0]), z
+    # the two occupancy rules agree except near grazing exits
+    assert (p != g).mean() < 1e-3

@@ -1,0 +1,110 @@
+"""Host logic of the PRODUCT: its __host__ __device__ arithmetic, Karras hierarchy rule and
+traversal (dxrvoxelizer_amd/csrc/dxv_math.h, dxv_trace.h) compiled for the CPU by
+tests/hostcheck and compared bit for bit with the oracle.  The GPU kernels instantiate exactly
+this code; the -m gpu tests then only have to prove the device build, sort and launch."""
+import numpy as np
+import pytest
+
+from dxrvoxelizer_amd import meshes
+
+
+def check_tree(nodes, T):
+    """Every leaf and every internal node reachable exactly once; child boxes finite; heights."""
+    c = nodes[:, 12:14].view(np.int32)
+    seen_leaf = np.zeros(T, np.int32)
+    seen_node = np.zeros(max(T - 1, 1), np.int32)
+    stack = [0]
+    while stack:
+        n = stack.pop()
+        seen_node[n] += 1
+        for link in c[n]:
+            if link < 0:
+                seen_leaf[~link] += 1
+            else:
+                stack.append(int(link))
+    assert np.all(seen_leaf == 1) and np.all(seen_node == 1)
+    boxes = nodes[:, :12].view(np.float32)
+    assert np.isfinite(boxes).all()
+    assert np.all(boxes[:, 0:3] <= boxes[:, 3:6]) and np.all(boxes[:, 6:9] <= boxes[:, 9:12])
+
+
+@pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
+def test_host_lbvh_equals_oracle_assets(orc, hostcheck, request, name):
+    vb, ib, _ = request.getfixturevalue(name)
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    check_tree(h.nodes(), h.T)
+    keys = h.keys()
+    assert np.all(keys[1:] > keys[:-1])
+    assert 1 <= h.height <= 62
+    for N, mode in ((32, 0), (32, 1), (64, 0)):
+        g, ovf = h.voxelize(N, mode, stack=h.height)
+        assert not ovf
+        assert np.array_equal(g, s.voxelize(N, mode=mode))
+
+
+def test_host_texels_equal_oracle(orc, hostcheck, bunny):
+    vb, ib, _ = bunny
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    g, tex, ovf = h.voxelize(32, 0, texels=True)
+    og, otex = s.voxelize(32, texels=True)
+    assert not ovf and np.array_equal(g, og) and np.array_equal(tex, otex)
+
+
+@pytest.mark.parametrize("gen,args", [("cube", ()), ("tetrahedron", ()), ("uv_sphere", (24, 12)), ("torus", (60, 30)),
+                                      ("soup", (3000,))])
+def test_host_lbvh_equals_oracle_brute_synthetic(orc, hostcheck, gen, args):
+    vb, ib = getattr(meshes, gen)(*args)
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    check_tree(h.nodes(), h.T)
+    modes = (0,) if gen == "soup" else (0, 1)
+    for mode in modes:
+        g, ovf = h.voxelize(16, mode)
+        assert not ovf
+        assert np.array_equal(g, s.voxelize(16, mode=mode, algo=orc.ALGO_BRUTE))
+
+
+def test_single_triangle_and_duplicates(orc, hostcheck):
+    """T == 1 (dummy sibling) and many identical triangles (equal Morton codes -> index bits
+    decide the hierarchy)."""
+    vb = np.zeros((5, 6), np.float32)
+    vb[:3, :3] = [[-0.9, -0.9, 0.4], [0.9, -0.9, 0.4], [0.0, 0.9, 0.4]]
+    vb[:3, 3:] = [0.57735, 0.57735, 0.57735]
+    vb[3, :3], vb[4, :3] = [-1, -1, -1], [1, 1, 1]
+    one = np.arange(3, dtype=np.uint32)
+    s = orc.Scene(vb, one)
+    h = hostcheck(vb, one, s.bound)
+    for mode in (0, 1):
+        g, ovf = h.voxelize(16, mode)
+        assert not ovf and np.array_equal(g, s.voxelize(16, mode=mode, algo=orc.ALGO_BRUTE))
+    many = np.tile(one, 37)
+    s = orc.Scene(vb, many)
+    h = hostcheck(vb, many, s.bound)
+    check_tree(h.nodes(), h.T)
+    g, ovf = h.voxelize(16, 0)
+    assert not ovf and np.array_equal(g, s.voxelize(16, algo=orc.ALGO_BRUTE))
+    g, ovf = h.voxelize(16, 1)
+    assert np.array_equal(g, s.voxelize(16, mode=1, algo=orc.ALGO_BRUTE))
+
+
+def test_stack_overflow_is_reported(orc, hostcheck, bunny):
+    vb, ib, _ = bunny
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    _, ovf = h.voxelize(32, 0, stack=1)
+    assert ovf
+
+
+def test_slab_concatenation_equals_full_grid(orc, hostcheck, dragon):
+    vb, ib, _ = dragon
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    from dxrvoxelizer_amd.slabs import gather_slabs, slab_range
+    full, _ = h.voxelize(32, 0)
+    parts = []
+    for r in range(8):
+        z0, nz = slab_range(32, r, 8)
+        parts.append((z0, h.voxelize(32, 0, z0=z0, nz=nz)[0]))
+    assert np.array_equal(gather_slabs(parts), full)
