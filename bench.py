@@ -49,21 +49,19 @@ def algorithmic_bytes(N, nz, T, V):
 
 def cpu_baseline(vb, ib, N, mode, budget_s=15.0):
     """The oracle's scalar BVH voxelizer ('port': the reference has no CPU path) on a bounded
-    sample of the same workload: evenly spaced Z slices, all host cores (OpenMP)."""
+    sample of the same workload: evenly spaced Z slices, all host cores (OpenMP over rows)."""
     from oracle import orc
     import numpy as np
     scene = orc.Scene(vb, ib)
     cores = orc.lib().orc_num_procs()
+    probe = sorted(set(int(z) for z in np.linspace(0, N - 1, 16).round()))
     t0 = time.perf_counter()
-    probe = [int(z) for z in np.linspace(0, N - 1, 8).round()]
-    for z in probe:
-        scene.voxelize(N, mode=mode, z0=z, nz=1)
+    orc.voxelize_slices(scene, N, probe, mode=mode)
     per_slice = (time.perf_counter() - t0) / len(probe)
-    n = int(max(8, min(N, budget_s / max(per_slice, 1e-6))))
+    n = int(max(16, min(N, budget_s / max(per_slice, 1e-6))))
     zs = sorted(set(int(z) for z in np.linspace(0, N - 1, n).round()))
     t0 = time.perf_counter()
-    for z in zs:
-        scene.voxelize(N, mode=mode, z0=z, nz=1)
+    orc.voxelize_slices(scene, N, zs, mode=mode)
     dt = time.perf_counter() - t0
     return {"value": len(zs) * N * N / dt / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
             "sample": f"{len(zs)} evenly spaced Z slices of the {N}^3 grid ({len(zs) * N * N} voxels, {dt:.1f} s), "
@@ -107,8 +105,9 @@ def main():
 
     N, mode = args.grid, (dxv.MODE_REFERENCE if args.mode == "reference" else dxv.MODE_PARITY)
     vox = dxv.Voxelizer(local_rank)
-    stream = torch.cuda.current_stream()
-    vox.set_stream(stream.cuda_stream)           # kernels and torch events share one stream
+    stream = torch.cuda.Stream()                 # a real (non-null) stream: kernels, torch events and
+    torch.cuda.set_stream(stream)                # RCCL all share it
+    vox.set_stream(stream.cuda_stream)
     if args.brick >= 0:
         vox.set_option("brick", args.brick)
     if args.stack >= 0:

@@ -61,9 +61,12 @@ struct dxv_ctx {
     dxv_stats stats{};
 
     // options
-    int optBrick = 1;
-    int optStack = 0;
+    int optBrick = 4;        // 4x4x4 voxels = one wavefront per workgroup (fastest in the r01 sweeps)
+    int optStack = 0;        // 0 = adaptive (start small, grow on overflow), else forced depth
     int optRefit = 0;
+    int stackNow = 16;       // adaptive: LDS stack entries per thread currently in use for this scene
+    int lastMode = 0;
+    bool pending = false;    // a voxelize launch has not been checked by dxv_sync yet
 };
 
 namespace {
@@ -141,6 +144,29 @@ float elapsed(hipEvent_t a, hipEvent_t b)
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
     return ms;
+}
+
+// Stack policy.  The stack never needs more than treeHeight entries, but rays rarely push more
+// than a dozen, and LDS (entries * 4 B * threads) is what limits resident waves.  Adaptive mode
+// starts at 16 entries; a kernel that runs out reports it through the status word and dxv_sync
+// re-runs the launch with the always-sufficient depth and keeps it for this scene.
+int safe_stack(const dxv_ctx* c) { return stack_round_up((int)c->hdr.treeHeight); }
+
+int launch_now(dxv_ctx* c)
+{
+    VoxelizeParams p{};
+    p.scene.nodes = scene_nodes(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
+    memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
+    memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
+    p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
+    p.N = c->stats.grid_dim; p.z0 = c->stats.z0; p.nz = c->stats.nz; p.mode = c->lastMode;
+    const int st = c->optStack ? c->optStack : c->stackNow;
+    c->stats.stack_entries = (uint32_t)st;
+    DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
+    DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
+    DXV_HIP(c, hipEventRecord(c->ev[6], c->stream));
+    c->pending = true;
+    return 0;
 }
 
 } // namespace
@@ -281,6 +307,7 @@ int dxv_build(dxv_ctx* c)
     DXV_HIP(c, hipMemcpyAsync(c->dScene, &c->hdr, sizeof(SceneHeader), hipMemcpyHostToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->haveScene = true;
+    c->stackNow = stack_round_up((int)(c->hdr.treeHeight < 16 ? c->hdr.treeHeight : 16));
     c->stats.num_nodes = c->hdr.numNodes;
     c->stats.tree_height = c->hdr.treeHeight;
     c->stats.prep_ms = elapsed(c->ev[0], c->ev[1]);
@@ -314,27 +341,28 @@ int dxv_voxelize_async(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t n
         c->texelCap = bytes;
     }
     c->gridBytes = bytes;
-    VoxelizeParams p{};
-    p.nodes = scene_nodes(c); p.triPos = scene_tripos(c); p.triNrm = scene_trinrm(c);
-    p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
-    p.N = N; p.z0 = z0; p.nz = nz; p.mode = mode; p.treeHeight = c->hdr.treeHeight;
-    DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
-    DXV_HIP(c, launch_voxelize(p, c->optBrick, c->optStack, c->stream, &c->stats.stack_entries));
-    DXV_HIP(c, hipEventRecord(c->ev[6], c->stream));
     c->stats.grid_dim = N; c->stats.z0 = z0; c->stats.nz = nz;
-    return 0;
+    c->lastMode = mode;
+    return launch_now(c);
 }
 
 int dxv_sync(dxv_ctx* c)
 {
     if (!c) return 1;
     DXV_HIP(c, hipSetDevice(c->device));
-    uint32_t status = 0;
-    DXV_HIP(c, hipMemcpyAsync(&status, c->dStatus, sizeof(status), hipMemcpyDeviceToHost, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->stats.grid_dim) c->stats.voxelize_ms = elapsed(c->ev[5], c->ev[6]);
-    if (status) {
-        (void)hipMemsetAsync(c->dStatus, 0, sizeof(uint32_t), c->stream);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        uint32_t status = 0;
+        DXV_HIP(c, hipMemcpyAsync(&status, c->dStatus, sizeof(status), hipMemcpyDeviceToHost, c->stream));
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->pending) c->stats.voxelize_ms = elapsed(c->ev[5], c->ev[6]);
+        c->pending = false;
+        if (!status) return 0;
+        DXV_HIP(c, hipMemsetAsync(c->dStatus, 0, sizeof(uint32_t), c->stream));
+        if (attempt == 0 && !c->optStack && c->stackNow < safe_stack(c) && c->haveScene && c->stats.grid_dim) {
+            c->stackNow = safe_stack(c);       // grow once to the depth that cannot overflow and redo
+            if (launch_now(c)) return 1;
+            continue;
+        }
         return fail(c, "voxelize kernel reported status 0x%x (traversal stack overflow: tree height %u, stack %u)",
                     status, c->hdr.treeHeight, c->stats.stack_entries);
     }
@@ -426,6 +454,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     c->T = h.numTris; c->V = h.numVerts;
     memcpy(c->bound, h.bound, sizeof(c->bound));
     c->haveScene = true;
+    c->stackNow = stack_round_up((int)(h.treeHeight < 16 ? h.treeHeight : 16));
     c->stats.num_tris = h.numTris; c->stats.num_verts = h.numVerts; c->stats.num_nodes = h.numNodes;
     c->stats.tree_height = h.treeHeight;
     memcpy(c->stats.bound, h.bound, sizeof(h.bound));
@@ -446,8 +475,8 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
         if (value < 0 || value >= num_brick_shapes()) return fail(c, "option brick: %lld out of range", (long long)value);
         c->optBrick = (int)value;
     } else if (!strcmp(key, "stack")) {
-        if (value != 0 && value != 16 && value != 24 && value != 32 && value != 48 && value != 64)
-            return fail(c, "option stack: %lld not in {0,16,24,32,48,64}", (long long)value);
+        if (value != 0 && (value < 0 || value > 64 || stack_round_up((int)value) != (int)value))
+            return fail(c, "option stack: %lld not in {0,8,12,16,24,32,48,64}", (long long)value);
         c->optStack = (int)value;
     } else if (!strcmp(key, "refit")) {
         if (value != 0 && value != 1) return fail(c, "option refit: %lld not in {0,1}", (long long)value);

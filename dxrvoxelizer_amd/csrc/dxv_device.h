@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "dxv_types.h"
+#include "dxv_trace.h"
 
 namespace dxv {
 
@@ -33,18 +34,15 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
 
 // traverse.hip
 struct VoxelizeParams {
-    const Node* nodes;
-    const TriPos* triPos;
-    const TriNrm* triNrm;
+    SceneView scene;
     uint8_t* grid;          // N*N*nz bytes
     uint32_t* texels;       // optional N*N*nz words
     uint32_t* status;       // status word (bit 0: traversal stack overflow)
     uint32_t N, z0, nz;
     int mode;
-    uint32_t treeHeight;
 };
-struct KernelChoice { int brick; int stackEntries; }; // brick: index into the brick-shape table
-hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int forceStack, hipStream_t s, uint32_t* stackUsed);
+hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
+int stack_round_up(int want);
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
 int num_brick_shapes();
 

@@ -38,9 +38,29 @@ struct Ray {
 DXV_HD void ray_origin(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, float& ox, float& oy, float& oz)
 {
     const float fn = (float)N;
+    if ((N & (N - 1u)) == 0u) {
+        // power-of-two grid: x / N == x * (1/N) exactly (both are exact scalings), no divisions
+        const float rn = 1.0f / fn;
+        ox = ((float)ix + 0.5f) * rn * 2.0f - 1.0f;
+        oy = -(((float)iy + 0.5f) * rn * 2.0f - 1.0f);
+        oz = ((float)iz + 0.5f) * rn * 2.0f - 1.0f;
+        return;
+    }
     ox = ((float)ix + 0.5f) / fn * 2.0f - 1.0f;          // hlsl:46
     oy = -(((float)iy + 0.5f) / fn * 2.0f - 1.0f);       // hlsl:49
     oz = ((float)iz + 0.5f) / fn * 2.0f - 1.0f;
+}
+
+// A radial ray whose origin lies beyond the scene's root box on the side it is moving to can not
+// enter any box inside the root box: on that axis sign(d) == sign(o), so the exit distance
+// fma(hi, 1/d, -(o/d)) is negative for every box (margin 1e-5 >> the 2^-24 relative rounding of
+// o/d) and slab() fails for both children of the root.  Exact shortcut, not an approximation.
+DXV_HD bool origin_leaves_root(float ox, float oy, float oz, const float* rootLo, const float* rootHi)
+{
+    const float m = 1e-5f;
+    return (ox > rootHi[0] + m && ox > 0.0f) || (ox < rootLo[0] - m && ox < 0.0f) ||
+           (oy > rootHi[1] + m && oy > 0.0f) || (oy < rootLo[1] - m && oy < 0.0f) ||
+           (oz > rootHi[2] + m && oz > 0.0f) || (oz < rootLo[2] - m && oz < 0.0f);
 }
 
 DXV_HD void ray_shear(Ray& r)
@@ -60,15 +80,20 @@ DXV_HD void ray_shear(Ray& r)
 }
 
 // Reference mode: direction = normalize(pos) (hlsl:52); canonical form p / sqrtf((xx+yy)+zz).
-DXV_HD Ray make_ray_reference(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz)
+DXV_HD void finish_ray_reference(Ray& r)
 {
-    Ray r;
-    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
     const float len = __builtin_sqrtf((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz);
     r.dx = r.ox / len; r.dy = r.oy / len; r.dz = r.oz / len;
     r.ivx = 1.0f / r.dx; r.ivy = 1.0f / r.dy; r.ivz = 1.0f / r.dz;
     r.nox = -(r.ox * r.ivx); r.noy = -(r.oy * r.ivy); r.noz = -(r.oz * r.ivz);
-    ray_shear(r);
+    r.kz = -1;   // shear constants are set up by the first triangle test (most rays never need them)
+}
+
+DXV_HD Ray make_ray_reference(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz)
+{
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    finish_ray_reference(r);
     return r;
 }
 

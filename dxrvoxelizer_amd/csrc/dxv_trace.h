@@ -42,9 +42,10 @@ DXV_HD void load_node(const Node* nodes, int32_t i, F4& q0, F4& q1, F4& q2, int3
     c1 = __builtin_bit_cast(int32_t, q3.y);
 }
 
-DXV_HD void leaf_reference(const Ray& r, const TriPos* tris, int32_t leaf, float tn, Hit& best)
+DXV_HD void leaf_reference(Ray& r, const TriPos* tris, int32_t leaf, float tn, Hit& best)
 {
     const TriPos tp = tris[leaf];
+    if (r.kz < 0) ray_shear(r);
     float t, b1, b2;
     if (!tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2)) return;
     if (tn > t) return;
@@ -52,9 +53,13 @@ DXV_HD void leaf_reference(const Ray& r, const TriPos* tris, int32_t leaf, float
     if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = b1; best.b2 = b2; best.k = k; best.leaf = leaf; }
 }
 
+// Optional per-ray counters (tests / tuning only; compiled out of the shipped kernels).
+struct TraceStats { uint32_t nodes, leaves, maxsp; };
+
 // Returns false when the stack capacity was exceeded (caller reports the error).
-template <class Stack>
-DXV_HD bool trace_reference(const Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best)
+template <class Stack, bool STATS = false>
+DXV_HD bool trace_reference(Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
+                            TraceStats* st = nullptr)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
     int sp = 0;
@@ -63,9 +68,11 @@ DXV_HD bool trace_reference(const Ray& r, const Node* nodes, const TriPos* tris,
         F4 q0, q1, q2;
         int32_t c0, c1;
         load_node(nodes, node, q0, q1, q2, c0, c1);
+        if (STATS) st->nodes++;
         float tn0, tn1;
         bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= best.t;
         bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= best.t;
+        if (STATS) st->leaves += (h0 && c0 < 0) + (h1 && c1 < 0);
         if (h0 && c0 < 0) { leaf_reference(r, tris, ~c0, tn0, best); h0 = false; }
         if (h1 && c1 < 0) { leaf_reference(r, tris, ~c1, tn1, best); h1 = false; }
         h0 = h0 && tn0 <= best.t;
@@ -75,6 +82,7 @@ DXV_HD bool trace_reference(const Ray& r, const Node* nodes, const TriPos* tris,
             const int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
             if (sp >= cap) return false;
             stk.put(sp++, farc);
+            if (STATS && (uint32_t)sp > st->maxsp) st->maxsp = (uint32_t)sp;
             node = nearc;
         } else if (h0) node = c0;
         else if (h1) node = c1;
@@ -119,6 +127,50 @@ DXV_HD bool trace_parity(const Ray& r, const Node* nodes, const TriPos* tris, co
         }
     }
     return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// One voxel, start to finish: raygenMain + closestHitMain + missMain
+// (Content/Shaders/DXRVoxelizer.hlsl:58-85, :132-148).  Shared by the kernels and tests/hostcheck.
+// ------------------------------------------------------------------------------------------
+struct SceneView {
+    const Node* nodes;
+    const TriPos* triPos;
+    const TriNrm* triNrm;
+    float rootLo[3], rootHi[3];
+};
+
+// returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
+// when the traversal stack was too small.
+template <class Stack>
+DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
+                               const Stack& stk, int cap, uint32_t* texel, bool& overflow)
+{
+    if (texel) *texel = 0;
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
+    finish_ray_reference(r);
+    Hit best;
+    if (!trace_reference(r, sc.nodes, sc.triPos, stk, cap, best)) { overflow = true; return 0; }
+    if (best.k == 0xffffffffu) return 0;                                         // missMain
+    const TriNrm tn = sc.triNrm[best.leaf];
+    float nx, ny, nz;
+    const bool in = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz);
+    if (in && texel) *texel = pack_texel(nx, ny, nz);
+    return in ? 1 : 0;
+}
+
+template <class Stack>
+DXV_HD uint8_t voxel_parity(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
+                            const Stack& stk, int cap, bool& overflow)
+{
+    const Ray r = make_ray_parity(N, ix, iy, iz);
+    // +X ray: nothing to count when the origin is outside the root's y/z extent or beyond its +x face
+    if (!slab_parity(r, sc.rootLo[1], sc.rootLo[2], sc.rootHi[0], sc.rootHi[1], sc.rootHi[2])) return 0;
+    uint32_t count;
+    if (!trace_parity(r, sc.nodes, sc.triPos, stk, cap, count)) { overflow = true; return 0; }
+    return (uint8_t)(count & 1u);
 }
 
 } // namespace dxv

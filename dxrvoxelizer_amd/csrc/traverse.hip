@@ -17,14 +17,14 @@ namespace dxv {
 
 template <int BX, int BY, int BZ>
 struct Brick {
-    static constexpr int x = BX, y = BY, z = BZ;
-    static_assert(BX * BY * BZ == 256, "one voxel per thread of a 256-thread workgroup");
+    static constexpr int x = BX, y = BY, z = BZ, threads = BX * BY * BZ;
+    static_assert(threads == 64 || threads == 128 || threads == 256, "one voxel per thread, whole wavefronts");
 };
 
 template <class B, int STACK, int MODE, bool TEXELS>
-__global__ __launch_bounds__(256) void k_voxelize(VoxelizeParams p)
+__global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
 {
-    __shared__ int32_t stack[STACK * 256];
+    __shared__ int32_t stack[STACK * B::threads];
     const uint32_t N = p.N;
     const uint32_t nbx = (N + B::x - 1) / B::x, nby = (N + B::y - 1) / B::y, nbz = (p.nz + B::z - 1) / B::z;
     const uint32_t nb = nbx * nby * nbz;
@@ -41,35 +41,31 @@ __global__ __launch_bounds__(256) void k_voxelize(VoxelizeParams p)
     const uint32_t iz = p.z0 + lz;
     const size_t id = ((size_t)lz * N + iy) * N + ix;
 
-    StridedStack stk{stack + tid, 256};
-    uint8_t occ = 0;
+    const StridedStack stk{stack + tid, B::threads};
+    bool overflow = false;
+    uint8_t occ;
     if (MODE == 0) {
-        const Ray r = make_ray_reference(N, ix, iy, iz);
-        Hit best;
-        if (!trace_reference(r, p.nodes, p.triPos, stk, STACK, best)) atomicOr(p.status, 1u);
         uint32_t texel = 0;
-        if (best.k != 0xffffffffu) {                     // else missMain: nothing written
-            const TriNrm tn = p.triNrm[best.leaf];
-            float nx, ny, nz;
-            occ = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz) ? 1 : 0;
-            if (TEXELS && occ) texel = pack_texel(nx, ny, nz);
-        }
+        occ = voxel_reference(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
         if (TEXELS) p.texels[id] = texel;
     } else {
-        const Ray r = make_ray_parity(N, ix, iy, iz);
-        uint32_t count;
-        if (!trace_parity(r, p.nodes, p.triPos, stk, STACK, count)) atomicOr(p.status, 1u);
-        occ = (uint8_t)(count & 1u);
+        occ = voxel_parity(p.scene, N, ix, iy, iz, stk, STACK, overflow);
     }
+    if (overflow) atomicOr(p.status, 1u);
     p.grid[id] = occ;
 }
 
-using BrickRow = Brick<64, 4, 1>;    // wave = 64x1x1 row
-using BrickTile = Brick<8, 8, 4>;    // wave = 8x8x1 tile
-using BrickCube = Brick<4, 4, 16>;   // wave = 4x4x4 cube
-using BrickSlab = Brick<16, 4, 4>;   // wave = 16x4x1
+// brick shapes: (x, y, z) voxels per workgroup; a wavefront owns 64 consecutive threads of it
+using Brick0 = Brick<64, 4, 1>;    // 256 threads, wave = 64x1x1 row
+using Brick1 = Brick<8, 8, 4>;     // 256 threads, wave = 8x8x1 tile
+using Brick2 = Brick<4, 4, 16>;    // 256 threads, wave = 4x4x4 cube
+using Brick3 = Brick<16, 4, 4>;    // 256 threads, wave = 16x4x1
+using Brick4 = Brick<4, 4, 4>;     // 64 threads,  one wave per workgroup
+using Brick5 = Brick<8, 8, 1>;     // 64 threads
+using Brick6 = Brick<4, 4, 8>;     // 128 threads
+using Brick7 = Brick<8, 4, 2>;     // 64 threads
 
-int num_brick_shapes() { return 4; }
+int num_brick_shapes() { return 8; }
 
 template <class B, int STACK>
 static hipError_t launch_shape(const VoxelizeParams& p, hipStream_t s)
@@ -79,7 +75,7 @@ static hipError_t launch_shape(const VoxelizeParams& p, hipStream_t s)
     const uint64_t chunk = (nb + 7) / 8;
     const uint64_t grid = chunk * 8;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const dim3 g((uint32_t)grid), b(256);
+    const dim3 g((uint32_t)grid), b(B::threads);
     if (p.mode == 0) {
         if (p.texels) k_voxelize<B, STACK, 0, true><<<g, b, 0, s>>>(p);
         else k_voxelize<B, STACK, 0, false><<<g, b, 0, s>>>(p);
@@ -93,6 +89,8 @@ template <class B>
 static hipError_t launch_stack(const VoxelizeParams& p, int stackEntries, hipStream_t s)
 {
     switch (stackEntries) {
+    case 8: return launch_shape<B, 8>(p, s);
+    case 12: return launch_shape<B, 12>(p, s);
     case 16: return launch_shape<B, 16>(p, s);
     case 24: return launch_shape<B, 24>(p, s);
     case 32: return launch_shape<B, 32>(p, s);
@@ -101,28 +99,27 @@ static hipError_t launch_stack(const VoxelizeParams& p, int stackEntries, hipStr
     }
 }
 
-// The stack holds internal nodes only and one entry per level at most, so treeHeight - 1 entries
-// always suffice; pick the smallest instantiated depth that covers it (LDS = depth * 1 KiB).
-static int stack_for_height(uint32_t h)
+// The stack holds internal nodes only, one entry per level at most: treeHeight entries always
+// suffice.  Smallest instantiated depth >= want (LDS = depth * 4 B per thread).
+int stack_round_up(int want)
 {
-    const int need = (int)h;
-    if (need <= 16) return 16;
-    if (need <= 24) return 24;
-    if (need <= 32) return 32;
-    if (need <= 48) return 48;
+    const int sizes[] = {8, 12, 16, 24, 32, 48, 64};
+    for (int v : sizes) if (want <= v) return v;
     return 64;
 }
 
-hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int forceStack, hipStream_t s, uint32_t* stackUsed)
+hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s)
 {
-    const int st = forceStack > 0 ? forceStack : stack_for_height(p.treeHeight);
-    if (st != 16 && st != 24 && st != 32 && st != 48 && st != 64) return hipErrorInvalidValue;
-    if (stackUsed) *stackUsed = (uint32_t)st;
+    if (stack_round_up(stackEntries) != stackEntries) return hipErrorInvalidValue;
     switch (brickShape) {
-    case 0: return launch_stack<BrickRow>(p, st, s);
-    case 1: return launch_stack<BrickTile>(p, st, s);
-    case 2: return launch_stack<BrickCube>(p, st, s);
-    case 3: return launch_stack<BrickSlab>(p, st, s);
+    case 0: return launch_stack<Brick0>(p, stackEntries, s);
+    case 1: return launch_stack<Brick1>(p, stackEntries, s);
+    case 2: return launch_stack<Brick2>(p, stackEntries, s);
+    case 3: return launch_stack<Brick3>(p, stackEntries, s);
+    case 4: return launch_stack<Brick4>(p, stackEntries, s);
+    case 5: return launch_stack<Brick5>(p, stackEntries, s);
+    case 6: return launch_stack<Brick6>(p, stackEntries, s);
+    case 7: return launch_stack<Brick7>(p, stackEntries, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -764,6 +764,37 @@ ORC_API int orc_voxelize(const orc_scene* s, uint32_t N, int mode, int algo, uin
     return 0;
 }
 
+/* Same as orc_voxelize for an arbitrary list of slices (one parallel region over all their rows:
+ * the cpu_baseline sample of bench.py). out = nlist * N * N bytes, slice j of the list first. */
+ORC_API int orc_voxelize_slices(const orc_scene* s, uint32_t N, int mode, int algo, const uint32_t* zlist,
+                                uint32_t nlist, int threads, uint8_t* out)
+{
+    if (!s || !out || !zlist || N < 2 || (N & 1u)) return 1;
+    for (uint32_t j = 0; j < nlist; ++j) if (zlist[j] >= N) return 1;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads); else omp_set_num_threads(omp_get_num_procs());
+#else
+    (void)threads;
+#endif
+    const int64_t rows = (int64_t)nlist * N;
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int64_t row = 0; row < rows; ++row) {
+        const uint32_t iz = zlist[row / N], iy = (uint32_t)(row % N);
+        uint8_t* dst = out + (size_t)row * N;
+        for (uint32_t ix = 0; ix < N; ++ix) {
+            if (mode == ORC_MODE_REFERENCE) {
+                dst[ix] = (uint8_t)orc_voxel_reference(s, N, ix, iy, iz, algo, NULL, NULL, NULL, NULL);
+            } else {
+                orc_ray r;
+                ray_make_parity(&r, N, ix, iy, iz);
+                const uint32_t c = algo == ORC_ALGO_BRUTE ? count_par_brute(s, &r) : count_par_bvh(s, &r);
+                dst[ix] = (uint8_t)(c & 1u);
+            }
+        }
+    }
+    return 0;
+}
+
 ORC_API int orc_num_procs(void)
 {
 #ifdef _OPENMP

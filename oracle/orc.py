@@ -54,6 +54,8 @@ def lib():
         L.orc_voxelize.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
                                    _u8p, C.c_void_p]
         L.orc_voxelize.restype = C.c_int
+        L.orc_voxelize_slices.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, _u32p, C.c_uint32, C.c_int, _u8p]
+        L.orc_voxelize_slices.restype = C.c_int
         L.orc_num_procs.restype = C.c_int
         _LIB = L
     return _LIB
@@ -124,6 +126,15 @@ class Scene:
         if rc:
             raise RuntimeError(f"orc_voxelize -> {rc}")
         return (out, tex) if texels else out
+
+
+def voxelize_slices(scene, N, zlist, mode=MODE_REFERENCE, algo=ALGO_BVH, threads=0):
+    z = np.ascontiguousarray(zlist, np.uint32)
+    out = np.zeros((len(z), N, N), np.uint8)
+    rc = lib().orc_voxelize_slices(scene._h, N, mode, algo, z, len(z), threads, out)
+    if rc:
+        raise RuntimeError(f"orc_voxelize_slices -> {rc}")
+    return out
 
 
 def ref_objloader(path, out_bin=None):

@@ -107,6 +107,11 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
 {
     HcScene* s = static_cast<HcScene*>(p);
     int overflow = 0;
+    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    {   // root box = union of the root node's two child boxes (as k_root_info computes it)
+        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
+        for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
+    }
 #pragma omp parallel for schedule(dynamic, 4) reduction(| : overflow)
     for (int64_t row = 0; row < (int64_t)nz * N; ++row) {
         const uint32_t lz = (uint32_t)(row / N), iy = (uint32_t)(row % N), iz = z0 + lz;
@@ -114,29 +119,42 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
         StridedStack stk{stack, 1};
         for (uint32_t ix = 0; ix < N; ++ix) {
             const size_t id = ((size_t)lz * N + iy) * N + ix;
-            uint8_t occ = 0;
-            if (mode == 0) {
-                const Ray r = make_ray_reference(N, ix, iy, iz);
-                Hit best;
-                if (!trace_reference(r, s->nodes.data(), s->triPos.data(), stk, stackCap, best)) overflow |= 1;
-                uint32_t texel = 0;
-                if (best.k != 0xffffffffu) {
-                    const TriNrm& tn = s->triNrm[best.leaf];
-                    float nx, ny, nz_;
-                    occ = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz_) ? 1 : 0;
-                    if (occ) texel = pack_texel(nx, ny, nz_);
-                }
-                if (texels) texels[id] = texel;
-            } else {
-                const Ray r = make_ray_parity(N, ix, iy, iz);
-                uint32_t count;
-                if (!trace_parity(r, s->nodes.data(), s->triPos.data(), stk, stackCap, count)) overflow |= 1;
-                occ = (uint8_t)(count & 1u);
-            }
-            out[id] = occ;
+            bool ovf = false;
+            uint32_t texel = 0;
+            out[id] = mode == 0 ? voxel_reference(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
+                                : voxel_parity(sc, N, ix, iy, iz, stk, stackCap, ovf);
+            if (texels) texels[id] = texel;
+            if (ovf) overflow |= 1;
         }
     }
     return overflow;
+}
+
+// per-ray traversal statistics over slices z0, z0+zstep, ... (tuning aid):
+// out[0] rays, out[1] internal-node visits, out[2] leaf tests, out[3] max stack depth,
+// out[4] rays with zero leaf tests, out[5] rays with <= 2 node visits; hist[64] of max stack depth
+__attribute__((visibility("default"))) void hc_trace_stats(void* p, uint32_t N, uint32_t zstep, uint64_t* out, uint64_t* hist)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    uint64_t rays = 0, nodes = 0, leaves = 0, maxsp = 0, noleaf = 0, trivial = 0;
+    uint64_t h[64] = {0};
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, nodes, leaves, noleaf, trivial, h[:64]) reduction(max : maxsp)
+    for (int64_t row = 0; row < (int64_t)((N + zstep - 1) / zstep) * N; ++row) {
+        const uint32_t iz = (uint32_t)(row / N) * zstep, iy = (uint32_t)(row % N);
+        int32_t stack[128];
+        StridedStack stk{stack, 1};
+        for (uint32_t ix = 0; ix < N; ++ix) {
+            Ray r = make_ray_reference(N, ix, iy, iz);
+            Hit best;
+            TraceStats st{0, 0, 0};
+            trace_reference<StridedStack, true>(r, s->nodes.data(), s->triPos.data(), stk, 128, best, &st);
+            rays++; nodes += st.nodes; leaves += st.leaves; noleaf += st.leaves == 0; trivial += st.nodes <= 2;
+            if (st.maxsp > maxsp) maxsp = st.maxsp;
+            h[st.maxsp < 63 ? st.maxsp : 63]++;
+        }
+    }
+    out[0] = rays; out[1] = nodes; out[2] = leaves; out[3] = maxsp; out[4] = noleaf; out[5] = trivial;
+    for (int i = 0; i < 64; ++i) hist[i] = h[i];
 }
 
 } // extern "C"

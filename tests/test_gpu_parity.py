@@ -149,8 +149,8 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
     vb, ib, _ = dragon
     vox.InitFromArrays(vb, ib)
     want = orc.Scene(vb, ib).voxelize(64)
-    for brick in range(4):
-        for stack in (0, 32, 48, 64):
+    for brick in range(8):
+        for stack in (0, 12, 32, 64):
             vox.set_option("brick", brick)
             vox.set_option("stack", stack)
             vox.Voxelize(64)
@@ -212,14 +212,26 @@ def test_errors_are_loud(dxv, bunny):
         v.InitFromArrays(vb, np.array([0, 1, 10 ** 6], np.uint32))
     with pytest.raises(dxv.DxvError):
         v.InitFromArrays(np.zeros((3, 6), np.float32), np.arange(3, dtype=np.uint32))   # zero extent
-    v.InitFromArrays(vb, ib)
-    v.set_option("stack", 16)                             # bunny's tree is deeper than 16
-    if v.stats()["tree_height"] > 17:
-        with pytest.raises(dxv.DxvError) as e:
-            v.Voxelize(64)
-        assert "stack" in str(e.value)
-    v.set_option("stack", 0)
-    v.Voxelize(64)                                        # and the context recovers
+    # 2^17+ identical triangles: every ray that hits them descends both children at every level
+    tri = np.zeros((5, 6), np.float32)
+    tri[:3, :3] = [[-0.9, -0.9, 0.4], [0.9, -0.9, 0.4], [0.0, 0.9, 0.4]]
+    tri[:3, 3:] = [0.57735, 0.57735, 0.57735]
+    tri[3, :3], tri[4, :3] = [-1, -1, -1], [1, 1, 1]
+    deep = np.tile(np.arange(3, dtype=np.uint32), 140000)
+    v.InitFromArrays(tri, deep)
+    assert v.stats()["tree_height"] >= 17
+    v.set_option("stack", 8)                              # forced depth: overflow must be reported
+    with pytest.raises(dxv.DxvError) as e:
+        v.Voxelize(16)
+    assert "stack" in str(e.value)
+    v.set_option("stack", 0)                              # adaptive: grows once, then succeeds
+    v.Voxelize(16)
+    assert v.stats()["stack_entries"] >= 17
+    one = dxv.Voxelizer(0)
+    one.InitFromArrays(tri, np.arange(3, dtype=np.uint32))
+    one.Voxelize(16)
+    assert np.array_equal(v.Grid(), one.Grid())           # 140000 coincident copies == one triangle
+    one.close()
     v.close()
 
 

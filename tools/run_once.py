@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Minimal driver for profilers (no torch): build the scene once, voxelize K times.
+    python3 tools/run_once.py [mesh] [N] [K] [mode] [key=value ...]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dxrvoxelizer_amd as dxv  # noqa: E402
+from bench import make_mesh  # noqa: E402
+
+mesh = sys.argv[1] if len(sys.argv) > 1 else "torus1m"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+mode = dxv.MODE_PARITY if len(sys.argv) > 4 and sys.argv[4] == "parity" else dxv.MODE_REFERENCE
+v = dxv.Voxelizer(0)
+for kv in sys.argv[5:]:
+    k, val = kv.split("=")
+    v.set_option(k, int(val))
+vb, ib, _ = make_mesh(mesh)
+v.InitFromArrays(vb, ib)
+for _ in range(K):
+    v.Voxelize(N, mode)
+print(v.stats(), v.CountSolid())
+v.close()
