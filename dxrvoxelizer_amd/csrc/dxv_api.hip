@@ -64,6 +64,8 @@ struct dxv_ctx {
     int optBrick = 4;        // 4x4x4 voxels = one wavefront per workgroup (fastest in the r01 sweeps)
     int optStack = 0;        // 0 = adaptive (start small, grow on overflow), else forced depth
     int optRefit = 0;
+    int optMorton = 1;       // Morton brick order
+    int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
     int stackNow = 16;       // adaptive: LDS stack entries per thread currently in use for this scene
     int lastMode = 0;
     bool pending = false;    // a voxelize launch has not been checked by dxv_sync yet
@@ -160,6 +162,8 @@ int launch_now(dxv_ctx* c)
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
     p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
     p.N = c->stats.grid_dim; p.z0 = c->stats.z0; p.nz = c->stats.nz; p.mode = c->lastMode;
+    p.morton = (uint32_t)c->optMorton;
+    p.regionBits = (uint32_t)c->optRegion;
     const int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
@@ -481,6 +485,12 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "refit")) {
         if (value != 0 && value != 1) return fail(c, "option refit: %lld not in {0,1}", (long long)value);
         c->optRefit = (int)value;
+    } else if (!strcmp(key, "region")) {
+        if (value < 0 || value > 24) return fail(c, "option region: %lld not in [0,24]", (long long)value);
+        c->optRegion = (int)value;
+    } else if (!strcmp(key, "morton")) {
+        if (value != 0 && value != 1) return fail(c, "option morton: %lld not in {0,1}", (long long)value);
+        c->optMorton = (int)value;
     } else return fail(c, "unknown option '%s'", key);
     return 0;
 }

@@ -40,6 +40,9 @@ struct VoxelizeParams {
     uint32_t* status;       // status word (bit 0: traversal stack overflow)
     uint32_t N, z0, nz;
     int mode;
+    uint32_t morton;        // 1: Morton brick order (default), 0: linear x,y,z order
+    uint32_t mortonBits;    // filled by the launcher
+    uint32_t regionBits;    // log2 of the bricks per XCD region
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
 int stack_round_up(int want);

@@ -12,8 +12,8 @@
 // the current closest t can never drop an acceptable triangle.
 //
 // Leaves never enter the stack: a hit leaf child is intersected while its parent is visited
-// (its entry distance is at hand there), so the stack holds internal nodes only and its depth
-// is bounded by the tree height.
+// (its entry distance is at hand there), so the stack holds internal nodes only: at most one
+// entry per level plus the sentinel, i.e. treeHeight entries always suffice.
 #pragma once
 #include "dxv_math.h"
 
@@ -33,18 +33,25 @@ struct StridedStack {
     DXV_HD int32_t get(int e) const { return base[e * stride]; }
 };
 
+// 32-bit byte offsets from a wave-uniform base: the device build addresses nodes and triangles
+// as base(SGPR pair) + offset(VGPR) (up to 4 GiB of nodes = 67 M nodes per scene).
 DXV_HD void load_node(const Node* nodes, int32_t i, F4& q0, F4& q1, F4& q2, int32_t& c0, int32_t& c1)
 {
-    const F4* p = reinterpret_cast<const F4*>(nodes + i);
+    const F4* p = reinterpret_cast<const F4*>(reinterpret_cast<const char*>(nodes) + ((uint32_t)i << 6));
     q0 = p[0]; q1 = p[1]; q2 = p[2];
     const F4 q3 = p[3];
     c0 = __builtin_bit_cast(int32_t, q3.x);
     c1 = __builtin_bit_cast(int32_t, q3.y);
 }
 
+DXV_HD TriPos load_tri(const TriPos* tris, int32_t leaf)
+{
+    return *reinterpret_cast<const TriPos*>(reinterpret_cast<const char*>(tris) + (uint32_t)leaf * 48u);
+}
+
 DXV_HD void leaf_reference(Ray& r, const TriPos* tris, int32_t leaf, float tn, Hit& best)
 {
-    const TriPos tp = tris[leaf];
+    const TriPos tp = load_tri(tris, leaf);
     if (r.kz < 0) ray_shear(r);
     float t, b1, b2;
     if (!tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2)) return;
@@ -57,14 +64,18 @@ DXV_HD void leaf_reference(Ray& r, const TriPos* tris, int32_t leaf, float tn, H
 struct TraceStats { uint32_t nodes, leaves, maxsp; };
 
 // Returns false when the stack capacity was exceeded (caller reports the error).
+// Entry 0 of the stack holds a negative sentinel, so "pop" needs no emptiness test and the loop has
+// a single exit (node < 0); capacity for real entries is cap - 1.
 template <class Stack, bool STATS = false>
 DXV_HD bool trace_reference(Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
                             TraceStats* st = nullptr)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
-    int sp = 0;
+    stk.put(0, -1);
+    int sp = 1;
+    bool ok = true;
     int32_t node = 0;
-    for (;;) {
+    while (node >= 0) {
         F4 q0, q1, q2;
         int32_t c0, c1;
         load_node(nodes, node, q0, q1, q2, c0, c1);
@@ -72,31 +83,31 @@ DXV_HD bool trace_reference(Ray& r, const Node* nodes, const TriPos* tris, const
         float tn0, tn1;
         bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= best.t;
         bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= best.t;
-        if (STATS) st->leaves += (h0 && c0 < 0) + (h1 && c1 < 0);
-        if (h0 && c0 < 0) { leaf_reference(r, tris, ~c0, tn0, best); h0 = false; }
-        if (h1 && c1 < 0) { leaf_reference(r, tris, ~c1, tn1, best); h1 = false; }
-        h0 = h0 && tn0 <= best.t;
-        h1 = h1 && tn1 <= best.t;
-        if (h0 && h1) {
-            const bool swap = tn1 < tn0;
-            const int32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
-            if (sp >= cap) return false;
-            stk.put(sp++, farc);
-            if (STATS && (uint32_t)sp > st->maxsp) st->maxsp = (uint32_t)sp;
-            node = nearc;
-        } else if (h0) node = c0;
-        else if (h1) node = c1;
-        else {
-            if (sp == 0) break;
-            node = stk.get(--sp);
+        const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
+        if (STATS) st->leaves += l0 + l1;
+        if (l0 || l1) {
+            // lanes with a leaf in either child test it together; a second leaf is the rare case
+            leaf_reference(r, tris, l0 ? ~c0 : ~c1, l0 ? tn0 : tn1, best);
+            if (l0 && l1) leaf_reference(r, tris, ~c1, tn1, best);
         }
+        h0 = h0 && c0 >= 0 && tn0 <= best.t;
+        h1 = h1 && c1 >= 0 && tn1 <= best.t;
+        const bool both = h0 && h1;
+        const bool swap = tn1 < tn0;
+        if (both) {
+            if (sp >= cap) { ok = false; break; }
+            stk.put(sp++, swap ? c0 : c1);
+            if (STATS && (uint32_t)(sp - 1) > st->maxsp) st->maxsp = (uint32_t)(sp - 1);
+        }
+        if (h0 || h1) node = (h0 && !(both && swap)) ? c0 : c1;
+        else node = stk.get(--sp);
     }
-    return true;
+    return ok;
 }
 
 DXV_HD uint32_t leaf_parity(const Ray& r, const TriPos* tris, int32_t leaf)
 {
-    const TriPos tp = tris[leaf];
+    const TriPos tp = load_tri(tris, leaf);
     float t, b1, b2;
     return tri_test<true>(r, tp.v0, tp.v1, tp.v2, t, b1, b2) ? 1u : 0u;
 }
@@ -105,28 +116,31 @@ template <class Stack>
 DXV_HD bool trace_parity(const Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, uint32_t& count)
 {
     count = 0;
-    int sp = 0;
+    stk.put(0, -1);
+    int sp = 1;
+    bool ok = true;
     int32_t node = 0;
-    for (;;) {
+    while (node >= 0) {
         F4 q0, q1, q2;
         int32_t c0, c1;
         load_node(nodes, node, q0, q1, q2, c0, c1);
         bool h0 = slab_parity(r, q0.y, q0.z, q0.w, q1.x, q1.y);
         bool h1 = slab_parity(r, q1.w, q2.x, q2.y, q2.z, q2.w);
-        if (h0 && c0 < 0) { count += leaf_parity(r, tris, ~c0); h0 = false; }
-        if (h1 && c1 < 0) { count += leaf_parity(r, tris, ~c1); h1 = false; }
-        if (h0 && h1) {
-            if (sp >= cap) return false;
-            stk.put(sp++, c1);
-            node = c0;
-        } else if (h0) node = c0;
-        else if (h1) node = c1;
-        else {
-            if (sp == 0) break;
-            node = stk.get(--sp);
+        const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
+        if (l0 || l1) {
+            count += leaf_parity(r, tris, l0 ? ~c0 : ~c1);
+            if (l0 && l1) count += leaf_parity(r, tris, ~c1);
         }
+        h0 = h0 && c0 >= 0;
+        h1 = h1 && c1 >= 0;
+        if (h0 && h1) {
+            if (sp >= cap) { ok = false; break; }
+            stk.put(sp++, c1);
+        }
+        if (h0 || h1) node = h0 ? c0 : c1;
+        else node = stk.get(--sp);
     }
-    return true;
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -21,6 +21,16 @@ struct Brick {
     static_assert(threads == 64 || threads == 128 || threads == 256, "one voxel per thread, whole wavefronts");
 };
 
+__device__ __forceinline__ uint32_t compact1by2(uint32_t x)
+{
+    x &= 0x09249249u;
+    x = (x ^ (x >> 2)) & 0x030c30c3u;
+    x = (x ^ (x >> 4)) & 0x0300f00fu;
+    x = (x ^ (x >> 8)) & 0xff0000ffu;
+    x = (x ^ (x >> 16)) & 0x000003ffu;
+    return x;
+}
+
 template <class B, int STACK, int MODE, bool TEXELS>
 __global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
 {
@@ -28,11 +38,23 @@ __global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
     const uint32_t N = p.N;
     const uint32_t nbx = (N + B::x - 1) / B::x, nby = (N + B::y - 1) / B::y, nbz = (p.nz + B::z - 1) / B::z;
     const uint32_t nb = nbx * nby * nbz;
-    // XCD-aware remap: workgroups b and b + 8 share an XCD; give each XCD a contiguous chunk
-    const uint32_t chunk = (nb + 7u) / 8u;
-    const uint32_t lin = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    // XCD-aware remap: workgroups b and b + 8 share an XCD.  Bricks are numbered along a Morton
+    // curve (below); runs of 2^regionBits consecutive bricks (compact regions) are dealt round-robin
+    // to the 8 XCDs: each XCD's L2 sees compact regions, and the regions of all XCDs are fine
+    // grained enough to balance the very uneven per-region cost.
+    const uint32_t rb = p.regionBits;
+    const uint32_t j = blockIdx.x >> 3;
+    const uint32_t lin = ((((j >> rb) << 3) | (blockIdx.x & 7u)) << rb) | (j & ((1u << rb) - 1u));
     if (lin >= nb) return;
-    const uint32_t bx = lin % nbx, by = (lin / nbx) % nby, bz = lin / (nbx * nby);
+    // brick order: Morton inside 2^m-brick super-blocks (m = p.mortonBits, the largest power of two
+    // dividing all three brick counts), super-blocks linear.  Consecutive workgroups of an XCD then
+    // cover a compact region and reuse the same part of the tree in L1/L2.
+    const uint32_t m = p.mortonBits;
+    const uint32_t low = lin & ((1u << (3u * m)) - 1u), high = lin >> (3u * m);
+    const uint32_t sx = nbx >> m, sy = nby >> m;
+    const uint32_t bx = ((high % sx) << m) | compact1by2(low);
+    const uint32_t by = (((high / sx) % sy) << m) | compact1by2(low >> 1);
+    const uint32_t bz = ((high / (sx * sy)) << m) | compact1by2(low >> 2);
     const uint32_t tid = threadIdx.x;
     const uint32_t ix = bx * B::x + tid % B::x;
     const uint32_t iy = by * B::y + (tid / B::x) % B::y;
@@ -68,12 +90,19 @@ using Brick7 = Brick<8, 4, 2>;     // 64 threads
 int num_brick_shapes() { return 8; }
 
 template <class B, int STACK>
-static hipError_t launch_shape(const VoxelizeParams& p, hipStream_t s)
+static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
 {
+    VoxelizeParams p = pin;
     const uint32_t nbx = (p.N + B::x - 1) / B::x, nby = (p.N + B::y - 1) / B::y, nbz = (p.nz + B::z - 1) / B::z;
+    uint32_t m = 0;
+    while (m < 10 && p.morton && !((nbx >> m) & 1u) && !((nby >> m) & 1u) && !((nbz >> m) & 1u)) ++m;
+    p.mortonBits = m;
     const uint64_t nb = (uint64_t)nbx * nby * nbz;
-    const uint64_t chunk = (nb + 7) / 8;
-    const uint64_t grid = chunk * 8;
+    uint32_t rb = p.regionBits;
+    while (rb > 0 && (8ull << rb) > nb) --rb;          // small grids: keep all XCDs busy
+    p.regionBits = rb;
+    const uint64_t span = 8ull << rb;                  // bricks per round of 8 regions
+    const uint64_t grid = (nb + span - 1) / span * span;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 g((uint32_t)grid), b(B::threads);
     if (p.mode == 0) {

@@ -150,11 +150,15 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
     vox.InitFromArrays(vb, ib)
     want = orc.Scene(vb, ib).voxelize(64)
     for brick in range(8):
-        for stack in (0, 12, 32, 64):
+        for stack, morton, region in ((0, 1, 9), (32, 0, 0), (64, 1, 3), (0, 0, 20), (48, 1, 24)):
             vox.set_option("brick", brick)
             vox.set_option("stack", stack)
+            vox.set_option("morton", morton)
+            vox.set_option("region", region)
             vox.Voxelize(64)
-            assert np.array_equal(vox.Grid(), want), (brick, stack)
+            assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region)
+    vox.set_option("morton", 1)
+    vox.set_option("region", 9)
     for n in (2, 6, 30, 66):                 # grids that do not fill whole bricks
         vox.set_option("brick", 1)
         vox.set_option("stack", 0)
