@@ -65,8 +65,10 @@ struct dxv_ctx {
     int optStack = 0;        // 0 = adaptive (start small, grow on overflow), else forced depth
     int optRefit = 0;
     int optMorton = 1;       // Morton brick order
+    int optQueue = 1;        // postponed-leaf traversal
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
-    int stackNow = 16;       // adaptive: LDS stack entries per thread currently in use for this scene
+    int optStack0 = 24;      // adaptive mode starts with this many entries (stack + leaf queue share them)
+    int stackNow = 24;       // adaptive: LDS stack entries per thread currently in use for this scene
     int lastMode = 0;
     bool pending = false;    // a voxelize launch has not been checked by dxv_sync yet
 };
@@ -152,7 +154,8 @@ float elapsed(hipEvent_t a, hipEvent_t b)
 // than a dozen, and LDS (entries * 4 B * threads) is what limits resident waves.  Adaptive mode
 // starts at 16 entries; a kernel that runs out reports it through the status word and dxv_sync
 // re-runs the launch with the always-sufficient depth and keeps it for this scene.
-int safe_stack(const dxv_ctx* c) { return stack_round_up((int)c->hdr.treeHeight); }
+// (+3: the postponed-leaf traversal keeps room for one push and two queued leaves)
+int safe_stack(const dxv_ctx* c) { return stack_round_up((int)c->hdr.treeHeight + 3); }
 
 int launch_now(dxv_ctx* c)
 {
@@ -164,6 +167,7 @@ int launch_now(dxv_ctx* c)
     p.N = c->stats.grid_dim; p.z0 = c->stats.z0; p.nz = c->stats.nz; p.mode = c->lastMode;
     p.morton = (uint32_t)c->optMorton;
     p.regionBits = (uint32_t)c->optRegion;
+    p.queued = (uint32_t)c->optQueue;
     const int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
@@ -311,7 +315,7 @@ int dxv_build(dxv_ctx* c)
     DXV_HIP(c, hipMemcpyAsync(c->dScene, &c->hdr, sizeof(SceneHeader), hipMemcpyHostToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->haveScene = true;
-    c->stackNow = stack_round_up((int)(c->hdr.treeHeight < 16 ? c->hdr.treeHeight : 16));
+    c->stackNow = stack_round_up((int)(c->hdr.treeHeight + 3 < (uint32_t)c->optStack0 ? c->hdr.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_nodes = c->hdr.numNodes;
     c->stats.tree_height = c->hdr.treeHeight;
     c->stats.prep_ms = elapsed(c->ev[0], c->ev[1]);
@@ -458,7 +462,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     c->T = h.numTris; c->V = h.numVerts;
     memcpy(c->bound, h.bound, sizeof(c->bound));
     c->haveScene = true;
-    c->stackNow = stack_round_up((int)(h.treeHeight < 16 ? h.treeHeight : 16));
+    c->stackNow = stack_round_up((int)(h.treeHeight + 3 < (uint32_t)c->optStack0 ? h.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_tris = h.numTris; c->stats.num_verts = h.numVerts; c->stats.num_nodes = h.numNodes;
     c->stats.tree_height = h.treeHeight;
     memcpy(c->stats.bound, h.bound, sizeof(h.bound));
@@ -485,6 +489,13 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "refit")) {
         if (value != 0 && value != 1) return fail(c, "option refit: %lld not in {0,1}", (long long)value);
         c->optRefit = (int)value;
+    } else if (!strcmp(key, "queue")) {
+        if (value != 0 && value != 1) return fail(c, "option queue: %lld not in {0,1}", (long long)value);
+        c->optQueue = (int)value;
+    } else if (!strcmp(key, "stack0")) {
+        if (value < 8 || value > 64 || stack_round_up((int)value) != (int)value) return fail(c, "option stack0: bad depth %lld", (long long)value);
+        c->optStack0 = (int)value;
+        if (c->haveScene) c->stackNow = stack_round_up((int)(c->hdr.treeHeight + 3 < (uint32_t)value ? c->hdr.treeHeight + 3 : (uint32_t)value));
     } else if (!strcmp(key, "region")) {
         if (value < 0 || value > 24) return fail(c, "option region: %lld not in [0,24]", (long long)value);
         c->optRegion = (int)value;

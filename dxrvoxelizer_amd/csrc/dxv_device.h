@@ -43,6 +43,7 @@ struct VoxelizeParams {
     uint32_t morton;        // 1: Morton brick order (default), 0: linear x,y,z order
     uint32_t mortonBits;    // filled by the launcher
     uint32_t regionBits;    // log2 of the bricks per XCD region
+    uint32_t queued;        // 1: postponed-leaf traversal (default), 0: leaves tested on the spot
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
 int stack_round_up(int want);

@@ -105,6 +105,128 @@ DXV_HD bool trace_reference(Ray& r, const Node* nodes, const TriPos* tris, const
     return ok;
 }
 
+// wave-level vote.  Device: true when the predicate holds in any active lane of the wavefront;
+// host (tests/hostcheck runs one ray at a time): the ray's own predicate.
+DXV_HD bool wave_any(bool x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(x) != 0ull;
+#else
+    return x;
+#endif
+}
+
+// Postponed-leaf traversal (default).  Walking internal nodes is cheap and coherent across the
+// wave; triangle tests are long and, done on the spot, run with a handful of lanes.  So hit leaf
+// children are only QUEUED (leaf index in the same LDS column as the stack: stack grows up from
+// entry 0, queue down from entry cap-1) while every lane keeps walking; the wave tests queued
+// triangles together when some lane's column is nearly full or no lane can walk any more.  Order of
+// tests does not matter for the result (closest = min (t, k)); a queued triangle's own box entry
+// distance is recomputed from its vertices exactly as the refit computed the leaf box.
+// One internal-node visit of the postponed-leaf walk: two slab tests, hit leaves queued, near child
+// next, far child pushed.  The twelve box planes and two links arrive by value so that the device
+// build can feed them from SGPRs (wave-uniform visit, scalar load) or VGPRs (divergent visit).
+template <class Stack>
+DXV_HD void node_step(const Ray& r, float lo0x, float lo0y, float lo0z, float hi0x, float hi0y, float hi0z,
+                      float lo1x, float lo1y, float lo1z, float hi1x, float hi1y, float hi1z, int32_t c0, int32_t c1,
+                      const Stack& stk, int cap, float bestT, int32_t& node, int& sp, int& qn)
+{
+    float tn0, tn1;
+    bool h0 = slab(r, lo0x, lo0y, lo0z, hi0x, hi0y, hi0z, tn0) && tn0 <= bestT;
+    bool h1 = slab(r, lo1x, lo1y, lo1z, hi1x, hi1y, hi1z, tn1) && tn1 <= bestT;
+    if (h0 && c0 < 0) stk.put(cap - 1 - qn++, ~c0);
+    if (h1 && c1 < 0) stk.put(cap - 1 - qn++, ~c1);
+    h0 = h0 && c0 >= 0;
+    h1 = h1 && c1 >= 0;
+    const bool both = h0 && h1;
+    const bool swap = tn1 < tn0;
+    if (both) stk.put(sp++, swap ? c0 : c1);
+    if (h0 || h1) node = (h0 && !(both && swap)) ? c0 : c1;
+    else node = stk.get(--sp);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// 64-B node through the scalar cache into 16 SGPRs (nodes are read-only during the kernel).
+// Eight 64-bit outputs: plain scalar-pair operands, which hipcc tracks reliably (512- and 128-bit
+// SGPR tuples as asm outputs were mis-tracked by ROCm 7.2's hipcc: elements folded together).
+struct NodeSgpr { uint64_t w[8]; };
+__device__ __forceinline__ NodeSgpr load_node_scalar(const Node* nodes, int32_t uniformIndex)
+{
+    const char* p = reinterpret_cast<const char*>(nodes) + ((uint64_t)(uint32_t)uniformIndex << 6);
+    NodeSgpr n;
+    asm volatile("s_load_dwordx2 %0, %8, 0x0\n\ts_load_dwordx2 %1, %8, 0x8\n\ts_load_dwordx2 %2, %8, 0x10\n\t"
+                 "s_load_dwordx2 %3, %8, 0x18\n\ts_load_dwordx2 %4, %8, 0x20\n\ts_load_dwordx2 %5, %8, 0x28\n\t"
+                 "s_load_dwordx2 %6, %8, 0x30\n\ts_load_dwordx2 %7, %8, 0x38\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(n.w[0]), "=&s"(n.w[1]), "=&s"(n.w[2]), "=&s"(n.w[3]), "=&s"(n.w[4]), "=&s"(n.w[5]),
+                   "=&s"(n.w[6]), "=&s"(n.w[7])
+                 : "s"(p) : "memory");
+    return n;
+}
+__device__ __forceinline__ float sgpr_lo(uint64_t v) { return __builtin_bit_cast(float, (uint32_t)v); }
+__device__ __forceinline__ float sgpr_hi(uint64_t v) { return __builtin_bit_cast(float, (uint32_t)(v >> 32)); }
+#endif
+
+template <class Stack, bool STATS = false>
+DXV_HD bool trace_reference_q(Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
+                              TraceStats* st = nullptr)
+{
+    best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
+    stk.put(0, -1);
+    int sp = 1, qn = 0;
+    bool ok = true;
+    int32_t node = 0;
+    for (;;) {
+        if (node >= 0) {
+            if (STATS) st->nodes++;
+#if defined(__HIP_DEVICE_COMPILE__)
+            // all lanes that are still walking sit on the same node (40-50 % of the visits): one
+            // scalar load instead of 64 lanes x 64 B through the vector L1
+            const int32_t n0 = __builtin_amdgcn_readfirstlane(node);
+            if (__builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
+                const NodeSgpr n = load_node_scalar(nodes, n0);
+                node_step(r, sgpr_lo(n.w[0]), sgpr_hi(n.w[0]), sgpr_lo(n.w[1]), sgpr_hi(n.w[1]), sgpr_lo(n.w[2]),
+                          sgpr_hi(n.w[2]), sgpr_lo(n.w[3]), sgpr_hi(n.w[3]), sgpr_lo(n.w[4]), sgpr_hi(n.w[4]),
+                          sgpr_lo(n.w[5]), sgpr_hi(n.w[5]), (int32_t)(uint32_t)n.w[6], (int32_t)(uint32_t)(n.w[6] >> 32),
+                          stk, cap, best.t, node, sp, qn);
+            } else
+#endif
+            {
+                F4 q0, q1, q2;
+                int32_t c0, c1;
+                load_node(nodes, node, q0, q1, q2, c0, c1);
+                node_step(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, c0, c1, stk, cap,
+                          best.t, node, sp, qn);
+            }
+            if (STATS && (uint32_t)(sp - 1) > st->maxsp) st->maxsp = (uint32_t)(sp - 1);
+        }
+        // room for one push and two queued leaves in the next step?
+        const bool tight = sp + qn + 3 > cap;
+        if (tight && qn == 0 && node >= 0) { ok = false; node = -1; }       // the stack alone is too deep
+        const bool walking = wave_any(node >= 0);
+        if (walking && !wave_any(tight && qn > 0)) continue;
+        for (int i = 0; wave_any(i < qn); ++i) {
+            if (i < qn) {
+                const int32_t leaf = stk.get(cap - 1 - i);
+                const TriPos tp = load_tri(tris, leaf);
+                float lo[3], hi[3], tn;
+                tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+                if (STATS) st->leaves++;
+                if (slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= best.t) {
+                    if (r.kz < 0) ray_shear(r);
+                    float t, b1, b2;
+                    if (tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2) && tn <= t) {
+                        const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
+                        if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = b1; best.b2 = b2; best.k = k; best.leaf = leaf; }
+                    }
+                }
+            }
+        }
+        qn = 0;
+        if (!walking) break;
+    }
+    return ok;
+}
+
 DXV_HD uint32_t leaf_parity(const Ray& r, const TriPos* tris, int32_t leaf)
 {
     const TriPos tp = load_tri(tris, leaf);
@@ -156,7 +278,7 @@ struct SceneView {
 
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
-template <class Stack>
+template <bool QUEUED, class Stack>
 DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
                                const Stack& stk, int cap, uint32_t* texel, bool& overflow)
 {
@@ -166,7 +288,9 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
     finish_ray_reference(r);
     Hit best;
-    if (!trace_reference(r, sc.nodes, sc.triPos, stk, cap, best)) { overflow = true; return 0; }
+    const bool ok = QUEUED ? trace_reference_q(r, sc.nodes, sc.triPos, stk, cap, best)
+                           : trace_reference(r, sc.nodes, sc.triPos, stk, cap, best);
+    if (!ok) { overflow = true; return 0; }
     if (best.k == 0xffffffffu) return 0;                                         // missMain
     const TriNrm tn = sc.triNrm[best.leaf];
     float nx, ny, nz;

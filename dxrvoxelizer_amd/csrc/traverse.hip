@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t compact1by2(uint32_t x)
     return x;
 }
 
-template <class B, int STACK, int MODE, bool TEXELS>
+template <class B, int STACK, int MODE, bool TEXELS, bool QUEUED>
 __global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
 {
     __shared__ int32_t stack[STACK * B::threads];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
     uint8_t occ;
     if (MODE == 0) {
         uint32_t texel = 0;
-        occ = voxel_reference(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
+        occ = voxel_reference<QUEUED>(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
         if (TEXELS) p.texels[id] = texel;
     } else {
         occ = voxel_parity(p.scene, N, ix, iy, iz, stk, STACK, overflow);
@@ -106,10 +106,11 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 g((uint32_t)grid), b(B::threads);
     if (p.mode == 0) {
-        if (p.texels) k_voxelize<B, STACK, 0, true><<<g, b, 0, s>>>(p);
-        else k_voxelize<B, STACK, 0, false><<<g, b, 0, s>>>(p);
+        if (p.texels) k_voxelize<B, STACK, 0, true, true><<<g, b, 0, s>>>(p);
+        else if (p.queued) k_voxelize<B, STACK, 0, false, true><<<g, b, 0, s>>>(p);
+        else k_voxelize<B, STACK, 0, false, false><<<g, b, 0, s>>>(p);
     } else {
-        k_voxelize<B, STACK, 1, false><<<g, b, 0, s>>>(p);
+        k_voxelize<B, STACK, 1, false, false><<<g, b, 0, s>>>(p);
     }
     return hipGetLastError();
 }

@@ -121,7 +121,8 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
             const size_t id = ((size_t)lz * N + iy) * N + ix;
             bool ovf = false;
             uint32_t texel = 0;
-            out[id] = mode == 0 ? voxel_reference(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
+            out[id] = mode == 0 ? voxel_reference<false>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
+                      : mode == 2 ? voxel_reference<true>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
                                 : voxel_parity(sc, N, ix, iy, iz, stk, stackCap, ovf);
             if (texels) texels[id] = texel;
             if (ovf) overflow |= 1;
@@ -155,6 +156,252 @@ __attribute__((visibility("default"))) void hc_trace_stats(void* p, uint32_t N, 
     }
     out[0] = rays; out[1] = nodes; out[2] = leaves; out[3] = maxsp; out[4] = noleaf; out[5] = trivial;
     for (int i = 0; i < 64; ++i) hist[i] = h[i];
+}
+
+static uint64_t g_uniform = 0, g_distinct = 0;
+#pragma omp threadprivate(g_uniform, g_distinct)
+// Lockstep (SIMT) replay of the reference-mode loop for 4x4x4-voxel waves: every iteration each
+// live lane visits one node.  out[0] waves, out[1] wave iterations, out[2] sum of live lanes over
+// iterations, out[3] iterations in which >=1 lane runs a leaf test, out[4] lanes in those leaf
+// tests, out[5] second-leaf executions, out[6] waves with zero iterations (all lanes culled by the
+// root early-out), out[7] iterations of the heaviest wave.
+__attribute__((visibility("default"))) void hc_simt_stats(void* p, uint32_t N, uint32_t bstep, uint64_t* out)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    {
+        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
+        for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
+    }
+    const uint32_t nb = N / 4;
+    uint64_t waves = 0, iters = 0, live = 0, leafIters = 0, leafLanes = 0, second = 0, empty = 0, heaviest = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : waves, iters, live, leafIters, leafLanes, second, empty) reduction(max : heaviest)
+    for (int64_t bzi = 0; bzi < (int64_t)nb; bzi += bstep) {
+        for (uint32_t byi = 0; byi < nb; ++byi) for (uint32_t bxi = 0; bxi < nb; ++bxi) {
+            struct Lane { Ray r; Hit best; int32_t node; int sp; int32_t stack[64]; };
+            static thread_local Lane L[64];
+            int nlive = 0;
+            for (int t = 0; t < 64; ++t) {
+                Lane& l = L[t];
+                const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
+                ray_origin(N, ix, iy, iz, l.r.ox, l.r.oy, l.r.oz);
+                l.node = -1;
+                if (origin_leaves_root(l.r.ox, l.r.oy, l.r.oz, sc.rootLo, sc.rootHi)) continue;
+                finish_ray_reference(l.r);
+                l.best.t = kTMax; l.best.k = 0xffffffffu; l.best.leaf = -1; l.best.b1 = l.best.b2 = 0;
+                l.stack[0] = -1; l.sp = 1; l.node = 0;
+                nlive++;
+            }
+            waves++;
+            if (!nlive) { empty++; continue; }
+            uint64_t myIters = 0;
+            for (;;) {
+                int liveNow = 0, leafNow = 0, secondNow = 0;
+                {
+                    int32_t first = -2; bool uni = true; int distinct = 0; int32_t seen[64];
+                    for (int t = 0; t < 64; ++t) {
+                        if (L[t].node < 0) continue;
+                        if (first == -2) first = L[t].node; else if (L[t].node != first) uni = false;
+                        bool f = false; for (int q = 0; q < distinct; ++q) if (seen[q] == L[t].node) { f = true; break; }
+                        if (!f) seen[distinct++] = L[t].node;
+                    }
+                    if (first != -2) { g_uniform += uni ? 1 : 0; g_distinct += distinct; }
+                }
+                for (int t = 0; t < 64; ++t) {
+                    Lane& l = L[t];
+                    if (l.node < 0) continue;
+                    liveNow++;
+                    F4 q0, q1, q2; int32_t c0, c1;
+                    load_node(sc.nodes, l.node, q0, q1, q2, c0, c1);
+                    float tn0, tn1;
+                    bool h0 = slab(l.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= l.best.t;
+                    bool h1 = slab(l.r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= l.best.t;
+                    const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
+                    if (l0 || l1) {
+                        leafNow++;
+                        leaf_reference(l.r, sc.triPos, l0 ? ~c0 : ~c1, l0 ? tn0 : tn1, l.best);
+                        if (l0 && l1) { secondNow++; leaf_reference(l.r, sc.triPos, ~c1, tn1, l.best); }
+                    }
+                    h0 = h0 && c0 >= 0 && tn0 <= l.best.t;
+                    h1 = h1 && c1 >= 0 && tn1 <= l.best.t;
+                    const bool both = h0 && h1, swap = tn1 < tn0;
+                    if (both) l.stack[l.sp++] = swap ? c0 : c1;
+                    if (h0 || h1) l.node = (h0 && !(both && swap)) ? c0 : c1;
+                    else l.node = l.stack[--l.sp];
+                }
+                if (!liveNow) break;
+                myIters++; live += liveNow;
+                if (leafNow) { leafIters++; leafLanes += leafNow; }
+                if (secondNow) second++;
+            }
+            iters += myIters;
+            if (myIters > heaviest) heaviest = myIters;
+        }
+    }
+    out[0] = waves; out[1] = iters; out[2] = live; out[3] = leafIters; out[4] = leafLanes; out[5] = second; out[6] = empty; out[7] = heaviest;
+    uint64_t uni = 0, dis = 0;
+#pragma omp parallel reduction(+ : uni, dis)
+    { uni += g_uniform; dis += g_distinct; g_uniform = 0; g_distinct = 0; }
+    out[8] = uni; out[9] = dis;
+}
+
+// Lockstep replay of the while-while variant: phase 1 = every lane walks internal nodes until it
+// has a pending leaf (or is finished), phase 2 = all lanes with a pending leaf test it together.
+// out[0] waves, out[1] phase-1 iterations, out[2] live lanes in them, out[3] phase-2 executions,
+// out[4] lanes in them, out[5] heaviest wave cost (70*p1 + 150*p2), out[6] total cost
+__attribute__((visibility("default"))) void hc_simt_stats_ww(void* p, uint32_t N, uint32_t bstep, int carry, uint64_t* out)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    {
+        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
+        for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
+    }
+    const uint32_t nb = N / 4;
+    uint64_t waves = 0, p1 = 0, p1live = 0, p2 = 0, p2lanes = 0, heaviest = 0, total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : waves, p1, p1live, p2, p2lanes, total) reduction(max : heaviest)
+    for (int64_t bzi = 0; bzi < (int64_t)nb; bzi += bstep) {
+        for (uint32_t byi = 0; byi < nb; ++byi) for (uint32_t bxi = 0; bxi < nb; ++bxi) {
+            struct Lane { Ray r; Hit best; int32_t node; int sp; int32_t stack[64]; int32_t pa, pb; float ta, tb; };
+            static thread_local Lane L[64];
+            for (int t = 0; t < 64; ++t) {
+                Lane& l = L[t];
+                const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
+                ray_origin(N, ix, iy, iz, l.r.ox, l.r.oy, l.r.oz);
+                l.node = -1; l.pa = l.pb = -1;
+                if (origin_leaves_root(l.r.ox, l.r.oy, l.r.oz, sc.rootLo, sc.rootHi)) continue;
+                finish_ray_reference(l.r);
+                l.best.t = kTMax; l.best.k = 0xffffffffu; l.best.leaf = -1; l.best.b1 = l.best.b2 = 0;
+                l.stack[0] = -1; l.sp = 1; l.node = 0;
+            }
+            waves++;
+            uint64_t my1 = 0, my2 = 0;
+            for (;;) {
+                // phase 1
+                for (;;) {
+                    int liveNow = 0;
+                    for (int t = 0; t < 64; ++t) {
+                        Lane& l = L[t];
+                        if (l.node < 0 || l.pa >= 0) continue;
+                        liveNow++;
+                        F4 q0, q1, q2; int32_t c0, c1;
+                        load_node(sc.nodes, l.node, q0, q1, q2, c0, c1);
+                        float tn0, tn1;
+                        bool h0 = slab(l.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= l.best.t;
+                        bool h1 = slab(l.r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= l.best.t;
+                        const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
+                        if (l0) { l.pa = ~c0; l.ta = tn0; if (l1) { l.pb = ~c1; l.tb = tn1; } }
+                        else if (l1) { l.pa = ~c1; l.ta = tn1; }
+                        h0 = h0 && c0 >= 0; h1 = h1 && c1 >= 0;
+                        const bool both = h0 && h1, swap = tn1 < tn0;
+                        if (both) l.stack[l.sp++] = swap ? c0 : c1;
+                        if (h0 || h1) l.node = (h0 && !(both && swap)) ? c0 : c1;
+                        else l.node = l.stack[--l.sp];
+                    }
+                    if (!liveNow) break;
+                    my1++; p1live += liveNow;
+                }
+                // phase 2
+                int pend = 0;
+                for (int t = 0; t < 64; ++t) if (L[t].pa >= 0) pend++;
+                if (!pend) break;
+                my2++; p2lanes += pend;
+                int sec = 0;
+                for (int t = 0; t < 64; ++t) {
+                    Lane& l = L[t];
+                    if (l.pa < 0) continue;
+                    leaf_reference(l.r, sc.triPos, l.pa, l.ta, l.best);
+                    if (carry) { l.pa = l.pb; l.ta = l.tb; l.pb = -1; }
+                    else { l.pa = -1; if (l.pb >= 0) { sec++; leaf_reference(l.r, sc.triPos, l.pb, l.tb, l.best); l.pb = -1; } }
+                }
+                if (sec) { my2++; p2lanes += sec; }
+            }
+            p1 += my1; p2 += my2;
+            const uint64_t cost = 70 * my1 + 150 * my2;
+            total += cost;
+            if (cost > heaviest) heaviest = cost;
+        }
+    }
+    out[0] = waves; out[1] = p1; out[2] = p1live; out[3] = p2; out[4] = p2lanes; out[5] = heaviest; out[6] = total;
+}
+
+// Lockstep replay of the postponed-leaf variant: every live lane keeps walking nodes; hit leaves go to
+// a per-lane queue (capacity Q).  The wave flushes (rounds of one leaf test per lane) when a lane's
+// queue cannot take two more entries, when >= thr lanes hold leaves, or when no lane can walk.
+__attribute__((visibility("default"))) void hc_simt_stats_q(void* p, uint32_t N, uint32_t bstep, int Q, int thr, uint64_t* out)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    {
+        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
+        for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
+    }
+    const uint32_t nb = N / 4;
+    uint64_t waves = 0, p1 = 0, p1live = 0, p2 = 0, p2lanes = 0, heaviest = 0, total = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : waves, p1, p1live, p2, p2lanes, total) reduction(max : heaviest)
+    for (int64_t bzi = 0; bzi < (int64_t)nb; bzi += bstep) {
+        for (uint32_t byi = 0; byi < nb; ++byi) for (uint32_t bxi = 0; bxi < nb; ++bxi) {
+            struct Lane { Ray r; Hit best; int32_t node; int sp; int32_t stack[64]; int32_t ql[8]; float qt[8]; int qn; };
+            static thread_local Lane L[64];
+            for (int t = 0; t < 64; ++t) {
+                Lane& l = L[t];
+                const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
+                ray_origin(N, ix, iy, iz, l.r.ox, l.r.oy, l.r.oz);
+                l.node = -1; l.qn = 0;
+                if (origin_leaves_root(l.r.ox, l.r.oy, l.r.oz, sc.rootLo, sc.rootHi)) continue;
+                finish_ray_reference(l.r);
+                l.best.t = kTMax; l.best.k = 0xffffffffu; l.best.leaf = -1; l.best.b1 = l.best.b2 = 0;
+                l.stack[0] = -1; l.sp = 1; l.node = 0;
+            }
+            waves++;
+            uint64_t my1 = 0, my2 = 0;
+            for (;;) {
+                int liveNow = 0, holders = 0, full = 0;
+                for (int t = 0; t < 64; ++t) {
+                    Lane& l = L[t];
+                    if (l.node >= 0) {
+                        liveNow++;
+                        F4 q0, q1, q2; int32_t c0, c1;
+                        load_node(sc.nodes, l.node, q0, q1, q2, c0, c1);
+                        float tn0, tn1;
+                        bool h0 = slab(l.r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= l.best.t;
+                        bool h1 = slab(l.r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= l.best.t;
+                        if (h0 && c0 < 0) { l.ql[l.qn] = ~c0; l.qt[l.qn++] = tn0; }
+                        if (h1 && c1 < 0) { l.ql[l.qn] = ~c1; l.qt[l.qn++] = tn1; }
+                        h0 = h0 && c0 >= 0; h1 = h1 && c1 >= 0;
+                        const bool both = h0 && h1, swap = tn1 < tn0;
+                        if (both) l.stack[l.sp++] = swap ? c0 : c1;
+                        if (h0 || h1) l.node = (h0 && !(both && swap)) ? c0 : c1;
+                        else l.node = l.stack[--l.sp];
+                    }
+                    if (l.qn) holders++;
+                    if (l.qn > Q - 2) full++;
+                }
+                if (liveNow) { my1++; p1live += liveNow; }
+                int stillLive = 0;
+                for (int t = 0; t < 64; ++t) if (L[t].node >= 0) stillLive++;
+                if (holders && (full || holders >= thr || !stillLive)) {
+                    for (;;) {
+                        int n = 0;
+                        for (int t = 0; t < 64; ++t) {
+                            Lane& l = L[t];
+                            if (!l.qn) continue;
+                            n++;
+                            l.qn--;
+                            if (l.qt[l.qn] <= l.best.t) leaf_reference(l.r, sc.triPos, l.ql[l.qn], l.qt[l.qn], l.best);
+                        }
+                        if (!n) break;
+                        my2++; p2lanes += n;
+                    }
+                } else if (!stillLive) break;
+            }
+            p1 += my1; p2 += my2;
+            const uint64_t cost = 70 * my1 + 150 * my2;
+            total += cost;
+            if (cost > heaviest) heaviest = cost;
+        }
+    }
+    out[0] = waves; out[1] = p1; out[2] = p1live; out[3] = p2; out[4] = p2lanes; out[5] = heaviest; out[6] = total;
 }
 
 } // extern "C"

@@ -150,15 +150,17 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
     vox.InitFromArrays(vb, ib)
     want = orc.Scene(vb, ib).voxelize(64)
     for brick in range(8):
-        for stack, morton, region in ((0, 1, 9), (32, 0, 0), (64, 1, 3), (0, 0, 20), (48, 1, 24)):
+        for stack, morton, region, queue in ((0, 1, 9, 1), (32, 0, 0, 0), (64, 1, 3, 1), (0, 0, 20, 0), (48, 1, 24, 1)):
             vox.set_option("brick", brick)
             vox.set_option("stack", stack)
             vox.set_option("morton", morton)
             vox.set_option("region", region)
+            vox.set_option("queue", queue)
             vox.Voxelize(64)
-            assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region)
+            assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region, queue)
     vox.set_option("morton", 1)
-    vox.set_option("region", 9)
+    vox.set_option("region", 6)
+    vox.set_option("queue", 1)
     for n in (2, 6, 30, 66):                 # grids that do not fill whole bricks
         vox.set_option("brick", 1)
         vox.set_option("stack", 0)
@@ -230,7 +232,7 @@ def test_errors_are_loud(dxv, bunny):
     assert "stack" in str(e.value)
     v.set_option("stack", 0)                              # adaptive: grows once, then succeeds
     v.Voxelize(16)
-    assert v.stats()["stack_entries"] >= 17
+    assert v.stats()["stack_entries"] >= 20
     one = dxv.Voxelizer(0)
     one.InitFromArrays(tri, np.arange(3, dtype=np.uint32))
     one.Voxelize(16)
