@@ -93,6 +93,7 @@ int fail(dxv_ctx* c, const char* fmt, ...)
     } while (0)
 
 Node* scene_nodes(dxv_ctx* c) { return reinterpret_cast<Node*>(c->dScene + c->hdr.offNodes); }
+Node32* scene_nodes32(dxv_ctx* c) { return reinterpret_cast<Node32*>(c->dScene + c->hdr.offNodes32); }
 TriPos* scene_tripos(dxv_ctx* c) { return reinterpret_cast<TriPos*>(c->dScene + c->hdr.offTriPos); }
 TriNrm* scene_trinrm(dxv_ctx* c) { return reinterpret_cast<TriNrm*>(c->dScene + c->hdr.offTriNrm); }
 
@@ -105,7 +106,8 @@ void layout_scene(SceneHeader& h, uint32_t T, uint32_t V)
     h.numVerts = V;
     h.numNodes = T > 1 ? T - 1 : 1;
     h.offNodes = align256(sizeof(SceneHeader));
-    h.offTriPos = align256(h.offNodes + sizeof(Node) * (size_t)h.numNodes);
+    h.offNodes32 = align256(h.offNodes + sizeof(Node) * (size_t)h.numNodes);
+    h.offTriPos = align256(h.offNodes32 + sizeof(Node32) * (size_t)h.numNodes);
     h.offTriNrm = align256(h.offTriPos + sizeof(TriPos) * (size_t)T);
     h.totalBytes = align256(h.offTriNrm + sizeof(TriNrm) * (size_t)T);
 }
@@ -160,7 +162,7 @@ int safe_stack(const dxv_ctx* c) { return stack_round_up((int)c->hdr.treeHeight 
 int launch_now(dxv_ctx* c)
 {
     VoxelizeParams p{};
-    p.scene.nodes = scene_nodes(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
+    p.scene.nodes = scene_nodes32(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
     memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
     p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
@@ -297,7 +299,7 @@ int dxv_build(dxv_ctx* c)
     memcpy(b.bound, c->bound, sizeof(c->bound));
     b.keys = c->dKeys; b.keysTmp = c->dKeysTmp; b.hist = c->dHist; b.parents = c->dParents;
     b.flags = c->dFlags; b.flags2 = c->dFlags2; b.rootInfo = c->dRootInfo;
-    b.nodes = scene_nodes(c); b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
+    b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
     DXV_HIP(c, lbvh_build(b, c->optRefit, c->stream, c->ev));
     uint32_t rootInfo[8];
     DXV_HIP(c, hipMemcpyAsync(rootInfo, c->dRootInfo, sizeof(rootInfo), hipMemcpyDeviceToHost, c->stream));
@@ -452,7 +454,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     SceneHeader want;
     layout_scene(want, h.numTris, h.numVerts);
     if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
-        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.treeHeight == 0 || h.treeHeight > 64)
+        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.treeHeight == 0 || h.treeHeight > 64)
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     c->haveScene = false;
     if (alloc_scene(c, h.numTris, h.numVerts)) return 1;
@@ -516,6 +518,7 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     case DXV_DBG_SORTED_KEYS: src = c->dKeys; want = sizeof(uint64_t) * T; if (c->scratchT != c->T) src = nullptr; break;
     case DXV_DBG_PARENTS: src = c->dParents; want = sizeof(uint32_t) * (2 * T - 1); if (c->scratchT != c->T) src = nullptr; break;
     case DXV_DBG_NODES: if (c->haveScene) { src = scene_nodes(c); want = sizeof(Node) * (size_t)c->hdr.numNodes; } break;
+    case DXV_DBG_NODES32: if (c->haveScene) { src = scene_nodes32(c); want = sizeof(Node32) * (size_t)c->hdr.numNodes; } break;
     case DXV_DBG_TRI_POS: if (c->haveScene) { src = scene_tripos(c); want = sizeof(TriPos) * T; } break;
     case DXV_DBG_TRI_NRM: if (c->haveScene) { src = scene_trinrm(c); want = sizeof(TriNrm) * T; } break;
     default: return fail(c, "dxv_debug_download: unknown selector %d", what);

@@ -24,7 +24,8 @@ struct BuildBuffers {
     uint32_t* flags;        // T-1 arrival counters (atomic refit) / ready flags (sweep refit)
     uint32_t* flags2;       // T-1 (sweep refit ping-pong)
     uint32_t* rootInfo;     // 8 words: rootLo[3], rootHi[3] (float bits), height, done
-    Node* nodes;            // max(T-1,1)
+    Node* nodes;            // max(T-1,1), exact boxes
+    Node32* nodes32;        // max(T-1,1), traversal copy
     TriPos* triPos;         // T
     TriNrm* triNrm;         // T
 };

@@ -230,6 +230,76 @@ DXV_HD void tri_box(const F4& a, const F4& b, const F4& c, float lo[3], float hi
 }
 
 // ------------------------------------------------------------------------------------------
+// Directed float -> half conversion for the compressed traversal nodes (integer arithmetic only,
+// identical on host and device).  half_down(x) <= x <= half_up(x) for every finite x;
+// beyond the half range the bound saturates to +-65504 on the inner side and +-inf on the outer.
+// ------------------------------------------------------------------------------------------
+DXV_HD float half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else {                      // subnormal half: m * 2^-24
+            const float v = (float)m * 5.9604644775390625e-08f;
+            bits = sign | __builtin_bit_cast(uint32_t, v);
+        }
+    } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    return __builtin_bit_cast(float, bits);
+}
+
+// magnitude truncated toward zero; *inexact tells whether bits were dropped
+DXV_HD uint16_t half_trunc_mag(float a /* >= 0, finite */, bool& inexact)
+{
+    const uint32_t bits = __builtin_bit_cast(uint32_t, a) & 0x7fffffffu;
+    const int32_t e = (int32_t)(bits >> 23) - 127;
+    const uint32_t m = (bits & 0x7fffffu) | 0x800000u;
+    if (bits == 0) { inexact = false; return 0; }
+    if (e > 15) { inexact = true; return 0x7bffu; }                 // above 65504: largest finite half
+    if (e >= -14) {                                                  // normal half
+        inexact = (m & 0x1fffu) != 0;
+        return (uint16_t)(((uint32_t)(e + 15) << 10) | ((m >> 13) & 1023u));
+    }
+    const int32_t shift = 13 + (-14 - e);                            // subnormal half
+    if (shift > 24) { inexact = true; return 0; }
+    inexact = (m & ((1u << shift) - 1u)) != 0;
+    return (uint16_t)(m >> shift);
+}
+
+DXV_HD uint16_t half_down(float x)
+{
+    bool inexact;
+    if (!(x == x)) return 0xfc00u;                                   // NaN: -inf is a valid lower bound
+    if (x >= 0.0f) { if (x > 3.0e38f) return 0x7bffu; return half_trunc_mag(x, inexact); }
+    if (x < -3.0e38f) return 0xfc00u;
+    const uint16_t h = half_trunc_mag(-x, inexact);
+    return (uint16_t)(0x8000u | (inexact ? h + 1u : h));             // magnitude up (0x7bff + 1 = inf)
+}
+
+DXV_HD uint16_t half_up(float x)
+{
+    bool inexact;
+    if (!(x == x)) return 0x7c00u;
+    if (x <= 0.0f) { if (x < -3.0e38f) return 0xfbffu; const uint16_t h = half_trunc_mag(-x, inexact); return (uint16_t)(h ? (0x8000u | h) : 0u); }
+    if (x > 3.0e38f) return 0x7c00u;
+    const uint16_t h = half_trunc_mag(x, inexact);
+    return (uint16_t)(inexact ? h + 1u : h);
+}
+
+DXV_HD Node32 compress_node(const Node& n)
+{
+    Node32 c;
+    c.b[0] = half_down(n.lo0x); c.b[1] = half_down(n.lo0y); c.b[2] = half_down(n.lo0z);
+    c.b[3] = half_up(n.hi0x);   c.b[4] = half_up(n.hi0y);   c.b[5] = half_up(n.hi0z);
+    c.b[6] = half_down(n.lo1x); c.b[7] = half_down(n.lo1y); c.b[8] = half_down(n.lo1z);
+    c.b[9] = half_up(n.hi1x);   c.b[10] = half_up(n.hi1y);  c.b[11] = half_up(n.hi1z);
+    c.c0 = n.c0; c.c1 = n.c1;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
 // Morton keys (30 bits over the centre of the padded box) and the Karras 2012 hierarchy rule.
 // Keys are (morton << 32) | triangle index: unique, so the tree is deterministic.
 // ------------------------------------------------------------------------------------------

@@ -33,15 +33,33 @@ struct StridedStack {
     DXV_HD int32_t get(int e) const { return base[e * stride]; }
 };
 
-// 32-bit byte offsets from a wave-uniform base: the device build addresses nodes and triangles
-// as base(SGPR pair) + offset(VGPR) (up to 4 GiB of nodes = 67 M nodes per scene).
-DXV_HD void load_node(const Node* nodes, int32_t i, F4& q0, F4& q1, F4& q2, int32_t& c0, int32_t& c1)
+DXV_HD float half_bits_to_float(uint32_t h16)
 {
-    const F4* p = reinterpret_cast<const F4*>(reinterpret_cast<const char*>(nodes) + ((uint32_t)i << 6));
-    q0 = p[0]; q1 = p[1]; q2 = p[2];
-    const F4 q3 = p[3];
-    c0 = __builtin_bit_cast(int32_t, q3.x);
-    c1 = __builtin_bit_cast(int32_t, q3.y);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)h16);      // v_cvt_f32_f16, exact
+#else
+    return half_to_float((uint16_t)h16);
+#endif
+}
+
+// Compressed node (32 B = two 16-B loads) -> twelve float planes + two links.  32-bit byte offsets
+// from a wave-uniform base: the device build addresses nodes and triangles as
+// base(SGPR pair) + offset(VGPR).
+struct NodePlanes { float b[12]; int32_t c0, c1; };
+DXV_HD NodePlanes load_node(const Node32* nodes, int32_t i)
+{
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(nodes) + ((uint32_t)i << 5));
+    struct alignas(16) U4 { uint32_t x, y, z, w; };
+    const U4 a = *reinterpret_cast<const U4*>(p), d = *reinterpret_cast<const U4*>(p + 4);
+    NodePlanes n;
+    n.b[0] = half_bits_to_float(a.x & 0xffffu); n.b[1] = half_bits_to_float(a.x >> 16);
+    n.b[2] = half_bits_to_float(a.y & 0xffffu); n.b[3] = half_bits_to_float(a.y >> 16);
+    n.b[4] = half_bits_to_float(a.z & 0xffffu); n.b[5] = half_bits_to_float(a.z >> 16);
+    n.b[6] = half_bits_to_float(a.w & 0xffffu); n.b[7] = half_bits_to_float(a.w >> 16);
+    n.b[8] = half_bits_to_float(d.x & 0xffffu); n.b[9] = half_bits_to_float(d.x >> 16);
+    n.b[10] = half_bits_to_float(d.y & 0xffffu); n.b[11] = half_bits_to_float(d.y >> 16);
+    n.c0 = (int32_t)d.z; n.c1 = (int32_t)d.w;
+    return n;
 }
 
 DXV_HD TriPos load_tri(const TriPos* tris, int32_t leaf)
@@ -49,9 +67,14 @@ DXV_HD TriPos load_tri(const TriPos* tris, int32_t leaf)
     return *reinterpret_cast<const TriPos*>(reinterpret_cast<const char*>(tris) + (uint32_t)leaf * 48u);
 }
 
-DXV_HD void leaf_reference(Ray& r, const TriPos* tris, int32_t leaf, float tn, Hit& best)
+// The triangle's own (exact, canonical) padded box decides candidacy: node boxes are outward
+// rounded supersets and only steer the walk.
+DXV_HD void leaf_reference(Ray& r, const TriPos* tris, int32_t leaf, Hit& best)
 {
     const TriPos tp = load_tri(tris, leaf);
+    float lo[3], hi[3], tn;
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+    if (!(slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= best.t)) return;
     if (r.kz < 0) ray_shear(r);
     float t, b1, b2;
     if (!tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2)) return;
@@ -67,7 +90,7 @@ struct TraceStats { uint32_t nodes, leaves, maxsp; };
 // Entry 0 of the stack holds a negative sentinel, so "pop" needs no emptiness test and the loop has
 // a single exit (node < 0); capacity for real entries is cap - 1.
 template <class Stack, bool STATS = false>
-DXV_HD bool trace_reference(Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
+DXV_HD bool trace_reference(Ray& r, const Node32* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
                             TraceStats* st = nullptr)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
@@ -76,19 +99,18 @@ DXV_HD bool trace_reference(Ray& r, const Node* nodes, const TriPos* tris, const
     bool ok = true;
     int32_t node = 0;
     while (node >= 0) {
-        F4 q0, q1, q2;
-        int32_t c0, c1;
-        load_node(nodes, node, q0, q1, q2, c0, c1);
+        const NodePlanes n = load_node(nodes, node);
+        const int32_t c0 = n.c0, c1 = n.c1;
         if (STATS) st->nodes++;
         float tn0, tn1;
-        bool h0 = slab(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= best.t;
-        bool h1 = slab(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= best.t;
+        bool h0 = slab(r, n.b[0], n.b[1], n.b[2], n.b[3], n.b[4], n.b[5], tn0) && tn0 <= best.t;
+        bool h1 = slab(r, n.b[6], n.b[7], n.b[8], n.b[9], n.b[10], n.b[11], tn1) && tn1 <= best.t;
         const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
         if (STATS) st->leaves += l0 + l1;
         if (l0 || l1) {
             // lanes with a leaf in either child test it together; a second leaf is the rare case
-            leaf_reference(r, tris, l0 ? ~c0 : ~c1, l0 ? tn0 : tn1, best);
-            if (l0 && l1) leaf_reference(r, tris, ~c1, tn1, best);
+            leaf_reference(r, tris, l0 ? ~c0 : ~c1, best);
+            if (l0 && l1) leaf_reference(r, tris, ~c1, best);
         }
         h0 = h0 && c0 >= 0 && tn0 <= best.t;
         h1 = h1 && c1 >= 0 && tn1 <= best.t;
@@ -146,28 +168,27 @@ DXV_HD void node_step(const Ray& r, float lo0x, float lo0y, float lo0z, float hi
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// 64-B node through the scalar cache into 16 SGPRs (nodes are read-only during the kernel).
-// Eight 64-bit outputs: plain scalar-pair operands, which hipcc tracks reliably (512- and 128-bit
+// 32-B node through the scalar cache into 8 SGPRs (nodes are read-only during the kernel).
+// Four 64-bit outputs: plain scalar-pair operands, which hipcc tracks reliably (512- and 128-bit
 // SGPR tuples as asm outputs were mis-tracked by ROCm 7.2's hipcc: elements folded together).
-struct NodeSgpr { uint64_t w[8]; };
-__device__ __forceinline__ NodeSgpr load_node_scalar(const Node* nodes, int32_t uniformIndex)
+struct NodeSgpr { uint64_t w[4]; };
+__device__ __forceinline__ NodeSgpr load_node_scalar(const Node32* nodes, int32_t uniformIndex)
 {
-    const char* p = reinterpret_cast<const char*>(nodes) + ((uint64_t)(uint32_t)uniformIndex << 6);
+    const char* p = reinterpret_cast<const char*>(nodes) + ((uint64_t)(uint32_t)uniformIndex << 5);
     NodeSgpr n;
-    asm volatile("s_load_dwordx2 %0, %8, 0x0\n\ts_load_dwordx2 %1, %8, 0x8\n\ts_load_dwordx2 %2, %8, 0x10\n\t"
-                 "s_load_dwordx2 %3, %8, 0x18\n\ts_load_dwordx2 %4, %8, 0x20\n\ts_load_dwordx2 %5, %8, 0x28\n\t"
-                 "s_load_dwordx2 %6, %8, 0x30\n\ts_load_dwordx2 %7, %8, 0x38\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&s"(n.w[0]), "=&s"(n.w[1]), "=&s"(n.w[2]), "=&s"(n.w[3]), "=&s"(n.w[4]), "=&s"(n.w[5]),
-                   "=&s"(n.w[6]), "=&s"(n.w[7])
-                 : "s"(p) : "memory");
+    asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %4, 0x8\n\ts_load_dwordx2 %2, %4, 0x10\n\t"
+                 "s_load_dwordx2 %3, %4, 0x18\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(n.w[0]), "=&s"(n.w[1]), "=&s"(n.w[2]), "=&s"(n.w[3]) : "s"(p) : "memory");
     return n;
 }
-__device__ __forceinline__ float sgpr_lo(uint64_t v) { return __builtin_bit_cast(float, (uint32_t)v); }
-__device__ __forceinline__ float sgpr_hi(uint64_t v) { return __builtin_bit_cast(float, (uint32_t)(v >> 32)); }
+__device__ __forceinline__ float sgpr_half(uint64_t v, int which)   // which = 0..3: 16-bit field of the pair
+{
+    return half_bits_to_float((uint32_t)(v >> (16 * which)) & 0xffffu);
+}
 #endif
 
 template <class Stack, bool STATS = false>
-DXV_HD bool trace_reference_q(Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
+DXV_HD bool trace_reference_q(Ray& r, const Node32* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
                               TraceStats* st = nullptr)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
@@ -184,18 +205,16 @@ DXV_HD bool trace_reference_q(Ray& r, const Node* nodes, const TriPos* tris, con
             const int32_t n0 = __builtin_amdgcn_readfirstlane(node);
             if (__builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
                 const NodeSgpr n = load_node_scalar(nodes, n0);
-                node_step(r, sgpr_lo(n.w[0]), sgpr_hi(n.w[0]), sgpr_lo(n.w[1]), sgpr_hi(n.w[1]), sgpr_lo(n.w[2]),
-                          sgpr_hi(n.w[2]), sgpr_lo(n.w[3]), sgpr_hi(n.w[3]), sgpr_lo(n.w[4]), sgpr_hi(n.w[4]),
-                          sgpr_lo(n.w[5]), sgpr_hi(n.w[5]), (int32_t)(uint32_t)n.w[6], (int32_t)(uint32_t)(n.w[6] >> 32),
-                          stk, cap, best.t, node, sp, qn);
+                node_step(r, sgpr_half(n.w[0], 0), sgpr_half(n.w[0], 1), sgpr_half(n.w[0], 2), sgpr_half(n.w[0], 3),
+                          sgpr_half(n.w[1], 0), sgpr_half(n.w[1], 1), sgpr_half(n.w[1], 2), sgpr_half(n.w[1], 3),
+                          sgpr_half(n.w[2], 0), sgpr_half(n.w[2], 1), sgpr_half(n.w[2], 2), sgpr_half(n.w[2], 3),
+                          (int32_t)(uint32_t)n.w[3], (int32_t)(uint32_t)(n.w[3] >> 32), stk, cap, best.t, node, sp, qn);
             } else
 #endif
             {
-                F4 q0, q1, q2;
-                int32_t c0, c1;
-                load_node(nodes, node, q0, q1, q2, c0, c1);
-                node_step(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, c0, c1, stk, cap,
-                          best.t, node, sp, qn);
+                const NodePlanes n = load_node(nodes, node);
+                node_step(r, n.b[0], n.b[1], n.b[2], n.b[3], n.b[4], n.b[5], n.b[6], n.b[7], n.b[8], n.b[9], n.b[10],
+                          n.b[11], n.c0, n.c1, stk, cap, best.t, node, sp, qn);
             }
             if (STATS && (uint32_t)(sp - 1) > st->maxsp) st->maxsp = (uint32_t)(sp - 1);
         }
@@ -230,12 +249,15 @@ DXV_HD bool trace_reference_q(Ray& r, const Node* nodes, const TriPos* tris, con
 DXV_HD uint32_t leaf_parity(const Ray& r, const TriPos* tris, int32_t leaf)
 {
     const TriPos tp = load_tri(tris, leaf);
+    float lo[3], hi[3];
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);                            // exact canonical box of the triangle
+    if (!slab_parity(r, lo[1], lo[2], hi[0], hi[1], hi[2])) return 0u;
     float t, b1, b2;
     return tri_test<true>(r, tp.v0, tp.v1, tp.v2, t, b1, b2) ? 1u : 0u;
 }
 
 template <class Stack>
-DXV_HD bool trace_parity(const Ray& r, const Node* nodes, const TriPos* tris, const Stack& stk, int cap, uint32_t& count)
+DXV_HD bool trace_parity(const Ray& r, const Node32* nodes, const TriPos* tris, const Stack& stk, int cap, uint32_t& count)
 {
     count = 0;
     stk.put(0, -1);
@@ -243,11 +265,10 @@ DXV_HD bool trace_parity(const Ray& r, const Node* nodes, const TriPos* tris, co
     bool ok = true;
     int32_t node = 0;
     while (node >= 0) {
-        F4 q0, q1, q2;
-        int32_t c0, c1;
-        load_node(nodes, node, q0, q1, q2, c0, c1);
-        bool h0 = slab_parity(r, q0.y, q0.z, q0.w, q1.x, q1.y);
-        bool h1 = slab_parity(r, q1.w, q2.x, q2.y, q2.z, q2.w);
+        const NodePlanes n = load_node(nodes, node);
+        const int32_t c0 = n.c0, c1 = n.c1;
+        bool h0 = slab_parity(r, n.b[1], n.b[2], n.b[3], n.b[4], n.b[5]);
+        bool h1 = slab_parity(r, n.b[7], n.b[8], n.b[9], n.b[10], n.b[11]);
         const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
         if (l0 || l1) {
             count += leaf_parity(r, tris, l0 ? ~c0 : ~c1);
@@ -270,7 +291,7 @@ DXV_HD bool trace_parity(const Ray& r, const Node* nodes, const TriPos* tris, co
 // (Content/Shaders/DXRVoxelizer.hlsl:58-85, :132-148).  Shared by the kernels and tests/hostcheck.
 // ------------------------------------------------------------------------------------------
 struct SceneView {
-    const Node* nodes;
+    const Node32* nodes;
     const TriPos* triPos;
     const TriNrm* triNrm;
     float rootLo[3], rootHi[3];

@@ -26,6 +26,17 @@ struct alignas(64) Node {
 };
 static_assert(sizeof(Node) == 64, "node is 64 B");
 
+// Traversal copy of a node, 32 B = two 16-B loads: the twelve box planes as IEEE half floats
+// rounded OUTWARD (lo down, hi up), so every stored box contains the exact one.  Supersets keep
+// the slab test conservative (monotone under inclusion); the exact per-triangle box is
+// re-derived from the triangle's vertices when a leaf is tested, so results are unchanged while
+// a node visit moves half the bytes through the vector memory path (the measured limiter).
+struct alignas(32) Node32 {
+    uint16_t b[12];                 // child 0: lo.xyz hi.xyz, child 1: lo.xyz hi.xyz
+    int32_t c0, c1;
+};
+static_assert(sizeof(Node32) == 32, "compressed node is 32 B");
+
 // Leaf payload in Morton order.  Positions are pre-mapped to the reference's normalised space
 // p' = (p - c) / w (Content/Voxelizer.cpp:304-306).  v0.w carries the triangle's index in the
 // caller's index buffer (PrimitiveIndex(), hlsl:93) as raw bits.
@@ -33,7 +44,7 @@ struct alignas(16) TriPos { F4 v0, v1, v2; };
 // Vertex normals of the same triangle (hlsl:102-107, :114-116), fetched once per ray at the end.
 struct alignas(16) TriNrm { F4 n0, n1, n2; };
 
-// Relocatable scene blob: [SceneHeader | nodes | triPos | triNrm], every section 256-B aligned.
+// Relocatable scene blob: [SceneHeader | nodes | nodes32 | triPos | triNrm], sections 256-B aligned.
 struct SceneHeader {
     uint32_t magic;       // 'DXVS'
     uint32_t version;
@@ -44,12 +55,13 @@ struct SceneHeader {
     float bound[4];
     float rootLo[3], rootHi[3];
     uint64_t offNodes, offTriPos, offTriNrm, totalBytes;
-    uint32_t pad[32];
+    uint64_t offNodes32;
+    uint32_t pad[30];
 };
 static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
 
 constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
-constexpr uint32_t kSceneVersion = 1;
+constexpr uint32_t kSceneVersion = 2;
 
 // canonical constants (hlsl:5, :76-77)
 constexpr float kThreshold = 0.12f;

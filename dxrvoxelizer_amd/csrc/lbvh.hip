@@ -7,6 +7,7 @@
 //   K2b k_tri_gather   per Morton slot: write the 48-B position and normal records
 //   K3  k_hierarchy    Karras 2012, one thread per internal node, parent links
 //   K4  k_refit_*      bottom-up box merge; a node stores the boxes of BOTH children
+//   K5  k_compress_nodes  32-B traversal copy of every node (outward-rounded half-float boxes)
 //
 // All kernels are HBM-streaming integer/float work: one thread per element, 16-B accesses where
 // the layout allows, no LDS needed outside the sort.
@@ -175,6 +176,13 @@ __global__ void k_single_tri(const TriPos* __restrict__ triPos, Node* __restrict
     nodes[0].c1 = ~0;
 }
 
+// K5: traversal copy of the nodes, boxes rounded outward to half floats (dxv_types.h Node32)
+__global__ __launch_bounds__(kThreads) void k_compress_nodes(const Node* __restrict__ nodes, uint32_t n, Node32* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) out[i] = compress_node(nodes[i]);
+}
+
 // rootInfo: lo[3], hi[3] (float bits), height of the root, 1
 __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict__ rootInfo)
 {
@@ -234,6 +242,7 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
             if (!rootReady) return hipErrorUnknown;
         }
     }
+    k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo);
     (void)hipEventRecord(ev[4], s);
     return hipGetLastError();

@@ -39,7 +39,8 @@ enum {
     DXV_DBG_NODES = 1,       /* max(T-1,1) x 64 B internal nodes                              */
     DXV_DBG_TRI_POS = 2,     /* T x 48 B: 3 x {x,y,z,w}; w of vertex 0 = triangle index bits  */
     DXV_DBG_TRI_NRM = 3,     /* T x 48 B: 3 x {nx,ny,nz,0}                                    */
-    DXV_DBG_PARENTS = 4      /* (T-1) internal + T leaf parent words: (parent << 1) | side    */
+    DXV_DBG_PARENTS = 4,     /* (T-1) internal + T leaf parent words: (parent << 1) | side    */
+    DXV_DBG_NODES32 = 5      /* max(T-1,1) x 32 B traversal nodes (half-float boxes)          */
 };
 
 typedef struct dxv_stats {

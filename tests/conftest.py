@@ -111,6 +111,13 @@ def hostcheck():
     L.hc_scene_height.restype = C.c_uint32
     L.hc_scene_nodes.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_scene_keys.argtypes = [C.c_void_p, C.c_void_p]
+    L.hc_scene_nodes32.argtypes = [C.c_void_p, C.c_void_p]
+    L.hc_half_down.argtypes = [C.c_float]
+    L.hc_half_down.restype = C.c_uint32
+    L.hc_half_up.argtypes = [C.c_float]
+    L.hc_half_up.restype = C.c_uint32
+    L.hc_half_to_float.argtypes = [C.c_uint32]
+    L.hc_half_to_float.restype = C.c_float
     L.hc_voxelize.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, u8p, C.c_void_p]
 
     class Host:
@@ -134,6 +141,11 @@ def hostcheck():
             L.hc_scene_nodes(self.h, out.ctypes.data_as(C.c_void_p))
             return out
 
+        def nodes32(self):
+            out = np.empty((max(self.T - 1, 1), 8), np.uint32)
+            L.hc_scene_nodes32(self.h, out.ctypes.data_as(C.c_void_p))
+            return out
+
         def keys(self):
             out = np.empty(self.T, np.uint64)
             L.hc_scene_keys(self.h, out.ctypes.data_as(C.c_void_p))
@@ -146,4 +158,5 @@ def hostcheck():
             ovf = L.hc_voxelize(self.h, N, mode, z0, nz, stack, g, t.ctypes.data_as(C.c_void_p) if texels else None)
             return (g, t, ovf) if texels else (g, ovf)
 
+    Host.lib = L
     return Host

@@ -10,11 +10,20 @@
 
 using namespace dxv;
 
+// old-style unpack for the replay tools below
+static inline void load_node(const Node32* nodes, int32_t i, F4& q0, F4& q1, F4& q2, int32_t& c0, int32_t& c1)
+{
+    const NodePlanes n = load_node(nodes, i);
+    q0 = F4{n.b[0], n.b[1], n.b[2], n.b[3]}; q1 = F4{n.b[4], n.b[5], n.b[6], n.b[7]}; q2 = F4{n.b[8], n.b[9], n.b[10], n.b[11]};
+    c0 = n.c0; c1 = n.c1;
+}
+
 struct HcScene {
     uint32_t T = 0;
     float bound[4];
     std::vector<uint64_t> keys;
     std::vector<Node> nodes;
+    std::vector<Node32> nodes32;
     std::vector<TriPos> triPos;
     std::vector<TriNrm> triNrm;
     uint32_t height = 0;
@@ -94,9 +103,15 @@ __attribute__((visibility("default"))) void* hc_scene_create(const float* vb, ui
         float lo[3], hi[3];
         s->height = refit(*s, 0, lo, hi);
     }
+    s->nodes32.resize(s->nodes.size());
+    for (size_t i = 0; i < s->nodes.size(); ++i) s->nodes32[i] = compress_node(s->nodes[i]);
     return s;
 }
 
+__attribute__((visibility("default"))) void hc_scene_nodes32(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes32.data(), s->nodes32.size() * sizeof(Node32)); }
+__attribute__((visibility("default"))) uint32_t hc_half_down(float x) { return half_down(x); }
+__attribute__((visibility("default"))) uint32_t hc_half_up(float x) { return half_up(x); }
+__attribute__((visibility("default"))) float hc_half_to_float(uint32_t h) { return half_to_float((uint16_t)h); }
 __attribute__((visibility("default"))) void hc_scene_destroy(void* p) { delete static_cast<HcScene*>(p); }
 __attribute__((visibility("default"))) uint32_t hc_scene_height(void* p) { return static_cast<HcScene*>(p)->height; }
 __attribute__((visibility("default"))) void hc_scene_nodes(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes.data(), s->nodes.size() * sizeof(Node)); }
@@ -107,7 +122,7 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
 {
     HcScene* s = static_cast<HcScene*>(p);
     int overflow = 0;
-    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
     {   // root box = union of the root node's two child boxes (as k_root_info computes it)
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
@@ -148,7 +163,7 @@ __attribute__((visibility("default"))) void hc_trace_stats(void* p, uint32_t N, 
             Ray r = make_ray_reference(N, ix, iy, iz);
             Hit best;
             TraceStats st{0, 0, 0};
-            trace_reference<StridedStack, true>(r, s->nodes.data(), s->triPos.data(), stk, 128, best, &st);
+            trace_reference<StridedStack, true>(r, s->nodes32.data(), s->triPos.data(), stk, 128, best, &st);
             rays++; nodes += st.nodes; leaves += st.leaves; noleaf += st.leaves == 0; trivial += st.nodes <= 2;
             if (st.maxsp > maxsp) maxsp = st.maxsp;
             h[st.maxsp < 63 ? st.maxsp : 63]++;
@@ -168,7 +183,7 @@ static uint64_t g_uniform = 0, g_distinct = 0;
 __attribute__((visibility("default"))) void hc_simt_stats(void* p, uint32_t N, uint32_t bstep, uint64_t* out)
 {
     HcScene* s = static_cast<HcScene*>(p);
-    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
     {
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
@@ -219,8 +234,8 @@ __attribute__((visibility("default"))) void hc_simt_stats(void* p, uint32_t N, u
                     const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
                     if (l0 || l1) {
                         leafNow++;
-                        leaf_reference(l.r, sc.triPos, l0 ? ~c0 : ~c1, l0 ? tn0 : tn1, l.best);
-                        if (l0 && l1) { secondNow++; leaf_reference(l.r, sc.triPos, ~c1, tn1, l.best); }
+                        leaf_reference(l.r, sc.triPos, l0 ? ~c0 : ~c1, l.best);
+                        if (l0 && l1) { secondNow++; leaf_reference(l.r, sc.triPos, ~c1, l.best); }
                     }
                     h0 = h0 && c0 >= 0 && tn0 <= l.best.t;
                     h1 = h1 && c1 >= 0 && tn1 <= l.best.t;
@@ -252,7 +267,7 @@ __attribute__((visibility("default"))) void hc_simt_stats(void* p, uint32_t N, u
 __attribute__((visibility("default"))) void hc_simt_stats_ww(void* p, uint32_t N, uint32_t bstep, int carry, uint64_t* out)
 {
     HcScene* s = static_cast<HcScene*>(p);
-    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
     {
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
@@ -310,9 +325,9 @@ __attribute__((visibility("default"))) void hc_simt_stats_ww(void* p, uint32_t N
                 for (int t = 0; t < 64; ++t) {
                     Lane& l = L[t];
                     if (l.pa < 0) continue;
-                    leaf_reference(l.r, sc.triPos, l.pa, l.ta, l.best);
+                    leaf_reference(l.r, sc.triPos, l.pa, l.best);
                     if (carry) { l.pa = l.pb; l.ta = l.tb; l.pb = -1; }
-                    else { l.pa = -1; if (l.pb >= 0) { sec++; leaf_reference(l.r, sc.triPos, l.pb, l.tb, l.best); l.pb = -1; } }
+                    else { l.pa = -1; if (l.pb >= 0) { sec++; leaf_reference(l.r, sc.triPos, l.pb, l.best); l.pb = -1; } }
                 }
                 if (sec) { my2++; p2lanes += sec; }
             }
@@ -331,7 +346,7 @@ __attribute__((visibility("default"))) void hc_simt_stats_ww(void* p, uint32_t N
 __attribute__((visibility("default"))) void hc_simt_stats_q(void* p, uint32_t N, uint32_t bstep, int Q, int thr, uint64_t* out)
 {
     HcScene* s = static_cast<HcScene*>(p);
-    SceneView sc{s->nodes.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
     {
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
@@ -388,7 +403,7 @@ __attribute__((visibility("default"))) void hc_simt_stats_q(void* p, uint32_t N,
                             if (!l.qn) continue;
                             n++;
                             l.qn--;
-                            if (l.qt[l.qn] <= l.best.t) leaf_reference(l.r, sc.triPos, l.ql[l.qn], l.qt[l.qn], l.best);
+                            if (l.qt[l.qn] <= l.best.t) leaf_reference(l.r, sc.triPos, l.ql[l.qn], l.best);
                         }
                         if (!n) break;
                         my2++; p2lanes += n;

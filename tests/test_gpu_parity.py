@@ -15,7 +15,7 @@ from dxrvoxelizer_amd.slabs import gather_slabs, slab_range
 
 pytestmark = pytest.mark.gpu
 
-DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS = range(5)
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32 = range(6)
 
 
 @pytest.fixture(scope="module")
@@ -54,6 +54,7 @@ def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
     assert np.array_equal(nodes[:, :12], want[:, :12]), "refit boxes differ"
     assert np.array_equal(nodes[:, 14:16], want[:, 14:16]), "subtree heights differ"
     assert st["tree_height"] == h.height
+    assert np.array_equal(vox.debug(DBG_NODES32), h.nodes32()), "compressed traversal nodes differ"
     tp = vox.debug(DBG_TRI_POS)
     k = tp[:, 3].view(np.uint32)
     assert np.array_equal(np.sort(k), np.arange(len(k), dtype=np.uint32))

@@ -110,3 +110,32 @@ def test_slab_concatenation_equals_full_grid(orc, hostcheck, dragon):
         z0, nz = slab_range(32, r, 8)
         parts.append((z0, h.voxelize(32, 0, z0=z0, nz=nz)[0]))
     assert np.array_equal(gather_slabs(parts), full)
+
+
+def test_half_conversions_are_outward_and_tight(hostcheck):
+    """Traversal nodes store half-float boxes rounded outward (dxv_math.h half_down / half_up): the
+    stored box must contain the exact one and be the tightest representable."""
+    L = hostcheck.lib
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-1.1, 1.1, 20000), rng.normal(0, 1e-3, 5000), [0.0, -0.0, 1.0, -1.0, 65504.0, 1e30, -1e30, 1e-9]])
+    for x in xs.astype(np.float32):
+        d, u = L.hc_half_down(x), L.hc_half_up(x)
+        fd, fu = L.hc_half_to_float(d), L.hc_half_to_float(u)
+        assert fd <= x <= fu
+        hd, hu = np.float16(fd), np.float16(fu)                    # numpy: exact f16 values
+        if abs(x) < 60000:
+            assert np.nextafter(hd, np.float16(np.inf)) > x or float(hd) == float(x)
+            assert np.nextafter(hu, np.float16(-np.inf)) < x or float(hu) == float(x)
+
+
+def test_compressed_nodes_contain_exact_boxes(orc, hostcheck, dragon):
+    vb, ib, _ = dragon
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    exact = h.nodes()[:, :12].view(np.float32)
+    packed = h.nodes32()
+    halves = packed[:, :6].copy().view(np.uint16).view(np.float16).astype(np.float32).reshape(-1, 12)
+    assert np.array_equal(packed[:, 6:8], h.nodes()[:, 12:14])     # links unchanged
+    for c in (0, 6):
+        assert np.all(halves[:, c:c + 3] <= exact[:, c:c + 3]) and np.all(halves[:, c + 3:c + 6] >= exact[:, c + 3:c + 6])
+    assert np.max(np.abs(halves - exact)) < 1e-3                   # half ulp near 1.0 is 2^-11
