@@ -130,10 +130,18 @@ def main():
     st0 = vox.stats()
     T, V = st0["num_tris"], st0["num_verts"]
 
+    # N > 1: block-cyclic Z partition (blocks of 8 slices dealt round-robin): contiguous slabs leave
+    # the GPUs that own empty space idle (profiles/r01: 2.5x at 8 slabs); still no collective.
+    zblock = 8
+    interleave = world > 1 and N % (zblock * world) == 0
     z0, nz = slab_range(N, rank, world)
+    if interleave:
+        nz = N // world
 
     def step():
-        if nz:
+        if interleave:
+            vox.VoxelizeInterleaved(N, rank, world, zblock, mode, sync=False)
+        elif nz:
             vox.Voxelize(N, mode, z0, nz, sync=False)
 
     for _ in range(args.warmup):
@@ -186,7 +194,8 @@ def main():
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}, {T} triangles, {N}^3 grid, {args.mode} predicate, "
-                                   f"one ray per voxel, Z-slab partition over {world} GPU(s)",
+                                   f"one ray per voxel, " + (f"Z blocks of {zblock} slices dealt round-robin over {world} GPUs"
+                                                           if interleave else f"Z-slab partition over {world} GPU(s)"),
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
                        "slab_slices_rank0": nz, "solid_voxels": int(tot.item()),
                        "tree_height": st["tree_height"], "stack_entries": st["stack_entries"],

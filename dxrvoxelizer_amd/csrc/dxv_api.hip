@@ -70,6 +70,7 @@ struct dxv_ctx {
     int optStack0 = 24;      // adaptive mode starts with this many entries (stack + leaf queue share them)
     int stackNow = 24;       // adaptive: LDS stack entries per thread currently in use for this scene
     int lastMode = 0;
+    uint32_t lastZBlock = 1, lastZPeriod = 1;
     bool pending = false;    // a voxelize launch has not been checked by dxv_sync yet
 };
 
@@ -167,6 +168,7 @@ int launch_now(dxv_ctx* c)
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
     p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
     p.N = c->stats.grid_dim; p.z0 = c->stats.z0; p.nz = c->stats.nz; p.mode = c->lastMode;
+    p.zBlock = c->lastZBlock; p.zPeriod = c->lastZPeriod;
     p.morton = (uint32_t)c->optMorton;
     p.regionBits = (uint32_t)c->optRegion;
     p.queued = (uint32_t)c->optQueue;
@@ -328,16 +330,15 @@ int dxv_build(dxv_ctx* c)
     return 0;
 }
 
-int dxv_voxelize_async(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nz)
+namespace {
+// slices this launch writes: local lz in [0, nzLocal) <-> global z0 + (lz / zBlock) * zPeriod + lz % zBlock
+int voxelize_common(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nzLocal, uint32_t zBlock, uint32_t zPeriod)
 {
-    if (!c) return 1;
     if (!c->haveScene) return fail(c, "dxv_voxelize: no scene (call dxv_build or dxv_scene_import first)");
-    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_voxelize: grid_dim must be even and in [2, 2048], got %u", N);
-    if (nz == 0 || z0 >= N || nz > N - z0) return fail(c, "dxv_voxelize: slab [%u, %u+%u) outside the grid (N=%u)", z0, z0, nz, N);
     if (mode != DXV_MODE_REFERENCE && mode != DXV_MODE_PARITY) return fail(c, "dxv_voxelize: unknown mode %d", mode);
     if (c->texels && mode != DXV_MODE_REFERENCE) return fail(c, "dxv_voxelize: texel output exists in reference mode only");
     DXV_HIP(c, hipSetDevice(c->device));
-    const size_t bytes = (size_t)N * N * nz;
+    const size_t bytes = (size_t)N * N * nzLocal;
     if (bytes > c->gridCap) {
         DXV_HIP(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->dGrid); c->dGrid = nullptr; c->gridCap = 0;
@@ -351,9 +352,33 @@ int dxv_voxelize_async(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t n
         c->texelCap = bytes;
     }
     c->gridBytes = bytes;
-    c->stats.grid_dim = N; c->stats.z0 = z0; c->stats.nz = nz;
-    c->lastMode = mode;
+    c->stats.grid_dim = N; c->stats.z0 = z0; c->stats.nz = nzLocal;
+    c->lastMode = mode; c->lastZBlock = zBlock; c->lastZPeriod = zPeriod;
     return launch_now(c);
+}
+} // namespace
+
+int dxv_voxelize_async(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nz)
+{
+    if (!c) return 1;
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_voxelize: grid_dim must be even and in [2, 2048], got %u", N);
+    if (nz == 0 || z0 >= N || nz > N - z0) return fail(c, "dxv_voxelize: slab [%u, %u+%u) outside the grid (N=%u)", z0, z0, nz, N);
+    return voxelize_common(c, N, mode, z0, nz, nz, nz);
+}
+
+int dxv_voxelize_interleaved_async(dxv_ctx* c, uint32_t N, int mode, uint32_t rank, uint32_t world, uint32_t zblock)
+{
+    if (!c) return 1;
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_voxelize: grid_dim must be even and in [2, 2048], got %u", N);
+    if (!world || rank >= world || !zblock || N % (zblock * world))
+        return fail(c, "dxv_voxelize_interleaved: need rank < world and grid_dim %% (zblock * world) == 0 (N=%u, world=%u, zblock=%u)", N, world, zblock);
+    return voxelize_common(c, N, mode, rank * zblock, N / world, zblock, zblock * world);
+}
+
+int dxv_voxelize_interleaved(dxv_ctx* c, uint32_t N, int mode, uint32_t rank, uint32_t world, uint32_t zblock)
+{
+    if (dxv_voxelize_interleaved_async(c, N, mode, rank, world, zblock)) return 1;
+    return dxv_sync(c);
 }
 
 int dxv_sync(dxv_ctx* c)

@@ -39,7 +39,8 @@ struct VoxelizeParams {
     uint8_t* grid;          // N*N*nz bytes
     uint32_t* texels;       // optional N*N*nz words
     uint32_t* status;       // status word (bit 0: traversal stack overflow)
-    uint32_t N, z0, nz;
+    uint32_t N, z0, nz;     // nz = slices written by this launch (local index lz in [0, nz))
+    uint32_t zBlock, zPeriod; // global slice of lz: z0 + (lz / zBlock) * zPeriod + lz % zBlock
     int mode;
     uint32_t morton;        // 1: Morton brick order (default), 0: linear x,y,z order
     uint32_t mortonBits;    // filled by the launcher

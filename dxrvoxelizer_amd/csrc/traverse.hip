@@ -60,7 +60,7 @@ __global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
     const uint32_t iy = by * B::y + (tid / B::x) % B::y;
     const uint32_t lz = bz * B::z + tid / (B::x * B::y);
     if (ix >= N || iy >= N || lz >= p.nz) return;
-    const uint32_t iz = p.z0 + lz;
+    const uint32_t iz = p.z0 + (lz / p.zBlock) * p.zPeriod + lz % p.zBlock;
     const size_t id = ((size_t)lz * N + iy) * N + ix;
 
     const StridedStack stk{stack + tid, B::threads};

@@ -121,10 +121,19 @@ def soup(num_tris=10_000_000, seed=0x5EED1234, extent=0.95, edge=0.02):
     pos[:, 0] = c
     pos[:, 1] = c + e1
     pos[:, 2] = c + e2
-    pos = pos.reshape(-1, 3)
-    ib = np.arange(3 * num_tris, dtype=np.uint32)
-    nrm = face_normals_like_reference(pos, ib)
-    return _vb(pos, nrm), ib
+    # private vertices: the reference's recomputeNormals rule reduces to the face normal
+    # normalize(cross(v1-v0, v2-v1)), normalised once more (float32 arithmetic throughout)
+    a, b = pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 1]
+    n = np.empty((num_tris, 3), np.float32)
+    n[:, 0] = a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1]
+    n[:, 1] = a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2]
+    n[:, 2] = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    for _ in range(2):
+        n /= np.sqrt(n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1] + n[:, 2] * n[:, 2])[:, None]
+    vb = np.empty((num_tris, 3, 6), np.float32)
+    vb[:, :, :3] = pos
+    vb[:, :, 3:] = n[:, None, :]
+    return vb.reshape(-1, 6), np.arange(3 * num_tris, dtype=np.uint32)
 
 
 def trisect(vb, ib):

@@ -30,6 +30,21 @@ def interleaved_blocks(N, rank, world, block):
     return out
 
 
+def interleaved_slices(N, rank, world, block):
+    """Global slice index of every local slice of `rank` in the block-cyclic partition, ascending
+    (what dxv_voxelize_interleaved computes)."""
+    lz = np.arange(int(N) // int(world))
+    return (lz // block * world + rank) * block + lz % block
+
+
+def scatter_interleaved(parts, N, world, block):
+    """Reassemble the full grid from per-rank interleaved grids [(rank, grid[N/world, N, N]), ...]."""
+    full = np.empty((N, N, N), np.uint8)
+    for rank, g in parts:
+        full[interleaved_slices(N, rank, world, block)] = g
+    return full
+
+
 def broadcast_scene(engine, dist, device, src=0):
     """Broadcast the built scene from rank `src` to every rank of the default process group.
 

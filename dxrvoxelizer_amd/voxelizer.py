@@ -82,6 +82,13 @@ class Voxelizer:
         self._last = (int(gridDim), int(nz))
         return True
 
+    def VoxelizeInterleaved(self, gridDim, rank, world, zblock=8, mode=MODE_REFERENCE, sync=True):
+        """This rank's share of a block-cyclic Z partition (dxv_voxelize_interleaved)."""
+        fn = self._lib.dxv_voxelize_interleaved if sync else self._lib.dxv_voxelize_interleaved_async
+        self._check(fn(self._ctx, int(gridDim), int(mode), int(rank), int(world), int(zblock)))
+        self._last = (int(gridDim), int(gridDim) // int(world))
+        return True
+
     def Sync(self):
         self._check(self._lib.dxv_sync(self._ctx))
 

@@ -185,6 +185,25 @@ def test_slabs_concatenate_to_the_full_grid(vox, bunny):
     assert np.array_equal(vox.Grid(), full[100:])
 
 
+def test_interleaved_partition_equals_full_grid(vox, dragon):
+    """The load-balanced partition bench.py uses for N > 1: block-cyclic Z blocks, ranks looped here."""
+    from dxrvoxelizer_amd.slabs import interleaved_slices, scatter_interleaved
+    vb, ib, _ = dragon
+    vox.InitFromArrays(vb, ib)
+    vox.Voxelize(128)
+    full = vox.Grid()
+    for world, block in ((8, 4), (4, 8), (2, 64), (1, 128)):
+        parts = []
+        for r in range(world):
+            vox.VoxelizeInterleaved(128, r, world, block)
+            parts.append((r, vox.Grid()))
+            assert np.array_equal(parts[-1][1], full[interleaved_slices(128, r, world, block)])
+        assert np.array_equal(scatter_interleaved(parts, 128, world, block), full)
+    import dxrvoxelizer_amd
+    with pytest.raises(dxrvoxelizer_amd.DxvError):
+        vox.VoxelizeInterleaved(128, 0, 3, 8)                 # 128 % 24 != 0
+
+
 def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     """What rank 0 broadcasts: export -> (device buffer) -> import into a second context."""
     import torch

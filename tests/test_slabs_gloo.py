@@ -24,6 +24,9 @@ def test_slab_ranges_cover_the_grid():
     assert slab_range(1024, 3, 8) == (384, 128)            # config 4: 128 slices per GPU
     blocks = [interleaved_blocks(64, r, 4, 8) for r in range(4)]
     assert sorted(sum(blocks, [])) == [(z, 8) for z in range(0, 64, 8)]
+    from dxrvoxelizer_amd.slabs import interleaved_slices
+    allz = np.concatenate([interleaved_slices(512, r, 8, 8) for r in range(8)])
+    assert sorted(allz) == list(range(512)) and list(interleaved_slices(512, 3, 8, 8)[:9]) == [24, 25, 26, 27, 28, 29, 30, 31, 88]
 
 
 class HostEngine:
