@@ -148,14 +148,20 @@ DXV_HD bool wave_any(bool x)
 // One internal-node visit of the postponed-leaf walk: two slab tests, hit leaves queued, near child
 // next, far child pushed.  The twelve box planes and two links arrive by value so that the device
 // build can feed them from SGPRs (wave-uniform visit, scalar load) or VGPRs (divergent visit).
-template <class Stack>
+template <bool PARITY, class Stack>
 DXV_HD void node_step(const Ray& r, float lo0x, float lo0y, float lo0z, float hi0x, float hi0y, float hi0z,
                       float lo1x, float lo1y, float lo1z, float hi1x, float hi1y, float hi1z, int32_t c0, int32_t c1,
                       const Stack& stk, int cap, float bestT, int32_t& node, int& sp, int& qn)
 {
-    float tn0, tn1;
-    bool h0 = slab(r, lo0x, lo0y, lo0z, hi0x, hi0y, hi0z, tn0) && tn0 <= bestT;
-    bool h1 = slab(r, lo1x, lo1y, lo1z, hi1x, hi1y, hi1z, tn1) && tn1 <= bestT;
+    float tn0 = 0.0f, tn1 = 0.0f;
+    bool h0, h1;
+    if (PARITY) {
+        h0 = slab_parity(r, lo0y, lo0z, hi0x, hi0y, hi0z);
+        h1 = slab_parity(r, lo1y, lo1z, hi1x, hi1y, hi1z);
+    } else {
+        h0 = slab(r, lo0x, lo0y, lo0z, hi0x, hi0y, hi0z, tn0) && tn0 <= bestT;
+        h1 = slab(r, lo1x, lo1y, lo1z, hi1x, hi1y, hi1z, tn1) && tn1 <= bestT;
+    }
     if (h0 && c0 < 0) stk.put(cap - 1 - qn++, ~c0);
     if (h1 && c1 < 0) stk.put(cap - 1 - qn++, ~c1);
     h0 = h0 && c0 >= 0;
@@ -187,11 +193,12 @@ __device__ __forceinline__ float sgpr_half(uint64_t v, int which)   // which = 0
 }
 #endif
 
-template <class Stack, bool STATS = false>
-DXV_HD bool trace_reference_q(Ray& r, const Node32* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
-                              TraceStats* st = nullptr)
+// The walk shared by both occupancy rules.  `Leaf` is called once per queued triangle:
+// leaf(leafIndex, TriPos).
+template <bool PARITY, class Stack, class Leaf, bool STATS = false>
+DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, const Stack& stk, int cap, const float& bestT,
+                        Leaf&& leaf, TraceStats* st = nullptr)
 {
-    best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
     stk.put(0, -1);
     int sp = 1, qn = 0;
     bool ok = true;
@@ -201,20 +208,20 @@ DXV_HD bool trace_reference_q(Ray& r, const Node32* nodes, const TriPos* tris, c
             if (STATS) st->nodes++;
 #if defined(__HIP_DEVICE_COMPILE__)
             // all lanes that are still walking sit on the same node (40-50 % of the visits): one
-            // scalar load instead of 64 lanes x 64 B through the vector L1
+            // scalar load instead of 64 lanes x 32 B through the vector L1
             const int32_t n0 = __builtin_amdgcn_readfirstlane(node);
             if (__builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
                 const NodeSgpr n = load_node_scalar(nodes, n0);
-                node_step(r, sgpr_half(n.w[0], 0), sgpr_half(n.w[0], 1), sgpr_half(n.w[0], 2), sgpr_half(n.w[0], 3),
-                          sgpr_half(n.w[1], 0), sgpr_half(n.w[1], 1), sgpr_half(n.w[1], 2), sgpr_half(n.w[1], 3),
-                          sgpr_half(n.w[2], 0), sgpr_half(n.w[2], 1), sgpr_half(n.w[2], 2), sgpr_half(n.w[2], 3),
-                          (int32_t)(uint32_t)n.w[3], (int32_t)(uint32_t)(n.w[3] >> 32), stk, cap, best.t, node, sp, qn);
+                node_step<PARITY>(r, sgpr_half(n.w[0], 0), sgpr_half(n.w[0], 1), sgpr_half(n.w[0], 2), sgpr_half(n.w[0], 3),
+                                  sgpr_half(n.w[1], 0), sgpr_half(n.w[1], 1), sgpr_half(n.w[1], 2), sgpr_half(n.w[1], 3),
+                                  sgpr_half(n.w[2], 0), sgpr_half(n.w[2], 1), sgpr_half(n.w[2], 2), sgpr_half(n.w[2], 3),
+                                  (int32_t)(uint32_t)n.w[3], (int32_t)(uint32_t)(n.w[3] >> 32), stk, cap, bestT, node, sp, qn);
             } else
 #endif
             {
                 const NodePlanes n = load_node(nodes, node);
-                node_step(r, n.b[0], n.b[1], n.b[2], n.b[3], n.b[4], n.b[5], n.b[6], n.b[7], n.b[8], n.b[9], n.b[10],
-                          n.b[11], n.c0, n.c1, stk, cap, best.t, node, sp, qn);
+                node_step<PARITY>(r, n.b[0], n.b[1], n.b[2], n.b[3], n.b[4], n.b[5], n.b[6], n.b[7], n.b[8], n.b[9], n.b[10],
+                                  n.b[11], n.c0, n.c1, stk, cap, bestT, node, sp, qn);
             }
             if (STATS && (uint32_t)(sp - 1) > st->maxsp) st->maxsp = (uint32_t)(sp - 1);
         }
@@ -225,25 +232,62 @@ DXV_HD bool trace_reference_q(Ray& r, const Node32* nodes, const TriPos* tris, c
         if (walking && !wave_any(tight && qn > 0)) continue;
         for (int i = 0; wave_any(i < qn); ++i) {
             if (i < qn) {
-                const int32_t leaf = stk.get(cap - 1 - i);
-                const TriPos tp = load_tri(tris, leaf);
-                float lo[3], hi[3], tn;
-                tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+                const int32_t l = stk.get(cap - 1 - i);
                 if (STATS) st->leaves++;
-                if (slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= best.t) {
-                    if (r.kz < 0) ray_shear(r);
-                    float t, b1, b2;
-                    if (tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2) && tn <= t) {
-                        const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
-                        if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = b1; best.b2 = b2; best.k = k; best.leaf = leaf; }
-                    }
-                }
+                leaf(l, load_tri(tris, l));
             }
         }
         qn = 0;
         if (!walking) break;
     }
     return ok;
+}
+
+// reference rule: candidacy by the triangle's own exact box, closest = min (t, k)
+struct LeafReference {
+    Ray& r;
+    Hit& best;
+    DXV_HD void operator()(int32_t leaf, const TriPos& tp) const
+    {
+        float lo[3], hi[3], tn;
+        tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+        if (!(slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= best.t)) return;
+        if (r.kz < 0) ray_shear(r);
+        float t, b1, b2;
+        if (!(tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2) && tn <= t)) return;
+        const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
+        if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = b1; best.b2 = b2; best.k = k; best.leaf = leaf; }
+    }
+};
+
+// parity rule: every accepted triangle counts once
+struct LeafParity {
+    const Ray& r;
+    uint32_t& count;
+    DXV_HD void operator()(int32_t, const TriPos& tp) const
+    {
+        float lo[3], hi[3];
+        tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+        if (!slab_parity(r, lo[1], lo[2], hi[0], hi[1], hi[2])) return;
+        float t, b1, b2;
+        if (tri_test<true>(r, tp.v0, tp.v1, tp.v2, t, b1, b2)) count++;
+    }
+};
+
+template <class Stack, bool STATS = false>
+DXV_HD bool trace_reference_q(Ray& r, const Node32* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
+                              TraceStats* st = nullptr)
+{
+    best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
+    return walk_queued<false, Stack, LeafReference, STATS>(r, nodes, tris, stk, cap, best.t, LeafReference{r, best}, st);
+}
+
+template <class Stack>
+DXV_HD bool trace_parity_q(const Ray& r, const Node32* nodes, const TriPos* tris, const Stack& stk, int cap, uint32_t& count)
+{
+    count = 0;
+    const float unused = 0.0f;
+    return walk_queued<true, Stack, LeafParity>(r, nodes, tris, stk, cap, unused, LeafParity{r, count});
 }
 
 DXV_HD uint32_t leaf_parity(const Ray& r, const TriPos* tris, int32_t leaf)
@@ -320,7 +364,7 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     return in ? 1 : 0;
 }
 
-template <class Stack>
+template <bool QUEUED, class Stack>
 DXV_HD uint8_t voxel_parity(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
                             const Stack& stk, int cap, bool& overflow)
 {
@@ -328,7 +372,9 @@ DXV_HD uint8_t voxel_parity(const SceneView& sc, uint32_t N, uint32_t ix, uint32
     // +X ray: nothing to count when the origin is outside the root's y/z extent or beyond its +x face
     if (!slab_parity(r, sc.rootLo[1], sc.rootLo[2], sc.rootHi[0], sc.rootHi[1], sc.rootHi[2])) return 0;
     uint32_t count;
-    if (!trace_parity(r, sc.nodes, sc.triPos, stk, cap, count)) { overflow = true; return 0; }
+    const bool ok = QUEUED ? trace_parity_q(r, sc.nodes, sc.triPos, stk, cap, count)
+                           : trace_parity(r, sc.nodes, sc.triPos, stk, cap, count);
+    if (!ok) { overflow = true; return 0; }
     return (uint8_t)(count & 1u);
 }
 

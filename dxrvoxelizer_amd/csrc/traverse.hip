@@ -71,7 +71,7 @@ __global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
         occ = voxel_reference<QUEUED>(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
         if (TEXELS) p.texels[id] = texel;
     } else {
-        occ = voxel_parity(p.scene, N, ix, iy, iz, stk, STACK, overflow);
+        occ = voxel_parity<QUEUED>(p.scene, N, ix, iy, iz, stk, STACK, overflow);
     }
     if (overflow) atomicOr(p.status, 1u);
     p.grid[id] = occ;
@@ -110,7 +110,8 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
         else if (p.queued) k_voxelize<B, STACK, 0, false, true><<<g, b, 0, s>>>(p);
         else k_voxelize<B, STACK, 0, false, false><<<g, b, 0, s>>>(p);
     } else {
-        k_voxelize<B, STACK, 1, false, false><<<g, b, 0, s>>>(p);
+        if (p.queued) k_voxelize<B, STACK, 1, false, true><<<g, b, 0, s>>>(p);
+        else k_voxelize<B, STACK, 1, false, false><<<g, b, 0, s>>>(p);
     }
     return hipGetLastError();
 }

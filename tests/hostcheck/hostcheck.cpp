@@ -138,7 +138,8 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
             uint32_t texel = 0;
             out[id] = mode == 0 ? voxel_reference<false>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
                       : mode == 2 ? voxel_reference<true>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
-                                : voxel_parity(sc, N, ix, iy, iz, stk, stackCap, ovf);
+                      : mode == 3 ? voxel_parity<true>(sc, N, ix, iy, iz, stk, stackCap, ovf)
+                                  : voxel_parity<false>(sc, N, ix, iy, iz, stk, stackCap, ovf);
             if (texels) texels[id] = texel;
             if (ovf) overflow |= 1;
         }

@@ -37,7 +37,7 @@ def test_host_lbvh_equals_oracle_assets(orc, hostcheck, request, name):
     keys = h.keys()
     assert np.all(keys[1:] > keys[:-1])
     assert 1 <= h.height <= 62
-    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2)):      # host mode 2 = postponed-leaf traversal
+    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2), (64, 3)):   # host modes 2/3 = postponed-leaf walks
         g, ovf = h.voxelize(N, mode, stack=h.height + 3)
         assert not ovf
         assert np.array_equal(g, s.voxelize(N, mode=mode % 2))
@@ -59,7 +59,7 @@ def test_host_lbvh_equals_oracle_brute_synthetic(orc, hostcheck, gen, args):
     s = orc.Scene(vb, ib)
     h = hostcheck(vb, ib, s.bound)
     check_tree(h.nodes(), h.T)
-    modes = (0, 2) if gen == "soup" else (0, 1, 2)
+    modes = (0, 2) if gen == "soup" else (0, 1, 2, 3)
     for mode in modes:
         g, ovf = h.voxelize(16, mode)
         assert not ovf
@@ -76,7 +76,7 @@ def test_single_triangle_and_duplicates(orc, hostcheck):
     one = np.arange(3, dtype=np.uint32)
     s = orc.Scene(vb, one)
     h = hostcheck(vb, one, s.bound)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         g, ovf = h.voxelize(16, mode)
         assert not ovf and np.array_equal(g, s.voxelize(16, mode=mode % 2, algo=orc.ALGO_BRUTE))
     many = np.tile(one, 37)
@@ -86,8 +86,9 @@ def test_single_triangle_and_duplicates(orc, hostcheck):
     for mode in (0, 2):
         g, ovf = h.voxelize(16, mode)
         assert not ovf and np.array_equal(g, s.voxelize(16, algo=orc.ALGO_BRUTE))
-    g, ovf = h.voxelize(16, 1)
-    assert np.array_equal(g, s.voxelize(16, mode=1, algo=orc.ALGO_BRUTE))
+    for mode in (1, 3):
+        g, ovf = h.voxelize(16, mode)
+        assert np.array_equal(g, s.voxelize(16, mode=1, algo=orc.ALGO_BRUTE))
 
 
 def test_stack_overflow_is_reported(orc, hostcheck, bunny):
