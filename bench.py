@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--brick", type=int, default=-1)
     ap.add_argument("--stack", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--interleave", action="store_true", help="use the block-cyclic partition call even on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,7 +100,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the voxelizer has no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -119,7 +121,7 @@ def main():
     if rank == 0:
         vb, ib, label = make_mesh(args.mesh)
         vox.InitFromArrays(vb, ib)               # upload + LBVH build (not part of a step)
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -133,7 +135,7 @@ def main():
     # N > 1: block-cyclic Z partition (blocks of 8 slices dealt round-robin): contiguous slabs leave
     # the GPUs that own empty space idle (profiles/r01: 2.5x at 8 slabs); still no collective.
     zblock = 8
-    interleave = world > 1 and N % (zblock * world) == 0
+    interleave = (world > 1 or args.interleave) and N % (zblock * world) == 0
     z0, nz = slab_range(N, rank, world)
     if interleave:
         nz = N // world
@@ -148,7 +150,7 @@ def main():
         step()
     vox.Sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -157,7 +159,7 @@ def main():
         step()
     ev1.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     vox.Sync()                                   # deferred kernel status (stack overflow) is an error
@@ -167,7 +169,7 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(solid)], dtype=torch.float64, device="cuda")
     kmax = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
@@ -211,7 +213,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     vox.close()
