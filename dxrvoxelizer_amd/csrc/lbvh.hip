@@ -198,31 +198,15 @@ __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict
     rootInfo[7] = 1;
 }
 
-hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[5])
+// K4 + K5 + root info over an existing hierarchy (links and parent words in place).
+static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t s)
 {
     const uint32_t T = b.T;
-    Bound4 bnd;
-    for (int a = 0; a < 4; ++a) bnd.c[a] = b.bound[a];
     const uint32_t numNodes = T > 1 ? T - 1 : 1;
     hipError_t e;
-    // poison the nodes (all-ones = NaN boxes): a box that was never merged cannot pass a slab test
-    if ((e = hipMemsetAsync(b.nodes, 0xff, sizeof(Node) * (size_t)numNodes, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
-
-    (void)hipEventRecord(ev[0], s);
-    k_tri_keys<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys);
-    (void)hipEventRecord(ev[1], s);
-    if (T > 1) {
-        if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;
-    }
-    (void)hipEventRecord(ev[2], s);
-    k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm);
     if (T == 1) {
         k_single_tri<<<1, 1, 0, s>>>(b.triPos, b.nodes);
-        (void)hipEventRecord(ev[3], s);
     } else {
-        k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents);
-        (void)hipEventRecord(ev[3], s);
         if ((e = hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * (size_t)(T - 1), s)) != hipSuccess) return e;
         if (refitMode == 0) {
             k_refit_atomic<<<blocks_for(T), kThreads, 0, s>>>(b.triPos, T, b.nodes, b.parents, b.flags);
@@ -244,7 +228,48 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     }
     k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo);
+    return hipGetLastError();
+}
+
+hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[5])
+{
+    const uint32_t T = b.T;
+    Bound4 bnd;
+    for (int a = 0; a < 4; ++a) bnd.c[a] = b.bound[a];
+    const uint32_t numNodes = T > 1 ? T - 1 : 1;
+    hipError_t e;
+    // poison the nodes (all-ones = NaN boxes): a box that was never merged cannot pass a slab test
+    if ((e = hipMemsetAsync(b.nodes, 0xff, sizeof(Node) * (size_t)numNodes, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
+
+    (void)hipEventRecord(ev[0], s);
+    k_tri_keys<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys);
+    (void)hipEventRecord(ev[1], s);
+    if (T > 1) {
+        if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;
+    }
+    (void)hipEventRecord(ev[2], s);
+    k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm);
+    if (T > 1) k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents);
+    (void)hipEventRecord(ev[3], s);
+    if ((e = refit_stage(b, refitMode, s)) != hipSuccess) return e;
     (void)hipEventRecord(ev[4], s);
+    return hipGetLastError();
+}
+
+// Dynamic meshes (the reference API's ALLOW_UPDATE / PERFORM_UPDATE, XUSG/RayTracing/XUSGRayTracing.h:13-22,
+// unused by the sample): vertices moved, topology and Morton order kept -> re-gather the triangle
+// records and refit the boxes.  ev[0..1] bracket the work.
+hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[2])
+{
+    Bound4 bnd;
+    for (int a = 0; a < 4; ++a) bnd.c[a] = b.bound[a];
+    hipError_t e;
+    if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    (void)hipEventRecord(ev[0], s);
+    k_tri_gather<<<blocks_for(b.T), kThreads, 0, s>>>(b.vb, b.ib, b.T, bnd, b.keys, b.triPos, b.triNrm);
+    if ((e = refit_stage(b, refitMode, s)) != hipSuccess) return e;
+    (void)hipEventRecord(ev[1], s);
     return hipGetLastError();
 }
 

@@ -74,6 +74,14 @@ class Voxelizer:
         self._check(self._lib.dxv_build(self._ctx))
         return True
 
+    def UpdateVertices(self, vb, refit=True):
+        """Animated vertices on fixed topology: upload + refit of the existing hierarchy (N4)."""
+        vb = np.ascontiguousarray(vb, np.float32).reshape(-1, 6)
+        self._check(self._lib.dxv_update_vertices(self._ctx, vb, len(vb)))
+        if refit:
+            self._check(self._lib.dxv_refit(self._ctx))
+        return True
+
     def Voxelize(self, gridDim, mode=MODE_REFERENCE, z0=0, nz=None, sync=True):
         """Voxelizer::voxelize (Content/Voxelizer.cpp:351-369) with gridDim as a parameter."""
         nz = gridDim - z0 if nz is None else nz

@@ -88,6 +88,14 @@ DXV_API int dxv_set_mesh(dxv_ctx* ctx, const float* vb, uint32_t num_verts, cons
  * an LBVH: Morton keys -> radix sort -> Karras hierarchy -> bottom-up refit. */
 DXV_API int dxv_build(dxv_ctx* ctx);
 
+/* Dynamic meshes ("real-time voxelization", README.md:2): the reference API exposes
+ * BuildFlag::ALLOW_UPDATE / PERFORM_UPDATE (XUSG/RayTracing/XUSGRayTracing.h:13-22) but the sample
+ * never uses them.  dxv_update_vertices replaces the vertex buffer contents (same vertex count,
+ * same index buffer; the normalising bound stays the one of dxv_set_mesh, as the reference's
+ * m_bound stays the one of Init) and dxv_refit recomputes the boxes of the existing hierarchy. */
+DXV_API int dxv_update_vertices(dxv_ctx* ctx, const float* vb, uint32_t num_verts);
+DXV_API int dxv_refit(dxv_ctx* ctx);
+
 /* Voxelize slices [z0, z0+nz) of a grid_dim^3 grid: replaces Voxelizer::voxelize =
  * DispatchRays(GRID_SIZE, GRID_SIZE*GRID_SIZE, 1) (Content/Voxelizer.cpp:351-369) with grid_dim
  * promoted from the GRID_SIZE macro (:8) to a parameter.  grid_dim must be even (an odd grid has

@@ -69,6 +69,7 @@ def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
 def test_refit_variants_identical(dxv, dragon):
     vb, ib, _ = dragon
     a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
+    a.set_option("refit", 0)
     b.set_option("refit", 1)
     a.InitFromArrays(vb, ib)
     b.InitFromArrays(vb, ib)
@@ -202,6 +203,38 @@ def test_interleaved_partition_equals_full_grid(vox, dragon):
     import dxrvoxelizer_amd
     with pytest.raises(dxrvoxelizer_amd.DxvError):
         vox.VoxelizeInterleaved(128, 0, 3, 8)                 # 128 % 24 != 0
+
+
+def test_refit_after_vertex_update_equals_rebuild(dxv, orc, bunny):
+    """N4: animate the vertices (fixed topology), refit the existing hierarchy; the grid must equal
+    the oracle on the deformed mesh normalised by the ORIGINAL bound (the reference's m_bound is set
+    once in Init) -- here checked by keeping two bound-defining helper vertices fixed."""
+    vb, ib, _ = bunny
+    lo, hi = vb[:, :3].min(0), vb[:, :3].max(0)
+    c = (lo + hi) / 2
+    big = 1.25 * (hi - lo).max() / 2
+    pins = np.zeros((2, 6), np.float32)
+    pins[0, :3], pins[1, :3] = c - big, c + big              # unreferenced vertices pin the bound
+    vb0 = np.concatenate([vb, pins]).astype(np.float32)
+    v = dxv.Voxelizer(0)
+    v.InitFromArrays(vb0, ib)
+    h0 = v.stats()["tree_height"]
+    for phase in (0.7, 1.9):
+        vb1 = vb0.copy()
+        y = (vb1[:-2, 1] - lo[1]) / (hi[1] - lo[1])
+        vb1[:-2, 0] += np.float32(0.12 * (hi[0] - lo[0])) * np.sin(6.0 * y + phase).astype(np.float32)   # sway
+        v.UpdateVertices(vb1)
+        assert v.stats()["tree_height"] == h0               # same hierarchy, new boxes
+        v.Voxelize(64)
+        want = orc.Scene(vb1, ib).voxelize(64)
+        assert np.array_equal(v.Grid(), want)
+    fresh = dxv.Voxelizer(0)
+    fresh.InitFromArrays(vb1, ib)                            # full rebuild of the deformed mesh
+    fresh.Voxelize(64)
+    assert np.array_equal(fresh.Grid(), v.Grid())
+    with pytest.raises(dxv.DxvError):
+        v.UpdateVertices(vb1[:-1])                           # vertex count must not change
+    v.close(), fresh.close()
 
 
 def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
