@@ -67,8 +67,8 @@ struct dxv_ctx {
     int optMorton = 1;       // Morton brick order
     int optQueue = 1;        // postponed-leaf traversal
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
-    int optStack0 = 24;      // adaptive mode starts with this many entries (stack + leaf queue share them)
-    int stackNow = 24;       // adaptive: LDS stack entries per thread currently in use for this scene
+    int optStack0 = 20;      // adaptive mode starts with this many entries (stack + leaf queue share them)
+    int stackNow = 20;       // adaptive: LDS stack entries per thread currently in use for this scene
     int lastMode = 0;
     uint32_t lastZBlock = 1, lastZPeriod = 1;
     bool pending = false;    // a voxelize launch has not been checked by dxv_sync yet
@@ -155,8 +155,9 @@ float elapsed(hipEvent_t a, hipEvent_t b)
 
 // Stack policy.  The stack never needs more than treeHeight entries, but rays rarely push more
 // than a dozen, and LDS (entries * 4 B * threads) is what limits resident waves.  Adaptive mode
-// starts at 16 entries; a kernel that runs out reports it through the status word and dxv_sync
-// re-runs the launch with the always-sufficient depth and keeps it for this scene.
+// starts at 20 entries; a kernel that runs out reports it through the status word and dxv_sync
+// re-runs the launch with the next larger depth (up to the always-sufficient one) and keeps it for
+// this scene.
 // (+3: the postponed-leaf traversal keeps room for one push and two queued leaves)
 int safe_stack(const dxv_ctx* c) { return stack_round_up((int)c->hdr.treeHeight + 3); }
 
@@ -423,7 +424,7 @@ int dxv_sync(dxv_ctx* c)
 {
     if (!c) return 1;
     DXV_HIP(c, hipSetDevice(c->device));
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 8; ++attempt) {
         uint32_t status = 0;
         DXV_HIP(c, hipMemcpyAsync(&status, c->dStatus, sizeof(status), hipMemcpyDeviceToHost, c->stream));
         DXV_HIP(c, hipStreamSynchronize(c->stream));
@@ -431,8 +432,10 @@ int dxv_sync(dxv_ctx* c)
         c->pending = false;
         if (!status) return 0;
         DXV_HIP(c, hipMemsetAsync(c->dStatus, 0, sizeof(uint32_t), c->stream));
-        if (attempt == 0 && !c->optStack && c->stackNow < safe_stack(c) && c->haveScene && c->stats.grid_dim) {
-            c->stackNow = safe_stack(c);       // grow once to the depth that cannot overflow and redo
+        if (!c->optStack && c->stackNow < safe_stack(c) && c->haveScene && c->stats.grid_dim) {
+            // grow to the next instantiated depth (at most up to the depth that cannot overflow) and redo
+            const int next = stack_round_up(c->stackNow + 1);
+            c->stackNow = next < safe_stack(c) ? next : safe_stack(c);
             if (launch_now(c)) return 1;
             continue;
         }

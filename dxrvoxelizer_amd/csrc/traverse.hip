@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t compact1by2(uint32_t x)
 }
 
 template <class B, int STACK, int MODE, bool TEXELS, bool QUEUED>
-__global__ __launch_bounds__(B::threads) void k_voxelize(VoxelizeParams p)
+__global__ __launch_bounds__(B::threads, 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs
 {
     __shared__ int32_t stack[STACK * B::threads];
     const uint32_t N = p.N;
@@ -123,6 +123,7 @@ static hipError_t launch_stack(const VoxelizeParams& p, int stackEntries, hipStr
     case 8: return launch_shape<B, 8>(p, s);
     case 12: return launch_shape<B, 12>(p, s);
     case 16: return launch_shape<B, 16>(p, s);
+    case 20: return launch_shape<B, 20>(p, s);
     case 24: return launch_shape<B, 24>(p, s);
     case 32: return launch_shape<B, 32>(p, s);
     case 48: return launch_shape<B, 48>(p, s);
@@ -134,7 +135,7 @@ static hipError_t launch_stack(const VoxelizeParams& p, int stackEntries, hipStr
 // suffice.  Smallest instantiated depth >= want (LDS = depth * 4 B per thread).
 int stack_round_up(int want)
 {
-    const int sizes[] = {8, 12, 16, 24, 32, 48, 64};
+    const int sizes[] = {8, 12, 16, 20, 24, 32, 48, 64};
     for (int v : sizes) if (want <= v) return v;
     return 64;
 }
