@@ -66,6 +66,7 @@ struct dxv_ctx {
     int optRefit = 1;        // 1 = level-synchronous sweeps (default: 17-30x faster than the fence-bound one-pass climb), 0 = atomic one-pass
     int optMorton = 1;       // Morton brick order
     int optQueue = 1;        // postponed-leaf traversal
+    int optRows = 1;         // parity mode: one tree walk per grid row (k_parity_rows) instead of per voxel
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
     int optStack0 = 20;      // adaptive mode starts with this many entries (stack + leaf queue share them)
     int stackNow = 20;       // adaptive: LDS stack entries per thread currently in use for this scene
@@ -176,7 +177,8 @@ int launch_now(dxv_ctx* c)
     const int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
-    DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
+    if (p.mode == DXV_MODE_PARITY && c->optRows) DXV_HIP(c, launch_parity_rows(p, c->stream));
+    else DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
     DXV_HIP(c, hipEventRecord(c->ev[6], c->stream));
     c->pending = true;
     return 0;
@@ -557,6 +559,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "refit")) {
         if (value != 0 && value != 1) return fail(c, "option refit: %lld not in {0,1}", (long long)value);
         c->optRefit = (int)value;
+    } else if (!strcmp(key, "rows")) {
+        if (value != 0 && value != 1) return fail(c, "option rows: %lld not in {0,1}", (long long)value);
+        c->optRows = (int)value;
     } else if (!strcmp(key, "queue")) {
         if (value != 0 && value != 1) return fail(c, "option queue: %lld not in {0,1}", (long long)value);
         c->optQueue = (int)value;

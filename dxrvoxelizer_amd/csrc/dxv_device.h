@@ -50,6 +50,7 @@ struct VoxelizeParams {
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
 int stack_round_up(int want);
+hipError_t launch_parity_rows(const VoxelizeParams& p, hipStream_t s);   // parity mode, one tree walk per row run
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
 int num_brick_shapes();
 

@@ -182,6 +182,56 @@ DXV_HD bool tri_test(const Ray& r, const F4& v0, const F4& v1, const F4& v2, flo
 }
 
 // ------------------------------------------------------------------------------------------
+// Parity mode, row form.  All voxels of a grid row (fixed iy, iz) fire the same +X line; for a
+// triangle everything tri_test<true> computes from the y/z coordinates -- the sheared vertices
+// (with Sx = Sy = 0 they are just v.yz - o.yz; the fma against -0 can only change the sign of a
+// zero, which no comparison below observes), the edge functions U, V, W with their exact-zero
+// fallback and fill rule, the sign test and det -- is the same for the whole row.  Only
+// t = ((U*(v0.x-ox) + V*(v1.x-ox)) + W*(v2.x-ox)) / det and the box test hi.x >= ox depend on the
+// voxel.  parity_row_setup is evaluated once per (row, triangle), parity_row_voxel per voxel:
+// bit-identical to the per-voxel definition, a row shares one BVH walk.
+// ------------------------------------------------------------------------------------------
+struct ParityRowTri { float U, V, W, det, v0x, v1x, v2x, hix; bool hit; };
+DXV_HD void tri_box(const F4& a, const F4& b, const F4& c, float lo[3], float hi[3]);
+
+DXV_HD ParityRowTri parity_row_setup(float oy, float oz, const F4& v0, const F4& v1, const F4& v2)
+{
+    ParityRowTri s;
+    float lo[3], hi[3];
+    tri_box(v0, v1, v2, lo, hi);
+    s.hit = lo[1] <= oy && oy <= hi[1] && lo[2] <= oz && oz <= hi[2];
+    s.hix = hi[0]; s.v0x = v0.x; s.v1x = v1.x; s.v2x = v2.x;
+    const float Ax = v0.y - oy, Ay = v0.z - oz, Bx = v1.y - oy, By = v1.z - oz, Cx = v2.y - oy, Cy = v2.z - oz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    float su = U, sv = V, sw = W;
+    if (su == 0.0f) { const float ey = By - Cy, ex = Bx - Cx; su = ey != 0.0f ? -ey : ex; }
+    if (sv == 0.0f) { const float ey = Cy - Ay, ex = Cx - Ax; sv = ey != 0.0f ? -ey : ex; }
+    if (sw == 0.0f) { const float ey = Ay - By, ex = Ax - Bx; sw = ey != 0.0f ? -ey : ex; }
+    if (su == 0.0f || sv == 0.0f || sw == 0.0f) s.hit = false;
+    if ((su < 0.0f || sv < 0.0f || sw < 0.0f) && (su > 0.0f || sv > 0.0f || sw > 0.0f)) s.hit = false;
+    s.U = U; s.V = V; s.W = W;
+    s.det = (U + V) + W;
+    if (s.det == 0.0f) s.hit = false;
+    return s;
+}
+
+DXV_HD bool parity_row_voxel(const ParityRowTri& s, float ox)
+{
+    if (!(s.hix >= ox)) return false;
+    const float Az = s.v0x - ox, Bz = s.v1x - ox, Cz = s.v2x - ox;      // Sz = 1
+    const float T = (s.U * Az + s.V * Bz) + s.W * Cz;
+    const float t = T / s.det;
+    return t > 0.0f && t < kTMax;
+}
+
+// ------------------------------------------------------------------------------------------
 // Closest-hit predicate: hlsl:110-116 (normal interpolation), :137-138 (test), :5 (threshold).
 // ------------------------------------------------------------------------------------------
 DXV_HD bool predicate(const Ray& r, const F4& n0, const F4& n1, const F4& n2, float b1, float b2,

@@ -378,4 +378,33 @@ DXV_HD uint8_t voxel_parity(const SceneView& sc, uint32_t N, uint32_t ix, uint32
     return (uint8_t)(count & 1u);
 }
 
+// ------------------------------------------------------------------------------------------
+// Parity mode, row form: one walk of the tree for a run of voxels of one grid row.
+// `each(tri)` is called for every triangle whose exact box contains (oy, oz) in y/z and is not
+// entirely left of oxMin; node tests use the outward-rounded boxes (supersets).  The walk depends
+// only on (oy, oz, oxMin): on the device it is wave-uniform (scalar node and triangle fetches,
+// one LDS stack per wave).  `NodeFetch(i)` returns NodePlanes, `TriFetch(leaf)` a TriPos.
+// ------------------------------------------------------------------------------------------
+template <class NodeFetch, class TriFetch, class StackT, class Each>
+DXV_HD void walk_parity_row(float oy, float oz, float oxMin, NodeFetch&& nodeAt, TriFetch&& triAt, StackT& stk, Each&& each)
+{
+    int sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        const NodePlanes n = nodeAt(node);
+        const bool h0 = n.b[1] <= oy && oy <= n.b[4] && n.b[2] <= oz && oz <= n.b[5] && n.b[3] >= oxMin;
+        const bool h1 = n.b[7] <= oy && oy <= n.b[10] && n.b[8] <= oz && oz <= n.b[11] && n.b[9] >= oxMin;
+        if (h0 && n.c0 < 0) each(triAt(~n.c0));
+        if (h1 && n.c1 < 0) each(triAt(~n.c1));
+        const bool i0 = h0 && n.c0 >= 0, i1 = h1 && n.c1 >= 0;
+        if (i0 && i1) { stk.push(sp, n.c1); node = n.c0; }
+        else if (i0) node = n.c0;
+        else if (i1) node = n.c1;
+        else {
+            if (sp == 0) break;
+            node = stk.pop(sp);
+        }
+    }
+}
+
 } // namespace dxv

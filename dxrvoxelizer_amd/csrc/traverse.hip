@@ -77,6 +77,128 @@ __global__ __launch_bounds__(B::threads, 8) void k_voxelize(VoxelizeParams p)   
     p.grid[id] = occ;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Parity mode, row kernel: one wavefront per run of 64*CH voxels of one grid row.  The tree walk
+// is wave-uniform (it depends on the row and the run's left end only): node and triangle records
+// arrive through the scalar cache into SGPRs, the stack is one LDS column per wave, branches are
+// scalar.  Lanes only diverge in data: lane l owns voxels x0 + 64 c + l (c < CH) and evaluates
+// parity_row_voxel for them.  Same per-voxel results as k_voxelize<..., MODE 1> (tests), an
+// order of magnitude fewer node visits.
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ TriPos load_tri_scalar(const TriPos* tris, int32_t uniformLeaf)
+{
+    const char* p = reinterpret_cast<const char*>(tris) + (uint64_t)(uint32_t)uniformLeaf * 48u;
+    uint64_t w0, w1, w2, w3, w4, w5;
+    asm volatile("s_load_dwordx2 %0, %6, 0x0\n\ts_load_dwordx2 %1, %6, 0x8\n\ts_load_dwordx2 %2, %6, 0x10\n\t"
+                 "s_load_dwordx2 %3, %6, 0x18\n\ts_load_dwordx2 %4, %6, 0x20\n\ts_load_dwordx2 %5, %6, 0x28\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3), "=&s"(w4), "=&s"(w5) : "s"(p) : "memory");
+    auto lo = [](uint64_t v) { return __builtin_bit_cast(float, (uint32_t)v); };
+    auto hi = [](uint64_t v) { return __builtin_bit_cast(float, (uint32_t)(v >> 32)); };
+    TriPos t;
+    t.v0 = F4{lo(w0), hi(w0), lo(w1), hi(w1)};
+    t.v1 = F4{lo(w2), hi(w2), lo(w3), hi(w3)};
+    t.v2 = F4{lo(w4), hi(w4), lo(w5), hi(w5)};
+    return t;
+}
+
+struct WaveStack {
+    int32_t* base;   // LDS, one column per wave
+    __device__ __forceinline__ void push(int& sp, int32_t v) { base[sp++] = v; }
+    __device__ __forceinline__ int32_t pop(int& sp) { return __builtin_amdgcn_readfirstlane(base[--sp]); }
+};
+#endif
+
+template <int CH>
+__global__ __launch_bounds__(64) void k_parity_rows(VoxelizeParams p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the stub: the body uses SGPR inline asm)
+    __shared__ int32_t stack[64];
+    const uint32_t N = p.N;
+    const uint32_t segLen = 64u * CH, nseg = (N + segLen - 1) / segLen;
+    const uint32_t nrows = N * p.nz, nwaves = nrows * nseg;
+    const uint32_t rb = p.regionBits;
+    const uint32_t j = blockIdx.x >> 3;
+    const uint32_t lin = ((((j >> rb) << 3) | (blockIdx.x & 7u)) << rb) | (j & ((1u << rb) - 1u));
+    if (lin >= nwaves) return;
+    const uint32_t seg = lin % nseg;
+    uint32_t row = lin / nseg, iy, lz;
+    if (!(N & 7u) && !(p.nz & 7u)) {                   // 8x8 tiles of rows: neighbours share tree paths
+        const uint32_t tile = row >> 6, in = row & 63u, tx = N >> 3;
+        iy = (tile % tx) * 8u + (in & 7u);
+        lz = (tile / tx) * 8u + (in >> 3);
+    } else { iy = row % N; lz = row / N; }
+    const uint32_t iz = p.z0 + (lz / p.zBlock) * p.zPeriod + lz % p.zBlock;
+    const uint32_t lane = threadIdx.x, x0 = seg * segLen;
+
+    float oxMin, oy, oz;
+    ray_origin(N, x0, iy, iz, oxMin, oy, oz);
+    float ox[CH];
+    uint32_t count[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        float ty, tz;
+        ray_origin(N, x0 + 64u * c + lane, iy, iz, ox[c], ty, tz);
+        count[c] = 0;
+    }
+    const SceneView& sc = p.scene;
+    if (sc.rootLo[1] <= oy && oy <= sc.rootHi[1] && sc.rootLo[2] <= oz && oz <= sc.rootHi[2] && sc.rootHi[0] >= oxMin) {
+        WaveStack stk{stack};
+        walk_parity_row(
+            oy, oz, oxMin,
+            [&](int32_t i) {
+                const NodeSgpr n = load_node_scalar(sc.nodes, i);
+                NodePlanes q;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) q.b[k] = sgpr_half(n.w[k >> 2], k & 3);
+                q.c0 = (int32_t)(uint32_t)n.w[3];
+                q.c1 = (int32_t)(uint32_t)(n.w[3] >> 32);
+                return q;
+            },
+            [&](int32_t leaf) { return load_tri_scalar(sc.triPos, leaf); }, stk,
+            [&](const TriPos& tp) {
+                const ParityRowTri s = parity_row_setup(oy, oz, tp.v0, tp.v1, tp.v2);
+                if (s.hit) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) count[c] += parity_row_voxel(s, ox[c]) ? 1u : 0u;
+                }
+            });
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const uint32_t ix = x0 + 64u * c + lane;
+        if (ix < N) p.grid[((size_t)lz * N + iy) * N + ix] = (uint8_t)(count[c] & 1u);
+    }
+#else
+    (void)p;
+#endif
+}
+
+template <int CH>
+static hipError_t launch_parity_rows_ch(const VoxelizeParams& pin, hipStream_t s)
+{
+    VoxelizeParams p = pin;
+    const uint32_t segLen = 64u * CH, nseg = (p.N + segLen - 1) / segLen;
+    const uint64_t nwaves = (uint64_t)p.N * p.nz * nseg;
+    uint32_t rb = p.regionBits;
+    while (rb > 0 && (8ull << rb) > nwaves) --rb;
+    p.regionBits = rb;
+    const uint64_t span = 8ull << rb;
+    const uint64_t grid = (nwaves + span - 1) / span * span;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    k_parity_rows<CH><<<dim3((uint32_t)grid), dim3(64), 0, s>>>(p);
+    return hipGetLastError();
+}
+
+hipError_t launch_parity_rows(const VoxelizeParams& p, hipStream_t s)
+{
+    if (p.N <= 64) return launch_parity_rows_ch<1>(p, s);
+    if (p.N <= 128) return launch_parity_rows_ch<2>(p, s);
+    if (p.N <= 256) return launch_parity_rows_ch<4>(p, s);
+    return launch_parity_rows_ch<8>(p, s);              // 512 voxels per wave; longer rows take several waves
+}
+
 // brick shapes: (x, y, z) voxels per workgroup; a wavefront owns 64 consecutive threads of it
 using Brick0 = Brick<64, 4, 1>;    // 256 threads, wave = 64x1x1 row
 using Brick1 = Brick<8, 8, 4>;     // 256 threads, wave = 8x8x1 tile

@@ -121,6 +121,29 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
                                                          uint8_t* out, uint32_t* texels)
 {
     HcScene* s = static_cast<HcScene*>(p);
+    if (mode == 4) {   // parity, row form (what k_parity_rows computes), one walk per row
+        SceneView scr{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
+        for (int a = 0; a < 3; ++a) { scr.rootLo[a] = min_(w[a], w[6 + a]); scr.rootHi[a] = max_(w[3 + a], w[9 + a]); }
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int64_t row = 0; row < (int64_t)nz * N; ++row) {
+            const uint32_t lz = (uint32_t)(row / N), iy = (uint32_t)(row % N), iz = z0 + lz;
+            std::vector<float> ox(N);
+            std::vector<uint32_t> cnt(N, 0);
+            float oy = 0, oz = 0;
+            for (uint32_t ix = 0; ix < N; ++ix) ray_origin(N, ix, iy, iz, ox[ix], oy, oz);
+            struct HostStack { int32_t e[128]; void push(int& sp, int32_t v) { e[sp++] = v; } int32_t pop(int& sp) { return e[--sp]; } } stk;
+            if (scr.rootLo[1] <= oy && oy <= scr.rootHi[1] && scr.rootLo[2] <= oz && oz <= scr.rootHi[2] && scr.rootHi[0] >= ox[0])
+                walk_parity_row(oy, oz, ox[0], [&](int32_t i) { return load_node(scr.nodes, i); },
+                                [&](int32_t leaf) { return load_tri(scr.triPos, leaf); }, stk,
+                                [&](const TriPos& tp) {
+                                    const ParityRowTri ps = parity_row_setup(oy, oz, tp.v0, tp.v1, tp.v2);
+                                    if (ps.hit) for (uint32_t ix = 0; ix < N; ++ix) cnt[ix] += parity_row_voxel(ps, ox[ix]) ? 1u : 0u;
+                                });
+            for (uint32_t ix = 0; ix < N; ++ix) out[((size_t)lz * N + iy) * N + ix] = (uint8_t)(cnt[ix] & 1u);
+        }
+        return 0;
+    }
     int overflow = 0;
     SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
     {   // root box = union of the root node's two child boxes (as k_root_info computes it)

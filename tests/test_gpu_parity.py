@@ -163,6 +163,22 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
     vox.set_option("morton", 1)
     vox.set_option("region", 6)
     vox.set_option("queue", 1)
+    # parity mode: row kernel (default) and the per-voxel kernels, whole grids and ragged slabs
+    pwant = orc.Scene(vb, ib).voxelize(64, mode=1)
+    for rows, queue, brick in ((1, 1, 4), (0, 1, 4), (0, 0, 1), (0, 1, 0)):
+        vox.set_option("rows", rows)
+        vox.set_option("queue", queue)
+        vox.set_option("brick", brick)
+        vox.Voxelize(64, 1)
+        assert np.array_equal(vox.Grid(), pwant), (rows, queue, brick)
+        vox.Voxelize(64, 1, 13, 9)
+        assert np.array_equal(vox.Grid(), pwant[13:22]), (rows, queue, brick)
+    vox.set_option("rows", 1)
+    vox.set_option("queue", 1)
+    vox.set_option("brick", 4)
+    for n in (2, 6, 30, 66, 130, 258):
+        vox.Voxelize(n, 1)
+        assert np.array_equal(vox.Grid(), orc.Scene(vb, ib).voxelize(n, mode=1)), n
     for n in (2, 6, 30, 66):                 # grids that do not fill whole bricks
         vox.set_option("brick", 1)
         vox.set_option("stack", 0)

@@ -37,8 +37,8 @@ def test_host_lbvh_equals_oracle_assets(orc, hostcheck, request, name):
     keys = h.keys()
     assert np.all(keys[1:] > keys[:-1])
     assert 1 <= h.height <= 62
-    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2), (64, 3)):   # host modes 2/3 = postponed-leaf walks
-        g, ovf = h.voxelize(N, mode, stack=h.height + 3)
+    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2), (64, 3), (64, 5)):   # 2/3 = postponed-leaf walks, 5 (-> 4) = parity rows
+        g, ovf = h.voxelize(N, 4 if mode == 5 else mode, stack=h.height + 3)
         assert not ovf
         assert np.array_equal(g, s.voxelize(N, mode=mode % 2))
 
@@ -59,9 +59,9 @@ def test_host_lbvh_equals_oracle_brute_synthetic(orc, hostcheck, gen, args):
     s = orc.Scene(vb, ib)
     h = hostcheck(vb, ib, s.bound)
     check_tree(h.nodes(), h.T)
-    modes = (0, 2) if gen == "soup" else (0, 1, 2, 3)
+    modes = (0, 2) if gen == "soup" else (0, 1, 2, 3, 5)
     for mode in modes:
-        g, ovf = h.voxelize(16, mode)
+        g, ovf = h.voxelize(16, 4 if mode == 5 else mode)
         assert not ovf
         assert np.array_equal(g, s.voxelize(16, mode=mode % 2, algo=orc.ALGO_BRUTE))
 
