@@ -165,6 +165,15 @@ def main():
     vox.Sync()                                   # deferred kernel status (stack overflow) is an error
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)   # avg launch duration on the kernel's stream
     solid = vox.CountSolid() if nz else 0
+    other_ms = None
+    if world == 1:                               # the second occupancy rule on the same scene, for the record
+        om = dxv.MODE_PARITY if mode == dxv.MODE_REFERENCE else dxv.MODE_REFERENCE
+        vox.Voxelize(N, om)
+        ts = []
+        for _ in range(5):
+            vox.Voxelize(N, om)
+            ts.append(vox.stats()["voxelize_ms"])
+        other_ms = float(np.median(ts))
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(solid)], dtype=torch.float64, device="cuda")
@@ -204,7 +213,10 @@ def main():
                        "build_ms": st0["build_ms"], "build_stages_ms": {k: st0[k] for k in
                                                                        ("prep_ms", "sort_ms", "hierarchy_ms", "refit_ms")},
                        "upload_ms": st0["upload_ms"], "scene_broadcast_ms": bcast_ms,
-                       "kernel_ms_max_over_ranks": float(kmax.item())},
+                       "kernel_ms_max_over_ranks": float(kmax.item()),
+                       "other_rule": None if other_ms is None else {
+                           "mode": "parity" if args.mode == "reference" else "reference", "ms": other_ms,
+                           "mvoxels_s": N ** 3 / other_ms / 1e3}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_voxelize", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_launch,

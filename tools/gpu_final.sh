@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round evidence run: tests, smoke, configs 2-5, bench line, rocprof kernel stats of the bench command,
+# PMC passes, CPU baseline table, build timings.  Everything lands in gpurun_out/final/.
+cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/final
+rm -rf $OUT; mkdir -p $OUT
+(time python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider) > $OUT/pytest_gpu.log 2>&1
+python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
+python tools/configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 10 --warmup 2 --interleave --no-cpu-baseline > $OUT/bench_torchrun_world1.log 2>&1
+python tools/build_bench.py bunny torus1m soup10m > $OUT/build.jsonl 2>&1
+python tools/cpu_baseline.py > $OUT/cpu_baseline.jsonl 2>&1
+python tools/sweep.py --meshes torus1m,bunny,dragon --grids 256,512 --bricks 4 --stacks 0 --modes reference,parity --reps 5 > $OUT/sweep.jsonl 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/prof_bench.log 2>&1
+R=$GRAFT_REPO_ROOT/tools/run_once.py
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq1 -- python3 $R torus1m 512 3 > $OUT/pmc_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_sq2 -- python3 $R torus1m 512 3 > $OUT/pmc_sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R torus1m 512 3 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R torus1m 512 3 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $R torus1m 512 3 > $OUT/pmc_tcc.log 2>&1
+rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcp -- python3 $R torus1m 512 3 > $OUT/pmc_tcp.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_parity -- python3 $R torus1m 512 3 parity > $OUT/pmc_fetch_parity.log 2>&1
+exit 0
