@@ -171,6 +171,8 @@ int launch_now(dxv_ctx* c)
     p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
     p.N = c->stats.grid_dim; p.z0 = c->stats.z0; p.nz = c->stats.nz; p.mode = c->lastMode;
     p.zBlock = c->lastZBlock; p.zPeriod = c->lastZPeriod;
+    p.zShift = 0;
+    while ((1u << p.zShift) < p.zBlock) ++p.zShift;
     p.morton = (uint32_t)c->optMorton;
     p.regionBits = (uint32_t)c->optRegion;
     p.queued = (uint32_t)c->optQueue;
@@ -411,8 +413,9 @@ int dxv_voxelize_interleaved_async(dxv_ctx* c, uint32_t N, int mode, uint32_t ra
 {
     if (!c) return 1;
     if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_voxelize: grid_dim must be even and in [2, 2048], got %u", N);
-    if (!world || rank >= world || !zblock || N % (zblock * world))
-        return fail(c, "dxv_voxelize_interleaved: need rank < world and grid_dim %% (zblock * world) == 0 (N=%u, world=%u, zblock=%u)", N, world, zblock);
+    if (!world || rank >= world || !zblock || (zblock & (zblock - 1u)) || N % (zblock * world))
+        return fail(c, "dxv_voxelize_interleaved: need rank < world, zblock a power of two and grid_dim %% (zblock * world) == 0 "
+                       "(N=%u, world=%u, zblock=%u)", N, world, zblock);
     return voxelize_common(c, N, mode, rank * zblock, N / world, zblock, zblock * world);
 }
 

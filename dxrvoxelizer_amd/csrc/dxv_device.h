@@ -42,6 +42,8 @@ struct VoxelizeParams {
     uint32_t* status;       // status word (bit 0: traversal stack overflow)
     uint32_t N, z0, nz;     // nz = slices written by this launch (local index lz in [0, nz))
     uint32_t zBlock, zPeriod; // global slice of lz: z0 + (lz / zBlock) * zPeriod + lz % zBlock
+    uint32_t zShift;          // log2(zBlock) when the partition is block-cyclic (zBlock is a power of two)
+    uint32_t superX, superY;  // brick super-blocks per axis (filled by the launcher)
     int mode;
     uint32_t morton;        // 1: Morton brick order (default), 0: linear x,y,z order
     uint32_t mortonBits;    // filled by the launcher

@@ -51,16 +51,20 @@ __global__ __launch_bounds__(B::threads, 8) void k_voxelize(VoxelizeParams p)   
     // cover a compact region and reuse the same part of the tree in L1/L2.
     const uint32_t m = p.mortonBits;
     const uint32_t low = lin & ((1u << (3u * m)) - 1u), high = lin >> (3u * m);
-    const uint32_t sx = nbx >> m, sy = nby >> m;
-    const uint32_t bx = ((high % sx) << m) | compact1by2(low);
-    const uint32_t by = (((high / sx) % sy) << m) | compact1by2(low >> 1);
-    const uint32_t bz = ((high / (sx * sy)) << m) | compact1by2(low >> 2);
+    uint32_t bx = compact1by2(low), by = compact1by2(low >> 1), bz = compact1by2(low >> 2);
+    if (p.superX == 1u && p.superY == 1u) bz |= high << m;      // usual case (cubic power-of-two grid): no divisions
+    else {
+        bx |= (high % p.superX) << m;
+        by |= ((high / p.superX) % p.superY) << m;
+        bz |= (high / (p.superX * p.superY)) << m;
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t ix = bx * B::x + tid % B::x;
     const uint32_t iy = by * B::y + (tid / B::x) % B::y;
     const uint32_t lz = bz * B::z + tid / (B::x * B::y);
     if (ix >= N || iy >= N || lz >= p.nz) return;
-    const uint32_t iz = p.z0 + (lz / p.zBlock) * p.zPeriod + lz % p.zBlock;
+    const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz                                    // contiguous slab
+                      : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));    // block-cyclic, zBlock = 2^zShift
     const size_t id = ((size_t)lz * N + iy) * N + ix;
 
     const StridedStack stk{stack + tid, B::threads};
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(64) void k_parity_rows(VoxelizeParams p)
         iy = (tile % tx) * 8u + (in & 7u);
         lz = (tile / tx) * 8u + (in >> 3);
     } else { iy = row % N; lz = row / N; }
-    const uint32_t iz = p.z0 + (lz / p.zBlock) * p.zPeriod + lz % p.zBlock;
+    const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
     const uint32_t lane = threadIdx.x, x0 = seg * segLen;
 
     float oxMin, oy, oz;
@@ -219,6 +223,8 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
     uint32_t m = 0;
     while (m < 10 && p.morton && !((nbx >> m) & 1u) && !((nby >> m) & 1u) && !((nbz >> m) & 1u)) ++m;
     p.mortonBits = m;
+    p.superX = nbx >> m;
+    p.superY = nby >> m;
     const uint64_t nb = (uint64_t)nbx * nby * nbz;
     uint32_t rb = p.regionBits;
     while (rb > 0 && (8ull << rb) > nb) --rb;          // small grids: keep all XCDs busy

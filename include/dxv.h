@@ -112,7 +112,8 @@ DXV_API int dxv_sync(dxv_ctx* ctx);
 /* Load-balanced multi-GPU partition: the grid's Z axis is cut into blocks of `zblock` slices dealt
  * round-robin to `world` ranks; this call voxelizes the grid_dim/world slices of `rank` (global
  * slice of local slice lz: (lz / zblock * world + rank) * zblock + lz % zblock, ascending) into a
- * compact grid_dim*grid_dim*(grid_dim/world)-byte grid.  Requires grid_dim % (zblock*world) == 0.
+ * compact grid_dim*grid_dim*(grid_dim/world)-byte grid.  Requires zblock to be a power of two and
+ * grid_dim % (zblock*world) == 0.
  * Contiguous slabs (dxv_voxelize with z0/nz) starve the GPUs that own empty space; see DESIGN.md. */
 DXV_API int dxv_voxelize_interleaved(dxv_ctx* ctx, uint32_t grid_dim, int mode, uint32_t rank, uint32_t world,
                                      uint32_t zblock);
