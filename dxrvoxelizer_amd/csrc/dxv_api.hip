@@ -66,6 +66,7 @@ struct dxv_ctx {
     int optRefit = 1;        // 1 = level-synchronous sweeps (default: 17-30x faster than the fence-bound one-pass climb), 0 = atomic one-pass
     int optMorton = 1;       // Morton brick order
     int optQueue = 1;        // postponed-leaf traversal
+    int optSubbox = 1;       // launch only the bricks around the scene's root box, memset the rest
     int optRows = 1;         // parity mode: one tree walk per grid row (k_parity_rows) instead of per voxel
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
     int optStack0 = 20;      // adaptive mode starts with this many entries (stack + leaf queue share them)
@@ -176,6 +177,7 @@ int launch_now(dxv_ctx* c)
     p.morton = (uint32_t)c->optMorton;
     p.regionBits = (uint32_t)c->optRegion;
     p.queued = (uint32_t)c->optQueue;
+    p.subbox = (uint32_t)c->optSubbox;
     const int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
@@ -562,6 +564,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "refit")) {
         if (value != 0 && value != 1) return fail(c, "option refit: %lld not in {0,1}", (long long)value);
         c->optRefit = (int)value;
+    } else if (!strcmp(key, "subbox")) {
+        if (value != 0 && value != 1) return fail(c, "option subbox: %lld not in {0,1}", (long long)value);
+        c->optSubbox = (int)value;
     } else if (!strcmp(key, "rows")) {
         if (value != 0 && value != 1) return fail(c, "option rows: %lld not in {0,1}", (long long)value);
         c->optRows = (int)value;

@@ -44,11 +44,14 @@ struct VoxelizeParams {
     uint32_t zBlock, zPeriod; // global slice of lz: z0 + (lz / zBlock) * zPeriod + lz % zBlock
     uint32_t zShift;          // log2(zBlock) when the partition is block-cyclic (zBlock is a power of two)
     uint32_t superX, superY;  // brick super-blocks per axis (filled by the launcher)
+    uint32_t nbx, nby, nbz;   // bricks launched per axis and their offset: only the part of the grid
+    uint32_t bx0, by0, bz0;   //   that the root early-out cannot clear (the rest is memset to 0)
     int mode;
     uint32_t morton;        // 1: Morton brick order (default), 0: linear x,y,z order
     uint32_t mortonBits;    // filled by the launcher
     uint32_t regionBits;    // log2 of the bricks per XCD region
     uint32_t queued;        // 1: postponed-leaf traversal (default), 0: leaves tested on the spot
+    uint32_t subbox;        // 1: launch only bricks the root early-out cannot clear (default)
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
 int stack_round_up(int want);

@@ -55,12 +55,16 @@ DXV_HD void ray_origin(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, float&
 // enter any box inside the root box: on that axis sign(d) == sign(o), so the exit distance
 // fma(hi, 1/d, -(o/d)) is negative for every box (margin 1e-5 >> the 2^-24 relative rounding of
 // o/d) and slab() fails for both children of the root.  Exact shortcut, not an approximation.
-DXV_HD bool origin_leaves_root(float ox, float oy, float oz, const float* rootLo, const float* rootHi)
+DXV_HD bool axis_leaves_root(float o, float lo, float hi)
 {
     const float m = 1e-5f;
-    return (ox > rootHi[0] + m && ox > 0.0f) || (ox < rootLo[0] - m && ox < 0.0f) ||
-           (oy > rootHi[1] + m && oy > 0.0f) || (oy < rootLo[1] - m && oy < 0.0f) ||
-           (oz > rootHi[2] + m && oz > 0.0f) || (oz < rootLo[2] - m && oz < 0.0f);
+    return (o > hi + m && o > 0.0f) || (o < lo - m && o < 0.0f);
+}
+
+DXV_HD bool origin_leaves_root(float ox, float oy, float oz, const float* rootLo, const float* rootHi)
+{
+    return axis_leaves_root(ox, rootLo[0], rootHi[0]) || axis_leaves_root(oy, rootLo[1], rootHi[1]) ||
+           axis_leaves_root(oz, rootLo[2], rootHi[2]);
 }
 
 DXV_HD void ray_shear(Ray& r)

@@ -152,14 +152,17 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
     vox.InitFromArrays(vb, ib)
     want = orc.Scene(vb, ib).voxelize(64)
     for brick in range(8):
-        for stack, morton, region, queue in ((0, 1, 9, 1), (32, 0, 0, 0), (64, 1, 3, 1), (0, 0, 20, 0), (48, 1, 24, 1)):
+        for stack, morton, region, queue, subbox in ((0, 1, 9, 1, 1), (32, 0, 0, 0, 0), (64, 1, 3, 1, 0), (0, 0, 20, 0, 1),
+                                                     (48, 1, 24, 1, 1)):
             vox.set_option("brick", brick)
             vox.set_option("stack", stack)
             vox.set_option("morton", morton)
             vox.set_option("region", region)
             vox.set_option("queue", queue)
+            vox.set_option("subbox", subbox)
             vox.Voxelize(64)
-            assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region, queue)
+            assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region, queue, subbox)
+    vox.set_option("subbox", 1)
     vox.set_option("morton", 1)
     vox.set_option("region", 6)
     vox.set_option("queue", 1)
@@ -251,6 +254,35 @@ def test_refit_after_vertex_update_equals_rebuild(dxv, orc, bunny):
     with pytest.raises(dxv.DxvError):
         v.UpdateVertices(vb1[:-1])                           # vertex count must not change
     v.close(), fresh.close()
+
+
+def test_thin_and_offcentre_scenes_with_subbox_launch(vox, orc):
+    """Only the bricks around the scene's root box are launched (the rest is memset): flat, thin,
+    off-centre scenes, slabs and the block-cyclic partition must still give the oracle's grids."""
+    from dxrvoxelizer_amd.slabs import interleaved_slices
+    base_vb, ib = meshes.uv_sphere(24, 12, 1.0)
+    for scale, shift in (((1.0, 0.05, 1.0), (0, 0, 0)), ((0.03, 1.0, 0.4), (0, 0, 0)), ((0.3, 0.3, 0.3), (2.0, -1.0, 0.5))):
+        vb = base_vb.copy()
+        vb[:, :3] = vb[:, :3] * np.float32(scale) + np.float32(shift)
+        if any(shift):                                            # an unreferenced far vertex moves the bound centre
+            vb = np.concatenate([vb, np.zeros((1, 6), np.float32)])
+        vox.InitFromArrays(vb, ib)
+        s = orc.Scene(vb, ib)
+        for mode in (0, 1):
+            want = s.voxelize(64, mode=mode)
+            for rows in ((1,) if mode == 0 else (0, 1)):
+                vox.set_option("rows", rows)
+                vox.Voxelize(64, mode)
+                assert np.array_equal(vox.Grid(), want), (scale, shift, mode, rows)
+                vox.Voxelize(64, mode, 20, 30)
+                assert np.array_equal(vox.Grid(), want[20:50])
+                vox.VoxelizeInterleaved(64, 1, 4, 4, mode)
+                assert np.array_equal(vox.Grid(), want[interleaved_slices(64, 1, 4, 4)])
+        vox.set_option("rows", 1)
+        vox.EnableTexels(True)
+        vox.Voxelize(64)
+        assert np.array_equal(vox.Texels(), s.voxelize(64, texels=True)[1])
+        vox.EnableTexels(False)
 
 
 def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
