@@ -22,7 +22,7 @@ class Stats(C.Structure):
                 ("prep_ms", C.c_float), ("sort_ms", C.c_float), ("hierarchy_ms", C.c_float),
                 ("refit_ms", C.c_float), ("build_ms", C.c_float), ("voxelize_ms", C.c_float),
                 ("grid_dim", C.c_uint32), ("z0", C.c_uint32), ("nz", C.c_uint32),
-                ("stack_entries", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+                ("stack_entries", C.c_uint32), ("render_ms", C.c_float), ("reserved", C.c_uint32 * 6)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("bound", "reserved")}
@@ -56,6 +56,7 @@ SYMBOLS = {
     "dxv_grid_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "dxv_enable_texels": (C.c_int, [C.c_void_p, C.c_int]),
     "dxv_texels_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dxv_render": (C.c_int, [C.c_void_p, _F32P, _F32P, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "dxv_scene_bytes": (C.c_size_t, [C.c_void_p]),
     "dxv_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dxv_scene_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

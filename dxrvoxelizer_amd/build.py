@@ -16,8 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libdxv.so")
 
-SOURCES = ["dxv_api.hip", "lbvh.hip", "radix_sort.hip", "traverse.hip", "obj_ingest.cpp"]
-HEADERS = ["dxv_device.h", "dxv_math.h", "dxv_trace.h", "dxv_types.h", os.path.join("..", "..", "include", "dxv.h")]
+SOURCES = ["dxv_api.hip", "lbvh.hip", "radix_sort.hip", "traverse.hip", "raycast.hip", "obj_ingest.cpp"]
+HEADERS = ["dxv_device.h", "dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_raycast.h", os.path.join("..", "..", "include", "dxv.h")]
 
 # -ffp-contract=off: the arithmetic of the path has a fixed operation order; the only fused
 # operations are the explicit fmaf calls in dxv_math.h (hipcc contracts by default).
@@ -55,7 +55,7 @@ def build(force=False, save_temps=False, verbose=False):
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     extra = ["-save-temps=obj"] if save_temps else []
-    with cf.ThreadPoolExecutor(max_workers=min(5, os.cpu_count() or 1)) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         results = list(ex.map(lambda s: _compile(s, extra), SOURCES))
     for _, err in results:
         if verbose and err.strip():

@@ -3,6 +3,7 @@
 // without a HIP device dxv_create fails.
 #include "../../include/dxv.h"
 #include "dxv_device.h"
+#include "dxv_raycast.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -56,6 +57,9 @@ struct dxv_ctx {
     bool texels = false;
     uint32_t* dStatus = nullptr;
     unsigned long long* dCount = nullptr;
+    uint32_t* dImage = nullptr;
+    size_t imageCap = 0;
+    float renderMs = 0.0f;
 
     hipEvent_t ev[10] = {};
     dxv_stats stats{};
@@ -229,6 +233,7 @@ void dxv_destroy(dxv_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     free_scratch(c);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene); (void)hipFree(c->dGrid);
+    (void)hipFree(c->dImage);
     (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dCount); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -456,6 +461,38 @@ int dxv_voxelize(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nz)
 {
     if (dxv_voxelize_async(c, N, mode, z0, nz)) return 1;
     return dxv_sync(c);
+}
+
+int dxv_render(dxv_ctx* c, const float eye[3], const float viewProj[16], const float posScale[4], uint32_t width,
+               uint32_t height, uint8_t* rgbaHost)
+{
+    if (!c) return 1;
+    if (!eye || !viewProj || !rgbaHost || !width || !height || width > 16384 || height > 16384)
+        return fail(c, "dxv_render: bad arguments");
+    const uint32_t N = c->stats.grid_dim;
+    if (!c->dGrid || !N || c->stats.z0 != 0 || c->stats.nz != N || c->lastZBlock != N)
+        return fail(c, "dxv_render: needs the whole grid of the last dxv_voxelize (z0 = 0, nz = grid_dim) on this context");
+    const float unit[4] = {0.0f, 0.0f, 0.0f, 1.0f};                 // DXRVoxelizer.cpp:37
+    RayCastCB cb;
+    if (!update_frame(c->bound, posScale ? posScale : unit, eye, viewProj, (float)width, (float)height, cb))
+        return fail(c, "dxv_render: singular view/projection chain");
+    DXV_HIP(c, hipSetDevice(c->device));
+    const size_t pixels = (size_t)width * height;
+    if (pixels > c->imageCap) {
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dImage); c->dImage = nullptr; c->imageCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dImage, pixels * 4));
+        c->imageCap = pixels;
+    }
+    if (dxv_sync(c)) return 1;                                       // the grid must be complete and valid
+    DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
+    DXV_HIP(c, launch_raycast(cb, c->dGrid, N, width, height, c->dImage, c->stream));
+    DXV_HIP(c, hipEventRecord(c->ev[9], c->stream));
+    DXV_HIP(c, hipMemcpyAsync(rgbaHost, c->dImage, pixels * 4, hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    c->renderMs = elapsed(c->ev[8], c->ev[9]);
+    c->stats.render_ms = c->renderMs;
+    return 0;
 }
 
 void* dxv_grid_device_ptr(dxv_ctx* c) { return c ? c->dGrid : nullptr; }

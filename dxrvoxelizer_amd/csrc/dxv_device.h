@@ -59,4 +59,9 @@ hipError_t launch_parity_rows(const VoxelizeParams& p, hipStream_t s);   // pari
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
 int num_brick_shapes();
 
+// raycast.hip
+struct RayCastCB;
+hipError_t launch_raycast(const RayCastCB& cb, const uint8_t* grid, uint32_t N, uint32_t width, uint32_t height,
+                          uint32_t* rgba8, hipStream_t s);
+
 } // namespace dxv

@@ -100,6 +100,16 @@ class Voxelizer:
     def Sync(self):
         self._check(self._lib.dxv_sync(self._ctx))
 
+    # ---- the grid's consumer (Voxelizer::UpdateFrame + Render's ray-cast pass) -----------------
+    def Render(self, eyePt, viewProj, width=1280, height=720, posScale=None):
+        """uint8 [height, width, 4] R8G8B8A8 image of the last full grid (dxv_render)."""
+        eye = np.ascontiguousarray(eyePt, np.float32).reshape(3)
+        vp = np.ascontiguousarray(viewProj, np.float32).reshape(16)
+        ps = None if posScale is None else np.ascontiguousarray(posScale, np.float32).ctypes.data_as(C.c_void_p)
+        out = np.empty((int(height), int(width), 4), np.uint8)
+        self._check(self._lib.dxv_render(self._ctx, eye, vp, ps, int(width), int(height), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # ---- results ----------------------------------------------------------------------------
     def Grid(self):
         """uint8 [nz, N, N] (z, y top->bottom, x) copy of the device grid."""

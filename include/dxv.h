@@ -51,7 +51,8 @@ typedef struct dxv_stats {
     float voxelize_ms;       /* last dxv_voxelize kernel, HIP events on the ctx stream         */
     uint32_t grid_dim, z0, nz; /* last dxv_voxelize                                            */
     uint32_t stack_entries;  /* LDS traversal stack entries per thread of the last launch      */
-    uint32_t reserved[7];
+    float render_ms;         /* last dxv_render kernel, HIP events                                  */
+    uint32_t reserved[6];
 } dxv_stats;
 
 /* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that
@@ -133,6 +134,15 @@ DXV_API int dxv_grid_count(dxv_ctx* ctx, uint64_t* solid);
  * (0 where the shader writes nothing).  Reference mode only. */
 DXV_API int dxv_enable_texels(dxv_ctx* ctx, int enable);
 DXV_API int dxv_texels_download(dxv_ctx* ctx, uint32_t* host, size_t bytes);
+
+/* The grid's consumer, for visual A/B against the reference: Voxelizer::UpdateFrame + renderRayCast
+ * (Content/Voxelizer.cpp:81-106, :371-399; Shaders/VSScreenQuad.hlsl + PSRayCast.hlsl: 128-step
+ * march through the grid's alpha with a 32-step light march).  eye and view_proj (row-major, row
+ * vectors: v' = v * M, as DirectXMath stores them) are what the app passes to UpdateFrame
+ * (DXRVoxelizer.cpp:249-254); pos_scale = {x, y, z, scale} or NULL for the default {0,0,0,1}.
+ * Renders the whole grid of the last dxv_voxelize into width*height R8G8B8A8 texels on the host. */
+DXV_API int dxv_render(dxv_ctx* ctx, const float eye[3], const float view_proj[16], const float pos_scale[4],
+                       uint32_t width, uint32_t height, uint8_t* rgba_host);
 
 /* Multi-GPU: the built scene (nodes + triangle data) as one relocatable device blob, so that
  * rank 0 builds once and the host layer broadcasts it (RCCL over xGMI) to the other ranks.

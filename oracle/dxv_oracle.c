@@ -795,6 +795,175 @@ ORC_API int orc_voxelize_slices(const orc_scene* s, uint32_t N, int mode, int al
     return 0;
 }
 
+/* ==========================================================================================
+ * N3 -- the grid's consumer (display pass).  Restates Content/Shaders/PSRayCast.hlsl:61-187 with
+ * the constants Voxelizer::UpdateFrame builds (Content/Voxelizer.cpp:81-106).  float32 in place
+ * of min16float, float trilinear CLAMP sampling of alpha.  Matrices: row-major, row vectors
+ * (v' = v * M), the DirectXMath convention of the reference.
+ * ======================================================================================== */
+typedef struct { float light[3], eye[3], s2l[16]; } orc_cb;
+
+static void m4_mul(const float* a, const float* b, float* o)
+{
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c)
+        o[4 * r + c] = ((a[4 * r] * b[c] + a[4 * r + 1] * b[4 + c]) + a[4 * r + 2] * b[8 + c]) + a[4 * r + 3] * b[12 + c];
+}
+
+static int m4_inv(const float* m, float* o)   /* Gauss-Jordan in double */
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { a[r][c] = m[4 * r + c]; a[r][4 + c] = r == c; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+        if (a[piv][col] == 0.0) return 0;
+        for (int c = 0; c < 8; ++c) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+        const double d = a[col][col];
+        for (int c = 0; c < 8; ++c) a[col][c] /= d;
+        for (int r = 0; r < 4; ++r) if (r != col) { const double f = a[r][col]; for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c]; }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) o[4 * r + c] = (float)a[r][4 + c];
+    return 1;
+}
+
+static void m4_coord(const float* p, const float* m, float* o)
+{
+    const float x = ((p[0] * m[0] + p[1] * m[4]) + p[2] * m[8]) + m[12], y = ((p[0] * m[1] + p[1] * m[5]) + p[2] * m[9]) + m[13];
+    const float z = ((p[0] * m[2] + p[1] * m[6]) + p[2] * m[10]) + m[14], w = ((p[0] * m[3] + p[1] * m[7]) + p[2] * m[11]) + m[15];
+    o[0] = x / w; o[1] = y / w; o[2] = z / w;
+}
+
+/* Voxelizer::UpdateFrame, Content/Voxelizer.cpp:81-106 */
+ORC_API int orc_update_frame(const float bound[4], const float ps[4], const float eye[3], const float vp[16], float w, float h,
+                             float light_out[3], float eye_out[3], float s2l_out[16])
+{
+    float S1[16] = {0}, T1[16] = {0}, S2[16] = {0}, T2[16] = {0}, a[16], b[16], world[16], worldI[16], wvp[16], ts[16] = {0}, l2s[16];
+    S1[0] = S1[5] = S1[10] = bound[3]; S1[15] = 1;
+    T1[0] = T1[5] = T1[10] = T1[15] = 1; T1[12] = bound[0]; T1[13] = bound[1]; T1[14] = bound[2];
+    S2[0] = S2[5] = S2[10] = ps[3]; S2[15] = 1;
+    T2[0] = T2[5] = T2[10] = T2[15] = 1; T2[12] = ps[0]; T2[13] = ps[1]; T2[14] = ps[2];
+    m4_mul(S1, T1, a); m4_mul(a, S2, b); m4_mul(b, T2, world);
+    if (!m4_inv(world, worldI)) return 1;
+    m4_mul(world, vp, wvp);
+    const float lp[3] = {-10.0f, 45.0f, -75.0f};
+    m4_coord(lp, worldI, light_out);
+    m4_coord(eye, worldI, eye_out);
+    ts[0] = 0.5f * w; ts[5] = -0.5f * h; ts[10] = 1.0f; ts[12] = 0.5f * w; ts[13] = 0.5f * h; ts[15] = 1.0f;
+    m4_mul(wvp, ts, l2s);
+    return m4_inv(l2s, s2l_out) ? 0 : 1;
+}
+
+static float tex_alpha(const uint8_t* g, uint32_t N, float tx, float ty, float tz)
+{
+    const float fn = (float)N;
+    const float u[3] = {tx * fn - 0.5f, ty * fn - 0.5f, tz * fn - 0.5f};
+    int i0[3], i1[3];
+    float w[3];
+    for (int a = 0; a < 3; ++a) {
+        const float f = floorf(u[a]);
+        w[a] = u[a] - f;
+        int lo = (int)f, hi = (int)(f + 1.0f);
+        if (lo < 0) lo = 0;
+        if (lo > (int)N - 1) lo = (int)N - 1;
+        if (hi < 0) hi = 0;
+        if (hi > (int)N - 1) hi = (int)N - 1;
+        i0[a] = lo; i1[a] = hi;
+    }
+#define G(x, y, z) (g[((size_t)(z) * N + (y)) * N + (x)] ? 1.0f : 0.0f)
+    const float c00 = G(i0[0], i0[1], i0[2]) + w[0] * (G(i1[0], i0[1], i0[2]) - G(i0[0], i0[1], i0[2]));
+    const float c10 = G(i0[0], i1[1], i0[2]) + w[0] * (G(i1[0], i1[1], i0[2]) - G(i0[0], i1[1], i0[2]));
+    const float c01 = G(i0[0], i0[1], i1[2]) + w[0] * (G(i1[0], i0[1], i1[2]) - G(i0[0], i0[1], i1[2]));
+    const float c11 = G(i0[0], i1[1], i1[2]) + w[0] * (G(i1[0], i1[1], i1[2]) - G(i0[0], i1[1], i1[2]));
+#undef G
+    const float c0 = c00 + w[1] * (c10 - c00), c1 = c01 + w[1] * (c11 - c01);
+    return c0 + w[2] * (c1 - c0);
+}
+
+static float density_at(const uint8_t* g, uint32_t N, const float* p)   /* PSRayCast.hlsl:104-113, :137 */
+{
+    const float d = tex_alpha(g, N, 0.5f * p[0] + 0.5f, -0.5f * p[1] + 0.5f, 0.5f * p[2] + 0.5f);
+    return fminf(d * 8.0f, 16.0f);
+}
+
+static void shade_pixel(const orc_cb* cb, const uint8_t* g, uint32_t N, float sx, float sy, float* rgba)
+{
+    static const float clear[3] = {0.0f, 0.2f, 0.4f};
+    const float maxDist = 2.0f * sqrtf(3.0f), stepScale = maxDist / 128.0f, lightScale = maxDist / 32.0f;
+    const float* m = cb->s2l;
+    const float hx = (sx * m[0] + sy * m[4]) + m[12], hy = (sx * m[1] + sy * m[5]) + m[13];
+    const float hz = (sx * m[2] + sy * m[6]) + m[14], hw = (sx * m[3] + sy * m[7]) + m[15];
+    float pos[3] = {hx / hw, hy / hw, hz / hw}, dir[3];
+    for (int a = 0; a < 3; ++a) dir[a] = pos[a] - cb->eye[a];
+    const float dl = sqrtf((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+    for (int a = 0; a < 3; ++a) dir[a] /= dl;
+    if (!(fabsf(pos[0]) <= 1.0f && fabsf(pos[1]) <= 1.0f && fabsf(pos[2]) <= 1.0f)) {      /* ComputeStartPoint */
+        float U = 3.402823466e+38f;
+        int hit = 0;
+        for (int i = 0; i < 3; ++i) {
+            const float sg = dir[i] > 0.0f ? 1.0f : (dir[i] < 0.0f ? -1.0f : 0.0f);
+            const float u = (-sg - pos[i]) / dir[i];
+            if (u < 0.0f) continue;
+            const int j = (i + 1) % 3, k = (i + 2) % 3;
+            if (fabsf(dir[j] * u + pos[j]) > 1.0f) continue;
+            if (fabsf(dir[k] * u + pos[k]) > 1.0f) continue;
+            if (u < U) { U = u; hit = 1; }
+        }
+        for (int a = 0; a < 3; ++a) pos[a] = fminf(fmaxf(dir[a] * U + pos[a], -1.0f), 1.0f);
+        if (!hit) { rgba[0] = clear[0]; rgba[1] = clear[1]; rgba[2] = clear[2]; rgba[3] = 0.0f; return; }
+    }
+    float step[3], ls[3];
+    const float ll = sqrtf((cb->light[0] * cb->light[0] + cb->light[1] * cb->light[1]) + cb->light[2] * cb->light[2]);
+    for (int a = 0; a < 3; ++a) { step[a] = dir[a] * stepScale; ls[a] = cb->light[a] / ll * lightScale; }
+    float transmit = 1.0f, scatter = 0.0f;
+    for (int i = 0; i < 128; ++i) {
+        if (fabsf(pos[0]) > 1.0f || fabsf(pos[1]) > 1.0f || fabsf(pos[2]) > 1.0f) break;
+        const float dens = density_at(g, N, pos);
+        if (dens > 0.01f) {
+            const float sd = dens * stepScale;
+            transmit *= fminf(fmaxf(1.0f - sd * 1.0f, 0.0f), 1.0f);
+            if (transmit < 0.01f) break;
+            float lt = 1.0f, lp[3] = {pos[0] + ls[0], pos[1] + ls[1], pos[2] + ls[2]};
+            for (int j = 0; j < 32; ++j) {
+                if (fabsf(lp[0]) > 1.0f || fabsf(lp[1]) > 1.0f || fabsf(lp[2]) > 1.0f) break;
+                const float ld = density_at(g, N, lp);
+                lt *= fminf(fmaxf(1.0f - 1.0f * lightScale * ld, 0.0f), 1.0f);
+                if (lt < 0.01f) break;
+                for (int a = 0; a < 3; ++a) lp[a] += ls[a];
+            }
+            scatter += lt * transmit * sd;
+        }
+        for (int a = 0; a < 3; ++a) pos[a] += step[a];
+    }
+    for (int c = 0; c < 3; ++c) {
+        float r = scatter * 0.8f + 0.2f;
+        r = r + transmit * (clear[c] * clear[c] - r);
+        rgba[c] = sqrtf(r);
+    }
+    rgba[3] = 1.0f;
+}
+
+/* cb_in = {light[3], eye[3], s2l[16]} (22 floats) or NULL to derive it with orc_update_frame. */
+ORC_API int orc_render(const uint8_t* grid, uint32_t N, const float bound[4], const float ps[4], const float eye[3],
+                       const float vp[16], uint32_t width, uint32_t height, const float* cb_in, uint8_t* rgba8)
+{
+    orc_cb cb;
+    if (cb_in) { memcpy(cb.light, cb_in, 12); memcpy(cb.eye, cb_in + 3, 12); memcpy(cb.s2l, cb_in + 6, 64); }
+    else if (orc_update_frame(bound, ps, eye, vp, (float)width, (float)height, cb.light, cb.eye, cb.s2l)) return 1;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t py = 0; py < (int64_t)height; ++py)
+        for (uint32_t px = 0; px < width; ++px) {
+            float c[4];
+            shade_pixel(&cb, grid, N, (float)px + 0.5f, (float)py + 0.5f, c);
+            for (int k = 0; k < 4; ++k) {
+                float v = c[k];
+                if (!(v > 0.0f)) v = 0.0f;
+                if (v > 1.0f) v = 1.0f;
+                rgba8[((size_t)py * width + px) * 4 + k] = (uint8_t)(v * 255.0f + 0.5f);
+            }
+        }
+    return 0;
+}
+
 ORC_API int orc_num_procs(void)
 {
 #ifdef _OPENMP

@@ -56,6 +56,10 @@ def lib():
         L.orc_voxelize.restype = C.c_int
         L.orc_voxelize_slices.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, _u32p, C.c_uint32, C.c_int, _u8p]
         L.orc_voxelize_slices.restype = C.c_int
+        L.orc_update_frame.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_float, C.c_float, _f32p, _f32p, _f32p]
+        L.orc_update_frame.restype = C.c_int
+        L.orc_render.argtypes = [_u8p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_void_p, _u8p]
+        L.orc_render.restype = C.c_int
         L.orc_num_procs.restype = C.c_int
         _LIB = L
     return _LIB
@@ -134,6 +138,33 @@ def voxelize_slices(scene, N, zlist, mode=MODE_REFERENCE, algo=ALGO_BVH, threads
     rc = lib().orc_voxelize_slices(scene._h, N, mode, algo, z, len(z), threads, out)
     if rc:
         raise RuntimeError(f"orc_voxelize_slices -> {rc}")
+    return out
+
+
+def update_frame(bound, eye, view_proj, width, height, pos_scale=(0, 0, 0, 1)):
+    """(lightPt[3], eyePt[3], screenToLocal[16]) as Voxelizer::UpdateFrame builds them."""
+    li, ey, m = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(16, np.float32)
+    rc = lib().orc_update_frame(np.ascontiguousarray(bound, np.float32), np.ascontiguousarray(pos_scale, np.float32),
+                                np.ascontiguousarray(eye, np.float32), np.ascontiguousarray(view_proj, np.float32).reshape(-1),
+                                float(width), float(height), li, ey, m)
+    if rc:
+        raise RuntimeError("orc_update_frame: singular matrix chain")
+    return li, ey, m
+
+
+def render(grid, bound, eye, view_proj, width, height, pos_scale=(0, 0, 0, 1), cb=None):
+    """uint8 [height, width, 4] image of the display pass over a full uint8 grid [N, N, N]."""
+    g = np.ascontiguousarray(grid, np.uint8)
+    out = np.zeros((height, width, 4), np.uint8)
+    cbp = None
+    if cb is not None:
+        cbv = np.ascontiguousarray(np.concatenate([np.ravel(c) for c in cb]), np.float32)
+        cbp = cbv.ctypes.data_as(C.c_void_p)
+    rc = lib().orc_render(g.reshape(-1), g.shape[0], np.ascontiguousarray(bound, np.float32),
+                          np.ascontiguousarray(pos_scale, np.float32), np.ascontiguousarray(eye, np.float32),
+                          np.ascontiguousarray(view_proj, np.float32).reshape(-1), width, height, cbp, out.reshape(-1))
+    if rc:
+        raise RuntimeError("orc_render failed")
     return out
 
 

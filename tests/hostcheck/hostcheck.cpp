@@ -3,6 +3,7 @@
 // hierarchy rule and the traversal can be checked against the oracle without a GPU.
 // Never linked into libdxv.so; the shipped library has no CPU path.
 #include "../../dxrvoxelizer_amd/csrc/dxv_trace.h"
+#include "../../dxrvoxelizer_amd/csrc/dxv_raycast.h"
 
 #include <algorithm>
 #include <cstring>
@@ -441,6 +442,35 @@ __attribute__((visibility("default"))) void hc_simt_stats_q(void* p, uint32_t N,
         }
     }
     out[0] = waves; out[1] = p1; out[2] = p1live; out[3] = p2; out[4] = p2lanes; out[5] = heaviest; out[6] = total;
+}
+
+// display pass (N3): the product's UpdateFrame constants and per-pixel march on the host
+__attribute__((visibility("default"))) int hc_update_frame(const float* bound, const float* ps, const float* eye, const float* vp,
+                                                           float w, float h, float* cb22)
+{
+    RayCastCB cb;
+    if (!update_frame(bound, ps, eye, vp, w, h, cb)) return 1;
+    memcpy(cb22, cb.lightPt, 12); memcpy(cb22 + 3, cb.eyePt, 12); memcpy(cb22 + 6, cb.screenToLocal, 64);
+    return 0;
+}
+
+__attribute__((visibility("default"))) void hc_render(const uint8_t* grid, uint32_t N, const float* cb22, uint32_t width,
+                                                      uint32_t height, uint8_t* rgba8)
+{
+    RayCastCB cb;
+    memcpy(cb.lightPt, cb22, 12); memcpy(cb.eyePt, cb22 + 3, 12); memcpy(cb.screenToLocal, cb22 + 6, 64);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t py = 0; py < (int64_t)height; ++py)
+        for (uint32_t px = 0; px < width; ++px) {
+            float c[4];
+            raycast_pixel(cb, grid, N, (float)px + 0.5f, (float)py + 0.5f, c);
+            for (int k = 0; k < 4; ++k) {
+                float v = c[k];
+                if (!(v > 0.0f)) v = 0.0f;
+                if (v > 1.0f) v = 1.0f;
+                rgba8[((size_t)py * width + px) * 4 + k] = (uint8_t)(v * 255.0f + 0.5f);
+            }
+        }
 }
 
 } // extern "C"
