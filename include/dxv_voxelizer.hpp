@@ -59,6 +59,28 @@ public:
 		return dxv_voxelize(m_ctx, gridDim, mode, z0, nz) == 0;
 	}
 
+	// Dynamic meshes: new vertex data on the same topology, refit of the existing hierarchy.
+	bool UpdateVertices(const float* vb, uint32_t numVerts)
+	{
+		if (!m_ctx) return setError("UpdateVertices before Init");
+		return dxv_update_vertices(m_ctx, vb, numVerts) == 0 && dxv_refit(m_ctx) == 0;
+	}
+
+	// Content/Voxelizer.h:20-22: UpdateFrame(frameIndex, eyePt, viewProj) stores the camera, Render
+	// runs voxelize + the ray-cast display pass.  eyePt[3]; viewProj row-major, row vectors
+	// (XMFLOAT4X4 of view * proj, DXRVoxelizer.cpp:249-254).
+	void UpdateFrame(const float eyePt[3], const float viewProj[16])
+	{
+		for (int i = 0; i < 3; ++i) m_eyePt[i] = eyePt[i];
+		for (int i = 0; i < 16; ++i) m_viewProj[i] = viewProj[i];
+	}
+	bool Render(uint32_t gridDim, uint32_t width, uint32_t height, std::vector<uint8_t>& rgba)
+	{
+		if (!Voxelize(gridDim)) return false;
+		rgba.resize(static_cast<size_t>(width) * height * 4);
+		return dxv_render(m_ctx, m_eyePt, m_viewProj, m_posScale, width, height, rgba.data()) == 0;
+	}
+
 	// Result: uint8 occupancy, x fastest, then y (top to bottom), then z.
 	bool Download(std::vector<uint8_t>& grid)
 	{
@@ -81,5 +103,7 @@ protected:
 	dxv_ctx*	m_ctx = nullptr;
 	int			m_device;
 	float		m_posScale[4] = { 0.0f, 0.0f, 0.0f, 1.0f };
+	float		m_eyePt[3] = { 8.0f, 12.0f, -14.0f };	// DXRVoxelizer.cpp:230
+	float		m_viewProj[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
 	std::string	m_err;
 };
