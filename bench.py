@@ -219,8 +219,10 @@ def main():
                            "mvoxels_s": N ** 3 / other_ms / 1e3}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_voxelize", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "traversal is latency/divergence bound: compulsory HBM bytes are tiny"},
+                         "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "compulsory HBM bytes are tiny: the measured limiter is VALU/SALU issue with waves "
+                                 "waiting on dependent L1/L2/scalar-cache fetches (profiles/r01/final/pmc_summary.json)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode)
