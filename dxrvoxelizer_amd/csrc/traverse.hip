@@ -3,13 +3,15 @@
 // Replaces DispatchRays(GRID_SIZE, GRID_SIZE*GRID_SIZE, 1) with raygenMain / closestHitMain /
 // missMain (Content/Voxelizer.cpp:366-368, Content/Shaders/DXRVoxelizer.hlsl:58-85, :132-148).
 //
-// Launch shape: a 256-thread workgroup owns a BX x BY x BZ brick of voxels, a wavefront a
-// 64-voxel sub-brick of it (lanes with neighbouring origins and near-parallel radial rays walk
-// the same nodes).  Workgroup ids are remapped so that each of the 8 XCDs works on one
-// contiguous Z range of bricks and its private L2 keeps the matching part of the tree.
-// The per-thread traversal stack is an LDS column (stack[entry][thread]: consecutive lanes hit
-// consecutive banks); its depth is chosen from the tree height recorded by the build, and an
-// overflow is reported through the status word, never ignored.
+// Launch shape: a workgroup owns a BX x BY x BZ brick of voxels (default 4x4x4 = one wavefront;
+// lanes with neighbouring origins and near-parallel radial rays walk the same nodes).  Bricks are
+// numbered along a Morton curve and dealt to the 8 XCDs in runs of 2^regionBits bricks, so each
+// private L2 sees compact regions while the uneven per-region cost balances.  Only the bricks the
+// exact root early-out cannot clear are launched when that removes a good part of the grid.
+// The per-thread traversal stack (shared with the postponed-leaf queue) is an LDS column
+// (stack[entry][thread]: consecutive lanes hit consecutive banks); its depth adapts (dxv_api.hip)
+// and an overflow is reported through the status word, never ignored.
+// Parity mode normally runs k_parity_rows (one wave-uniform walk per grid row, below).
 #include "dxv_device.h"
 #include "dxv_trace.h"
 
