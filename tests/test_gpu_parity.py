@@ -398,3 +398,25 @@ def test_full_size_properties_torus_1m_512(vox, orc):
         assert np.array_equal(p[z], s.voxelize(N, mode=1, z0=z, nz=1)[0]), z
     # the two occupancy rules agree except near grazing exits
     assert (p != g).mean() < 1e-3
+
+
+def test_largest_grid_2048_indexing(vox, orc, dragon):
+    """Maximum size: 2048^3 = 8.6 G voxels, ids beyond 2^32.  The full grid's solid count must equal
+    the sum over 8 Z slabs (same voxels, small ids), and spot slices must equal the oracle."""
+    vb, ib, _ = dragon
+    vox.InitFromArrays(vb, ib)
+    N = 2048
+    s = orc.Scene(vb, ib)
+    for mode in (1, 0):
+        vox.Voxelize(N, mode)
+        total = vox.CountSolid()
+        parts = 0
+        for r in range(8):
+            z0, nz = slab_range(N, r, 8)
+            vox.Voxelize(N, mode, z0, nz)
+            parts += vox.CountSolid()
+            if r == 5:                                   # slices 1280.. : first slice of the slab vs oracle row sample
+                g = vox.Grid()[0]
+                want = orc.voxelize_slices(s, N, [z0], mode=mode)[0]
+                assert np.array_equal(g, want)
+        assert total == parts and total > 0
