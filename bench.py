@@ -53,19 +53,19 @@ def cpu_baseline(vb, ib, N, mode, budget_s=15.0):
     from oracle import orc
     import numpy as np
     scene = orc.Scene(vb, ib)
-    cores = orc.lib().orc_num_procs()
+    cores = orc.usable_cores()                      # affinity mask capped by the cgroup CPU quota
     probe = sorted(set(int(z) for z in np.linspace(0, N - 1, 16).round()))
     t0 = time.perf_counter()
-    orc.voxelize_slices(scene, N, probe, mode=mode)
+    orc.voxelize_slices(scene, N, probe, mode=mode, threads=cores)
     per_slice = (time.perf_counter() - t0) / len(probe)
     n = int(max(16, min(N, budget_s / max(per_slice, 1e-6))))
     zs = sorted(set(int(z) for z in np.linspace(0, N - 1, n).round()))
     t0 = time.perf_counter()
-    orc.voxelize_slices(scene, N, zs, mode=mode)
+    orc.voxelize_slices(scene, N, zs, mode=mode, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": len(zs) * N * N / dt / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
             "sample": f"{len(zs)} evenly spaced Z slices of the {N}^3 grid ({len(zs) * N * N} voxels, {dt:.1f} s), "
-                      f"oracle BVH traversal, OpenMP over rows"}
+                      f"oracle BVH traversal, OpenMP over rows, {cores} threads (cgroup quota / affinity)"}
 
 
 def main():

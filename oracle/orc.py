@@ -132,6 +132,25 @@ class Scene:
         return (out, tex) if texels else out
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota (a
+    container limited to 16 CPUs of a 256-thread box must not run 256 OpenMP threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def voxelize_slices(scene, N, zlist, mode=MODE_REFERENCE, algo=ALGO_BVH, threads=0):
     z = np.ascontiguousarray(zlist, np.uint32)
     out = np.zeros((len(z), N, N), np.uint8)

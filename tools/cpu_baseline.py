@@ -24,7 +24,7 @@ def timed(fn, reps=3):
     return float(np.median(ts))
 
 
-cores = orc.lib().orc_num_procs()
+cores = orc.usable_cores()
 for mesh in ("bunny", "dragon", "torus1m"):
     vb, ib, label = make_mesh(mesh)
     t0 = time.perf_counter()
