@@ -13,7 +13,8 @@ class DxvError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libdxv.so")
+    # DXV_LIBRARY: load another build of the same library (A/B timing of kernel variants in tools/)
+    return os.environ.get("DXV_LIBRARY") or os.path.join(_HERE, "libdxv.so")
 
 
 class Stats(C.Structure):

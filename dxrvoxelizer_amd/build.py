@@ -43,9 +43,15 @@ def _compile(src, extra):
     if src.endswith(".cpp"):
         cmd = [c for c in cmd if not c.startswith("--offload-arch") and not c.startswith("-fhip")]
         cmd.insert(1, "-x"), cmd.insert(2, "c++")
+    if src.endswith(".hip"):
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")   # VGPR / scratch / LDS per kernel -> build/*.usage
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError("compile failed: %s\n%s%s" % (" ".join(cmd), r.stdout, r.stderr))
+    if src.endswith(".hip"):
+        with open(os.path.join(OBJDIR, os.path.splitext(src)[0] + ".usage"), "w") as fh:
+            fh.write(r.stderr)
+        return obj, "\n".join(l for l in r.stderr.splitlines() if "remark:" not in l)
     return obj, r.stderr
 
 
@@ -65,6 +71,27 @@ def build(force=False, save_temps=False, verbose=False):
     if r.returncode:
         raise RuntimeError("link failed: %s\n%s%s" % (" ".join(cmd), r.stdout, r.stderr))
     return LIB
+
+
+def kernel_resources(src="traverse"):
+    """{kernel name: {"vgprs": n, "scratch": bytes per lane, "lds": bytes, "occupancy": waves/SIMD}}
+    from the compiler's resource remarks of the last build."""
+    import re
+    path = os.path.join(OBJDIR, src + ".usage")
+    out, cur = {}, None
+    for line in open(path):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("lds", r"LDS Size \[bytes/block\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    return out
 
 
 if __name__ == "__main__":

@@ -140,3 +140,24 @@ def test_compressed_nodes_contain_exact_boxes(orc, hostcheck, dragon):
     for c in (0, 6):
         assert np.all(halves[:, c:c + 3] <= exact[:, c:c + 3]) and np.all(halves[:, c + 3:c + 6] >= exact[:, c + 3:c + 6])
     assert np.max(np.abs(halves - exact)) < 1e-3                   # half ulp near 1.0 is 2^-11
+
+
+def test_queued_walk_every_capacity_is_exact_or_reports_overflow(orc, hostcheck, dragon):
+    """The stack and the postponed-leaf queue share one LDS column.  For every column size the walk
+    must either report overflow or produce the exact grid -- never a silently wrong one (a lane whose
+    stack alone no longer leaves room after a flush has to stop)."""
+    vb, ib, _ = dragon
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    want = {0: s.voxelize(32), 1: s.voxelize(32, mode=1)}
+    clean = 0
+    for cap in range(5, 26):
+        for mode in (2, 3):
+            g, ovf = h.voxelize(32, mode, stack=cap)
+            if not ovf:
+                clean += 1
+                assert np.array_equal(g, want[mode % 2]), (cap, mode)
+            else:                                   # rays that did not overflow are still right
+                bad = g != want[mode % 2]
+                assert bad.mean() < 0.2, (cap, mode)
+    assert clean >= 10

@@ -1,0 +1,27 @@
+"""Guard against silent codegen regressions of the dominant kernels (found the hard way in round 1:
+one extra line made hipcc spill 36 B/lane to meet the 64-VGPR bound and cost 14 % on MI355X).
+Reads the compiler's own resource remarks recorded by dxrvoxelizer_amd/build.py."""
+import os
+
+from dxrvoxelizer_amd import build
+
+
+def resources():
+    usage = os.path.join(build.OBJDIR, "traverse.usage")
+    if not os.path.exists(usage):
+        build.build(force=True)
+    return build.kernel_resources("traverse")
+
+
+def test_default_kernels_do_not_spill_and_keep_full_occupancy(dxvlib):
+    res = resources()
+    default_ref = [v for k, v in res.items() if "k_voxelizeINS_5BrickILi4ELi4ELi4EEELi20ELi0ELb0ELb1E" in k]
+    default_par = [v for k, v in res.items() if "k_parity_rowsILi8E" in k]
+    assert len(default_ref) == 1 and len(default_par) == 1
+    r = default_ref[0]
+    assert r["scratch"] == 0 and r["vgprs"] <= 64 and r["occupancy"] == 8 and r["lds"] == 20 * 64 * 4
+    assert default_par[0]["scratch"] == 0 and default_par[0]["lds"] == 256
+    # no variant of the voxelize kernels may use scratch memory
+    for k, v in res.items():
+        if "k_voxelize" in k or "k_parity_rows" in k:
+            assert v["scratch"] == 0, k
