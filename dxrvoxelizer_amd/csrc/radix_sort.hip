@@ -2,7 +2,7 @@
 //
 // Only the Morton half needs sorting: the index half starts ascending and every pass is stable,
 // so P = 4 passes of 8-bit digits over bits [32, 64) order the full 64-bit key.  Each pass is
-//   histogram (per 4096-key tile, 256 bins)  ->  exclusive scan over (digit, tile)  ->
+//   histogram (per 4096-key tile, 256 bins)  ->  two-level exclusive scan over (digit, tile)  ->
 //   stable scatter (wave64 ballot match for the in-wave rank, LDS for the cross-wave rank).
 // HBM traffic per pass: 8 B read (histogram) + 8 B read + 8 B write (scatter) per key.
 #include "dxv_device.h"
@@ -31,41 +31,64 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __re
     hist[(uint64_t)threadIdx.x * numTiles + tile] = bins[threadIdx.x]; // digit-major
 }
 
-// Exclusive scan of `len` uint32 in place, one workgroup of 1024 threads: serial segment sums,
-// a block scan of the 1024 partials, serial write-back.
-__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ data, uint32_t len)
+// Two-level exclusive scan of the digit-major histogram hist[256][numTiles]:
+//   k_sort_scan_rows   one workgroup per digit: in-place exclusive scan of its row (coalesced),
+//                      row total -> totals[digit]
+//   k_sort_scan_digits one workgroup: exclusive scan of the 256 totals -> digitBase[256]
+// The scatter kernel adds digitBase[d] + hist[d][tile].  (A single-workgroup scan of the whole
+// 256 x numTiles array took 92 us per pass at 1 M keys, 80 % of the sort.)
+__global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t* __restrict__ hist, uint32_t numTiles, uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry;
+    uint32_t* row = hist + (uint64_t)blockIdx.x * numTiles;
     const uint32_t tid = threadIdx.x;
-    const uint32_t seg = (len + 1023u) / 1024u;
-    const uint32_t b = tid * seg, e = min(b + seg, len);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; ++i) s += data[i];
-    part[tid] = s;
+    if (tid == 0) carry = 0;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = tid >= off ? part[tid - off] : 0u;
+    for (uint32_t base = 0; base < numTiles; base += 256) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < numTiles ? row[i] : 0u;
+        part[tid] = v;
         __syncthreads();
-        part[tid] += v;
+        for (uint32_t off = 1; off < 256; off <<= 1) {
+            const uint32_t a = tid >= off ? part[tid - off] : 0u;
+            __syncthreads();
+            part[tid] += a;
+            __syncthreads();
+        }
+        if (i < numTiles) row[i] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == 255) carry += part[255];
         __syncthreads();
     }
-    uint32_t run = part[tid] - s; // exclusive prefix of this segment
-    for (uint32_t i = b; i < e; ++i) {
-        const uint32_t v = data[i];
-        data[i] = run;
-        run += v;
+    if (tid == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_sort_scan_digits(const uint32_t* __restrict__ totals, uint32_t* __restrict__ digitBase)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t v = totals[tid];
+    part[tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t a = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += a;
+        __syncthreads();
     }
+    digitBase[tid] = part[tid] - v;
 }
 
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                                uint32_t n, int shift, const uint32_t* __restrict__ offs,
-                                                               uint32_t numTiles)
+                                                               const uint32_t* __restrict__ digitBase, uint32_t numTiles)
 {
     __shared__ uint32_t run[256];            // keys of each digit already placed by earlier items
     __shared__ uint32_t wcnt[kWaves][256];   // per-wave digit counts of the current item
     const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    run[tid] = offs[(uint64_t)tid * numTiles + tile]; // global start of (digit = tid, this tile)
+    run[tid] = digitBase[tid] + offs[(uint64_t)tid * numTiles + tile]; // global start of (digit = tid, this tile)
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) wcnt[w][tid] = 0;
     __syncthreads();
@@ -109,14 +132,17 @@ hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* 
     uint64_t* dst = tmp;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 32 + 8 * pass;
+        uint32_t* totals = hist + 256u * (size_t)numTiles;      // 256 row totals + 256 digit bases behind the histogram
+        uint32_t* digitBase = totals + 256;
         k_sort_hist<<<numTiles, kSortThreads, 0, s>>>(src, n, shift, hist, numTiles);
-        k_sort_scan<<<1, 1024, 0, s>>>(hist, 256u * numTiles);
-        k_sort_scatter<<<numTiles, kSortThreads, 0, s>>>(src, dst, n, shift, hist, numTiles);
+        k_sort_scan_rows<<<256, 256, 0, s>>>(hist, numTiles, totals);
+        k_sort_scan_digits<<<1, 256, 0, s>>>(totals, digitBase);
+        k_sort_scatter<<<numTiles, kSortThreads, 0, s>>>(src, dst, n, shift, hist, digitBase, numTiles);
         uint64_t* t = src; src = dst; dst = t;
     }
     return hipGetLastError();
 }
 
-uint32_t radix_sort_hist_words(uint32_t n) { return 256u * ((n + kSortTile - 1) / kSortTile); }
+uint32_t radix_sort_hist_words(uint32_t n) { return 256u * ((n + kSortTile - 1) / kSortTile) + 512u; }
 
 } // namespace dxv
