@@ -11,6 +11,24 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 10 --warmup 2 --interleave --no-cpu-baseline > $OUT/bench_torchrun_world1.log 2>&1
 python tools/build_bench.py bunny torus1m soup10m > $OUT/build.jsonl 2>&1
 python tools/cpu_baseline.py > $OUT/cpu_baseline.jsonl 2>&1
+python - > $OUT/render.jsonl 2>&1 <<'PY'
+import sys, json, numpy as np
+sys.path.insert(0, '.')
+import dxrvoxelizer_amd as dxv
+from dxrvoxelizer_amd import camera
+from bench import make_mesh
+v = dxv.Voxelizer(0)
+for mesh, N in (("bunny", 64), ("dragon", 512)):
+    vb, ib, _ = make_mesh(mesh)
+    v.InitFromArrays(vb, ib); v.Voxelize(N)
+    eye, vp = camera.default_view_proj(1280, 720)
+    ts = []
+    for _ in range(6):
+        img = v.Render(eye, vp, 1280, 720)
+        ts.append(v.stats()["render_ms"])
+    camera.write_png(f"gpurun_out/final/render_{mesh}_{N}.png", img)
+    print(json.dumps({"mesh": mesh, "N": N, "render_ms_1280x720": float(np.median(ts[1:])), "opaque_px": int((img[..., 3] == 255).sum())}))
+PY
 python tools/sweep.py --meshes torus1m,bunny,dragon --grids 256,512 --bricks 4 --stacks 0 --modes reference,parity --reps 5 > $OUT/sweep.jsonl 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/prof_bench.log 2>&1
