@@ -352,7 +352,7 @@ int dxv_refit(dxv_ctx* c)
     c->haveScene = false;
     BuildBuffers b{};
     fill_build_buffers(c, b);
-    DXV_HIP(c, lbvh_refit(b, c->optRefit, c->stream, c->ev + 3));
+    DXV_HIP(c, lbvh_refit(b, c->optRefit, c->hdr.treeHeight, c->stream, c->ev + 3));
     if (finish_build(c, "dxv_refit")) return 1;
     c->stats.refit_ms = elapsed(c->ev[3], c->ev[4]);
     return 0;

@@ -32,7 +32,7 @@ struct BuildBuffers {
 struct BuildTimes { float prep, sort, hierarchy, refit; };
 // refitMode: 0 = one pass, bottom-up with per-node arrival counters; 1 = level-synchronous sweeps
 hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[5]);
-hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[2]);
+hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight, hipStream_t s, hipEvent_t ev[2]);
 
 // traverse.hip
 struct VoxelizeParams {

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(kThreads) void k_compress_nodes(const Node* __restr
 }
 
 // rootInfo: lo[3], hi[3] (float bits), height of the root, 1
-__global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict__ rootInfo)
+__global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict__ rootInfo,
+                            const uint32_t* __restrict__ rootReady)
 {
     float lo[3], hi[3], lo1[3], hi1[3];
     uint32_t h0, h1;
@@ -195,15 +196,16 @@ __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict
         rootInfo[3 + a] = __builtin_bit_cast(uint32_t, max_(hi[a], hi1[a]));
     }
     rootInfo[6] = (h0 > h1 ? h0 : h1) + 1;
-    rootInfo[7] = 1;
+    rootInfo[7] = rootReady ? *rootReady : 1u;      // sweep refit: the root's ready flag of the last sweep
 }
 
 // K4 + K5 + root info over an existing hierarchy (links and parent words in place).
-static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t s)
+static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t s, uint32_t knownHeight = 0)
 {
     const uint32_t T = b.T;
     const uint32_t numNodes = T > 1 ? T - 1 : 1;
     hipError_t e;
+    const uint32_t* rootReadyFlag = nullptr;
     if (T == 1) {
         k_single_tri<<<1, 1, 0, s>>>(b.triPos, b.nodes);
     } else {
@@ -211,10 +213,19 @@ static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t 
         if (refitMode == 0) {
             k_refit_atomic<<<blocks_for(T), kThreads, 0, s>>>(b.triPos, T, b.nodes, b.parents, b.flags);
         } else {
-            // tree height <= 62 (distinct 62-bit keys); sweep in batches until the root is ready
             uint32_t* prev = b.flags;
             uint32_t* next = b.flags2;
             uint32_t rootReady = 0;
+            if (knownHeight) {
+                // same hierarchy as before (dxv_refit): a node of height h is ready after h sweeps, so
+                // exactly `height` sweeps finish the root; no host round trips, the stream stays async
+                for (uint32_t it = 0; it < knownHeight; ++it) {
+                    k_refit_sweep<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, b.nodes, prev, next);
+                    uint32_t* t = prev; prev = next; next = t;
+                }
+                rootReady = 1;      // verified on the device: k_root_info copies the root's ready flag
+            }
+            // first build: tree height unknown (<= 62: distinct 62-bit keys); sweep in batches until the root is ready
             for (int batch = 0; batch < 16 && !rootReady; ++batch) {
                 for (int it = 0; it < 8; ++it) {
                     k_refit_sweep<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, b.nodes, prev, next);
@@ -224,10 +235,11 @@ static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t 
                 if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
             }
             if (!rootReady) return hipErrorUnknown;
+            rootReadyFlag = prev;
         }
     }
     k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
-    k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo);
+    k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, rootReadyFlag);
     return hipGetLastError();
 }
 
@@ -260,7 +272,7 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
 // Dynamic meshes (the reference API's ALLOW_UPDATE / PERFORM_UPDATE, XUSG/RayTracing/XUSGRayTracing.h:13-22,
 // unused by the sample): vertices moved, topology and Morton order kept -> re-gather the triangle
 // records and refit the boxes.  ev[0..1] bracket the work.
-hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[2])
+hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight, hipStream_t s, hipEvent_t ev[2])
 {
     Bound4 bnd;
     for (int a = 0; a < 4; ++a) bnd.c[a] = b.bound[a];
@@ -268,7 +280,7 @@ hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
     (void)hipEventRecord(ev[0], s);
     k_tri_gather<<<blocks_for(b.T), kThreads, 0, s>>>(b.vb, b.ib, b.T, bnd, b.keys, b.triPos, b.triNrm);
-    if ((e = refit_stage(b, refitMode, s)) != hipSuccess) return e;
+    if ((e = refit_stage(b, refitMode, s, treeHeight)) != hipSuccess) return e;
     (void)hipEventRecord(ev[1], s);
     return hipGetLastError();
 }
