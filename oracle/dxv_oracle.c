@@ -603,7 +603,8 @@ typedef struct { float t, b1, b2; uint32_t k; } orc_hit;
 static inline void consider_ref(const orc_scene* s, const orc_ray* r, uint32_t k, orc_hit* best)
 {
     float tn;
-    if (!slab(r, &s->lo[k].x, &s->hi[k].x, &tn)) return;
+    const float lo[3] = {s->lo[k].x, s->lo[k].y, s->lo[k].z}, hi[3] = {s->hi[k].x, s->hi[k].y, s->hi[k].z};
+    if (!slab(r, lo, hi, &tn)) return;
     if (tn > best->t) return;
     float t, b1, b2;
     if (!tri_test(r, &s->v0[k], &s->v1[k], &s->v2[k], 0, &t, &b1, &b2)) return;
@@ -663,7 +664,8 @@ static inline int box_parity(const orc_ray* r, const float lo[3], const float hi
 
 static inline uint32_t consider_par(const orc_scene* s, const orc_ray* r, uint32_t k)
 {
-    if (!box_parity(r, &s->lo[k].x, &s->hi[k].x)) return 0;
+    const float lo[3] = {s->lo[k].x, s->lo[k].y, s->lo[k].z}, hi[3] = {s->hi[k].x, s->hi[k].y, s->hi[k].z};
+    if (!box_parity(r, lo, hi)) return 0;
     float t, b1, b2;
     return (uint32_t)tri_test(r, &s->v0[k], &s->v1[k], &s->v2[k], 1, &t, &b1, &b2);
 }
