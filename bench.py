@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--stack", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--interleave", action="store_true", help="use the block-cyclic partition call even on one GPU")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="plumbing test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,11 +102,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the voxelizer has no CPU path)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     N, mode = args.grid, (dxv.MODE_REFERENCE if args.mode == "reference" else dxv.MODE_PARITY)
     vox = dxv.Voxelizer(local_rank)
