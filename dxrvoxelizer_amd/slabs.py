@@ -78,3 +78,32 @@ def gather_slabs(parts):
     """Concatenate per-rank slabs [(z0, grid[nz,N,N]), ...] into the full grid (host side)."""
     parts = sorted(parts, key=lambda p: p[0])
     return np.concatenate([g for _, g in parts if g.shape[0]], axis=0)
+
+
+class _DeviceBuffer:
+    """Zero-copy view of a device allocation for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_grid_tensor(vox, device):
+    """The context's device-resident grid of the last Voxelize as a torch uint8 tensor (no copy)."""
+    import torch
+
+    return torch.as_tensor(_DeviceBuffer(vox.grid_device_ptr(), vox.grid_bytes()), device=device)
+
+
+def allgather_grid(vox, dist, N, world, zblock, device):
+    """Optional collective ("or one ncclAllGather of N^3/G bytes per rank if a
+    device-resident full grid is wanted"): every rank ends up with the full [N, N, N] uint8 grid on
+    its device.  Ranks must have called VoxelizeInterleaved(N, rank, world, zblock) before."""
+    import torch
+
+    mine = device_grid_tensor(vox, device)
+    assert mine.numel() == N * N * (N // world)
+    out = torch.empty(world * mine.numel(), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    nblk = N // (zblock * world)
+    # rank-major [W, nblk, zblock, N, N] -> z-major [nblk, W, zblock, N, N]
+    return out.view(world, nblk, zblock, N, N).permute(1, 0, 2, 3, 4).reshape(N, N, N).contiguous()

@@ -420,3 +420,34 @@ def test_largest_grid_2048_indexing(vox, orc, dragon):
                 want = orc.voxelize_slices(s, N, [z0], mode=mode)[0]
                 assert np.array_equal(g, want)
         assert total == parts and total > 0
+
+
+def test_device_resident_full_grid_by_allgather(dxv, dragon, tmp_path):
+    """The optional collective: a device-resident full grid via all_gather (world 1 here; the
+    permutation from rank-major blocks to Z order is what matters and is checked for W = 1 and, on
+    the host, for W = 4 below)."""
+    import torch
+    import torch.distributed as dist
+    from dxrvoxelizer_amd.slabs import allgather_grid, device_grid_tensor, interleaved_slices
+    vb, ib, _ = dragon
+    v = dxv.Voxelizer(0)
+    v.InitFromArrays(vb, ib)
+    v.Voxelize(64)
+    full = v.Grid()
+    assert np.array_equal(device_grid_tensor(v, "cuda").cpu().numpy().reshape(64, 64, 64), full)   # zero-copy view
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1)
+    try:
+        v.VoxelizeInterleaved(64, 0, 1, 8)
+        g = allgather_grid(v, dist, 64, 1, 8, "cuda")
+        assert np.array_equal(g.cpu().numpy(), full)
+    finally:
+        dist.destroy_process_group()
+    # the same permutation for 4 ranks, emulated on the host
+    parts = []
+    for r in range(4):
+        v.VoxelizeInterleaved(64, r, 4, 8)
+        parts.append(torch.from_numpy(v.Grid().reshape(-1)))
+    out = torch.cat(parts)
+    z = out.view(4, 2, 8, 64, 64).permute(1, 0, 2, 3, 4).reshape(64, 64, 64).numpy()
+    assert np.array_equal(z, full)
+    v.close()
