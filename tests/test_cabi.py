@@ -62,3 +62,14 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "library_path", lambda: str(tmp_path / "libdxv.so"))
     with pytest.raises(_lib.DxvError):
         _lib.load_library()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/dxv.h must be consumable from C (cgo, JNI stubs, plain C hosts), not only C++."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "dxv.h"\nint main(void) { dxv_ctx* c = 0; dxv_stats s; (void)s; return dxv_create(&c, 0) == 0 ? (dxv_destroy(c), 0) : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "use.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "voxelize_obj.cpp")])
