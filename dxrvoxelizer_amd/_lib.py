@@ -54,6 +54,8 @@ SYMBOLS = {
     "dxv_grid_device_ptr": (C.c_void_p, [C.c_void_p]),
     "dxv_grid_bytes": (C.c_size_t, [C.c_void_p]),
     "dxv_grid_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dxv_grid_packed_bytes": (C.c_size_t, [C.c_void_p]),
+    "dxv_grid_download_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dxv_grid_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "dxv_enable_texels": (C.c_int, [C.c_void_p, C.c_int]),
     "dxv_texels_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -57,6 +57,8 @@ struct dxv_ctx {
     bool texels = false;
     uint32_t* dStatus = nullptr;
     unsigned long long* dCount = nullptr;
+    uint8_t* dPacked = nullptr;
+    size_t packedCap = 0;
     uint32_t* dImage = nullptr;
     size_t imageCap = 0;
     float renderMs = 0.0f;
@@ -234,7 +236,7 @@ void dxv_destroy(dxv_ctx* c)
     free_scratch(c);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene); (void)hipFree(c->dGrid);
     (void)hipFree(c->dImage);
-    (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dCount); (void)hipFree(c->dRootInfo);
+    (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -504,6 +506,26 @@ int dxv_grid_download(dxv_ctx* c, uint8_t* host, size_t bytes)
     if (!host || bytes != c->gridBytes || !c->gridBytes) return fail(c, "dxv_grid_download: expected %zu bytes, got %zu", c->gridBytes, bytes);
     DXV_HIP(c, hipSetDevice(c->device));
     DXV_HIP(c, hipMemcpyAsync(host, c->dGrid, bytes, hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+size_t dxv_grid_packed_bytes(const dxv_ctx* c) { return c ? (c->gridBytes + 7) / 8 : 0; }
+
+int dxv_grid_download_packed(dxv_ctx* c, uint8_t* host, size_t bytes)
+{
+    if (!c) return 1;
+    const size_t want = (c->gridBytes + 7) / 8;
+    if (!host || !want || bytes != want) return fail(c, "dxv_grid_download_packed: expected %zu bytes, got %zu", want, bytes);
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (want > c->packedCap) {
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dPacked); c->dPacked = nullptr; c->packedCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dPacked, align256(want)));
+        c->packedCap = want;
+    }
+    DXV_HIP(c, launch_pack_bits(c->dGrid, c->gridBytes, c->dPacked, c->stream));
+    DXV_HIP(c, hipMemcpyAsync(host, c->dPacked, want, hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }

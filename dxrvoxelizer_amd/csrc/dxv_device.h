@@ -57,6 +57,7 @@ hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEnt
 int stack_round_up(int want);
 hipError_t launch_parity_rows(const VoxelizeParams& p, hipStream_t s);   // parity mode, one tree walk per row run
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
+hipError_t launch_pack_bits(const uint8_t* grid, size_t n, uint8_t* packed, hipStream_t s);
 int num_brick_shapes();
 
 // raycast.hip

@@ -118,6 +118,18 @@ class Voxelizer:
         self._check(self._lib.dxv_grid_download(self._ctx, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
+    def GridBits(self, out=None):
+        """The grid as one bit per voxel, packed on the device (dxv_grid_download_packed): uint8
+        [ceil(nz*N*N/8)], voxel 8j+i in bit i of byte j == np.packbits(Grid().ravel(),
+        bitorder="little").  `out` may be any writable uint8 buffer of that size, e.g. pinned."""
+        nbytes = self._lib.dxv_grid_packed_bytes(self._ctx)
+        if out is None:
+            out = np.empty(nbytes, np.uint8)
+        ptr = out.ctypes.data_as(C.c_void_p) if isinstance(out, np.ndarray) else C.c_void_p(out.data_ptr())
+        size = out.nbytes if isinstance(out, np.ndarray) else out.numel() * out.element_size()
+        self._check(self._lib.dxv_grid_download_packed(self._ctx, ptr, size))
+        return out
+
     def Texels(self):
         n, nz = self._last
         out = np.empty((nz, n, n), np.uint32)

@@ -126,6 +126,12 @@ DXV_API int dxv_voxelize_interleaved_async(dxv_ctx* ctx, uint32_t grid_dim, int 
 DXV_API void* dxv_grid_device_ptr(dxv_ctx* ctx);
 DXV_API size_t dxv_grid_bytes(const dxv_ctx* ctx);
 DXV_API int dxv_grid_download(dxv_ctx* ctx, uint8_t* host, size_t bytes);
+/* The same grid as one BIT per voxel, packed on the device before it crosses PCIe (8x fewer
+ * bytes): voxel 8j+i of the last launch's slab is bit i of byte j; bytes = dxv_grid_packed_bytes
+ * = ceil(dxv_grid_bytes / 8).  What the reference's consumer reads is this one bit (alpha,
+ * Shaders/PSRayCast.hlsl:108). */
+DXV_API size_t dxv_grid_packed_bytes(const dxv_ctx* ctx);
+DXV_API int dxv_grid_download_packed(dxv_ctx* ctx, uint8_t* host, size_t bytes);
 /* Number of solid voxels of the last grid, reduced on the device. */
 DXV_API int dxv_grid_count(dxv_ctx* ctx, uint64_t* solid);
 

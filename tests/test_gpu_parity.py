@@ -451,3 +451,17 @@ def test_device_resident_full_grid_by_allgather(dxv, dragon, tmp_path):
     z = out.view(4, 2, 8, 64, 64).permute(1, 0, 2, 3, 4).reshape(64, 64, 64).numpy()
     assert np.array_equal(z, full)
     v.close()
+
+
+@pytest.mark.parametrize("n,z0,nz", [(64, 0, 64), (2, 0, 2), (6, 1, 3), (10, 0, 7), (256, 100, 9)])
+def test_bit_packed_download_equals_packbits(vox, bunny, n, z0, nz):
+    """dxv_grid_download_packed: voxel 8j+i in bit i of byte j, any slab size (ragged tails)."""
+    vb, ib, _ = bunny
+    vox.InitFromArrays(vb, ib)
+    vox.Voxelize(n, 0, z0, nz)
+    g = vox.Grid()
+    bits = vox.GridBits()
+    assert bits.shape == ((g.size + 7) // 8,)
+    assert np.array_equal(bits, np.packbits(g.reshape(-1), bitorder="little"))
+    with pytest.raises(Exception):
+        vox.GridBits(np.empty(bits.size + 1, np.uint8))
