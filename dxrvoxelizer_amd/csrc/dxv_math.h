@@ -129,6 +129,21 @@ DXV_HD bool slab(const Ray& r, float lox, float loy, float loz, float hix, float
     return tn <= tf;
 }
 
+// The same test with the planes already sorted by the ray: `in*` is the plane of each axis the
+// ray enters through (lo when that direction component is positive, hi when it is negative),
+// `out*` the other one.  t(plane) is monotone in `plane` with the sign of 1/d, so
+// min(t(lo), t(hi)) == t(in) and max(t(lo), t(hi)) == t(out) bit for bit: slab_sorted returns what
+// slab returns (direction components are never zero: voxel centres do not lie on an axis plane).
+DXV_HD bool slab_sorted(const Ray& r, float inx, float iny, float inz, float outx, float outy, float outz, float& tn)
+{
+    const float tix = fma_(inx, r.ivx, r.nox), tox = fma_(outx, r.ivx, r.nox);
+    const float tiy = fma_(iny, r.ivy, r.noy), toy = fma_(outy, r.ivy, r.noy);
+    const float tiz = fma_(inz, r.ivz, r.noz), toz = fma_(outz, r.ivz, r.noz);
+    tn = max_(max_(tix, tiy), max_(tiz, 0.0f));
+    const float tf = min_(min_(tox, toy), toz);
+    return tn <= tf;
+}
+
 // +X axis ray against a box (parity mode): origin inside the box's y/z extent and box not behind.
 DXV_HD bool slab_parity(const Ray& r, float loy, float loz, float hix, float hiy, float hiz)
 {
@@ -345,10 +360,9 @@ DXV_HD uint16_t half_up(float x)
 DXV_HD Node32 compress_node(const Node& n)
 {
     Node32 c;
-    c.b[0] = half_down(n.lo0x); c.b[1] = half_down(n.lo0y); c.b[2] = half_down(n.lo0z);
-    c.b[3] = half_up(n.hi0x);   c.b[4] = half_up(n.hi0y);   c.b[5] = half_up(n.hi0z);
-    c.b[6] = half_down(n.lo1x); c.b[7] = half_down(n.lo1y); c.b[8] = half_down(n.lo1z);
-    c.b[9] = half_up(n.hi1x);   c.b[10] = half_up(n.hi1y);  c.b[11] = half_up(n.hi1z);
+    c.b[0] = half_down(n.lo0x); c.b[1] = half_down(n.lo1x); c.b[2] = half_up(n.hi0x);  c.b[3] = half_up(n.hi1x);
+    c.b[4] = half_down(n.lo0y); c.b[5] = half_down(n.lo1y); c.b[6] = half_up(n.hi0y);  c.b[7] = half_up(n.hi1y);
+    c.b[8] = half_down(n.lo0z); c.b[9] = half_down(n.lo1z); c.b[10] = half_up(n.hi0z); c.b[11] = half_up(n.hi1z);
     c.c0 = n.c0; c.c1 = n.c1;
     return c;
 }

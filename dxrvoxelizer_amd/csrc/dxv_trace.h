@@ -51,15 +51,26 @@ DXV_HD NodePlanes load_node(const Node32* nodes, int32_t i)
     const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(nodes) + ((uint32_t)i << 5));
     struct alignas(16) U4 { uint32_t x, y, z, w; };
     const U4 a = *reinterpret_cast<const U4*>(p), d = *reinterpret_cast<const U4*>(p + 4);
-    NodePlanes n;
-    n.b[0] = half_bits_to_float(a.x & 0xffffu); n.b[1] = half_bits_to_float(a.x >> 16);
-    n.b[2] = half_bits_to_float(a.y & 0xffffu); n.b[3] = half_bits_to_float(a.y >> 16);
-    n.b[4] = half_bits_to_float(a.z & 0xffffu); n.b[5] = half_bits_to_float(a.z >> 16);
-    n.b[6] = half_bits_to_float(a.w & 0xffffu); n.b[7] = half_bits_to_float(a.w >> 16);
-    n.b[8] = half_bits_to_float(d.x & 0xffffu); n.b[9] = half_bits_to_float(d.x >> 16);
-    n.b[10] = half_bits_to_float(d.y & 0xffffu); n.b[11] = half_bits_to_float(d.y >> 16);
+    NodePlanes n;                       // b: child 0 lo.xyz hi.xyz, child 1 lo.xyz hi.xyz (Node32 is axis-major)
+    n.b[0] = half_bits_to_float(a.x & 0xffffu); n.b[6] = half_bits_to_float(a.x >> 16);    // x lo
+    n.b[3] = half_bits_to_float(a.y & 0xffffu); n.b[9] = half_bits_to_float(a.y >> 16);    // x hi
+    n.b[1] = half_bits_to_float(a.z & 0xffffu); n.b[7] = half_bits_to_float(a.z >> 16);    // y lo
+    n.b[4] = half_bits_to_float(a.w & 0xffffu); n.b[10] = half_bits_to_float(a.w >> 16);   // y hi
+    n.b[2] = half_bits_to_float(d.x & 0xffffu); n.b[8] = half_bits_to_float(d.x >> 16);    // z lo
+    n.b[5] = half_bits_to_float(d.y & 0xffffu); n.b[11] = half_bits_to_float(d.y >> 16);   // z hi
     n.c0 = (int32_t)d.z; n.c1 = (int32_t)d.w;
     return n;
+}
+
+// The six plane words of node i as stored (x lo, x hi, y lo, y hi, z lo, z hi; child 0 in the low
+// half, child 1 in the high half) and its links.
+struct NodeWords { uint32_t w[6]; int32_t c0, c1; };
+DXV_HD NodeWords load_node_words(const Node32* nodes, int32_t i)
+{
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(nodes) + ((uint32_t)i << 5));
+    struct alignas(16) U4 { uint32_t x, y, z, w; };
+    const U4 a = *reinterpret_cast<const U4*>(p), d = *reinterpret_cast<const U4*>(p + 4);
+    return NodeWords{{a.x, a.y, a.z, a.w, d.x, d.y}, (int32_t)d.z, (int32_t)d.w};
 }
 
 DXV_HD TriPos load_tri(const TriPos* tris, int32_t leaf)
@@ -146,21 +157,30 @@ DXV_HD bool wave_any(bool x)
 // tests does not matter for the result (closest = min (t, k)); a queued triangle's own box entry
 // distance is recomputed from its vertices exactly as the refit computed the leaf box.
 // One internal-node visit of the postponed-leaf walk: two slab tests, hit leaves queued, near child
-// next, far child pushed.  The twelve box planes and two links arrive by value so that the device
-// build can feed them from SGPRs (wave-uniform visit, scalar load) or VGPRs (divergent visit).
+// next, far child pushed.  The six plane words (Node32 order: child 0 in the low half, child 1 in
+// the high half) and two links arrive by value so that the device build can feed them from SGPRs
+// (wave-uniform visit, scalar load) or VGPRs (divergent visit).  Reference rule: the caller has
+// sorted them by the ray -- in* is the plane the ray enters a box through (lo where the direction
+// component is positive, hi where it is negative), out* the other: slab_sorted.  Parity rule:
+// in* = lo, out* = hi.
 template <bool PARITY, class Stack>
-DXV_HD void node_step(const Ray& r, float lo0x, float lo0y, float lo0z, float hi0x, float hi0y, float hi0z,
-                      float lo1x, float lo1y, float lo1z, float hi1x, float hi1y, float hi1z, int32_t c0, int32_t c1,
-                      const Stack& stk, int cap, float bestT, int32_t& node, int& sp, int& qn)
+DXV_HD void node_step(const Ray& r, uint32_t inx, uint32_t outx, uint32_t iny, uint32_t outy, uint32_t inz, uint32_t outz,
+                      int32_t c0, int32_t c1, const Stack& stk, int cap, float bestT, int32_t& node, int& sp, int& qn)
 {
     float tn0 = 0.0f, tn1 = 0.0f;
     bool h0, h1;
     if (PARITY) {
-        h0 = slab_parity(r, lo0y, lo0z, hi0x, hi0y, hi0z);
-        h1 = slab_parity(r, lo1y, lo1z, hi1x, hi1y, hi1z);
+        h0 = slab_parity(r, half_bits_to_float(iny & 0xffffu), half_bits_to_float(inz & 0xffffu), half_bits_to_float(outx & 0xffffu),
+                         half_bits_to_float(outy & 0xffffu), half_bits_to_float(outz & 0xffffu));
+        h1 = slab_parity(r, half_bits_to_float(iny >> 16), half_bits_to_float(inz >> 16), half_bits_to_float(outx >> 16),
+                         half_bits_to_float(outy >> 16), half_bits_to_float(outz >> 16));
     } else {
-        h0 = slab(r, lo0x, lo0y, lo0z, hi0x, hi0y, hi0z, tn0) && tn0 <= bestT;
-        h1 = slab(r, lo1x, lo1y, lo1z, hi1x, hi1y, hi1z, tn1) && tn1 <= bestT;
+        h0 = slab_sorted(r, half_bits_to_float(inx & 0xffffu), half_bits_to_float(iny & 0xffffu), half_bits_to_float(inz & 0xffffu),
+                         half_bits_to_float(outx & 0xffffu), half_bits_to_float(outy & 0xffffu),
+                         half_bits_to_float(outz & 0xffffu), tn0) && tn0 <= bestT;
+        h1 = slab_sorted(r, half_bits_to_float(inx >> 16), half_bits_to_float(iny >> 16), half_bits_to_float(inz >> 16),
+                         half_bits_to_float(outx >> 16), half_bits_to_float(outy >> 16), half_bits_to_float(outz >> 16), tn1) &&
+             tn1 <= bestT;
     }
     // (Unconditional stores to the next free slots + an unconditional pop were tried to get rid of
     // the exec-mask juggling around these small blocks: 15-20 % SLOWER on MI355X, the extra LDS
@@ -206,6 +226,18 @@ DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, c
     int sp = 1, qn = 0;
     bool ok = true;
     int32_t node = 0;
+    // The plane of each axis a box is entered through: hi where the direction is negative.  The
+    // radial direction has the signs of the origin (never zero); the parity ray enters through lo.
+    const bool negx = !PARITY && r.ox < 0.0f, negy = !PARITY && r.oy < 0.0f, negz = !PARITY && r.oz < 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // A brick lies in one octant of the grid unless it straddles a centre plane (grid sizes that
+    // are not a multiple of twice the brick): then the three choices are wave-uniform and a
+    // wave-uniform visit sorts the planes on the scalar unit as well.
+    const uint64_t active = __builtin_amdgcn_ballot_w64(true);
+    const uint64_t bx = __builtin_amdgcn_ballot_w64(negx), by = __builtin_amdgcn_ballot_w64(negy), bz = __builtin_amdgcn_ballot_w64(negz);
+    const bool octant = (bx == 0ull || bx == active) && (by == 0ull || by == active) && (bz == 0ull || bz == active);
+    const bool unx = bx != 0ull, uny = by != 0ull, unz = bz != 0ull;
+#endif
     for (;;) {
         // A step needs one free stack slot and two free queue slots: sp + qn + 3 <= cap.  The wave
         // flushes the queue whenever a queue is what is in the way (below), so no room here means
@@ -217,18 +249,18 @@ DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, c
             // all lanes that are still walking sit on the same node (40-50 % of the visits): one
             // scalar load instead of 64 lanes x 32 B through the vector L1
             const int32_t n0 = __builtin_amdgcn_readfirstlane(node);
-            if (__builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
+            if (octant && __builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
                 const NodeSgpr n = load_node_scalar(nodes, n0);
-                node_step<PARITY>(r, sgpr_half(n.w[0], 0), sgpr_half(n.w[0], 1), sgpr_half(n.w[0], 2), sgpr_half(n.w[0], 3),
-                                  sgpr_half(n.w[1], 0), sgpr_half(n.w[1], 1), sgpr_half(n.w[1], 2), sgpr_half(n.w[1], 3),
-                                  sgpr_half(n.w[2], 0), sgpr_half(n.w[2], 1), sgpr_half(n.w[2], 2), sgpr_half(n.w[2], 3),
+                const uint32_t xl = (uint32_t)n.w[0], xh = (uint32_t)(n.w[0] >> 32), yl = (uint32_t)n.w[1], yh = (uint32_t)(n.w[1] >> 32);
+                const uint32_t zl = (uint32_t)n.w[2], zh = (uint32_t)(n.w[2] >> 32);
+                node_step<PARITY>(r, unx ? xh : xl, unx ? xl : xh, uny ? yh : yl, uny ? yl : yh, unz ? zh : zl, unz ? zl : zh,
                                   (int32_t)(uint32_t)n.w[3], (int32_t)(uint32_t)(n.w[3] >> 32), stk, cap, bestT, node, sp, qn);
             } else
 #endif
             {
-                const NodePlanes n = load_node(nodes, node);
-                node_step<PARITY>(r, n.b[0], n.b[1], n.b[2], n.b[3], n.b[4], n.b[5], n.b[6], n.b[7], n.b[8], n.b[9], n.b[10],
-                                  n.b[11], n.c0, n.c1, stk, cap, bestT, node, sp, qn);
+                const NodeWords n = load_node_words(nodes, node);
+                node_step<PARITY>(r, negx ? n.w[1] : n.w[0], negx ? n.w[0] : n.w[1], negy ? n.w[3] : n.w[2], negy ? n.w[2] : n.w[3],
+                                  negz ? n.w[5] : n.w[4], negz ? n.w[4] : n.w[5], n.c0, n.c1, stk, cap, bestT, node, sp, qn);
             }
             if (STATS && (uint32_t)(sp - 1) > st->maxsp) st->maxsp = (uint32_t)(sp - 1);
         }

@@ -31,8 +31,11 @@ static_assert(sizeof(Node) == 64, "node is 64 B");
 // the slab test conservative (monotone under inclusion); the exact per-triangle box is
 // re-derived from the triangle's vertices when a leaf is tested, so results are unchanged while
 // a node visit moves half the bytes through the vector memory path (the measured limiter).
+// Plane order: one 32-bit word per (axis, side) holding child 0 in its low and child 1 in its high
+// half, so that picking the plane a ray ENTERS through (lo when the direction component is
+// positive, hi when negative) is one select per axis for both children (dxv_trace.h node_step).
 struct alignas(32) Node32 {
-    uint16_t b[12];                 // child 0: lo.xyz hi.xyz, child 1: lo.xyz hi.xyz
+    uint16_t b[12];                 // x: lo0 lo1 hi0 hi1, y: lo0 lo1 hi0 hi1, z: lo0 lo1 hi0 hi1
     int32_t c0, c1;
 };
 static_assert(sizeof(Node32) == 32, "compressed node is 32 B");
@@ -61,7 +64,7 @@ struct SceneHeader {
 static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
 
 constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
-constexpr uint32_t kSceneVersion = 2;
+constexpr uint32_t kSceneVersion = 3;
 
 // canonical constants (hlsl:5, :76-77)
 constexpr float kThreshold = 0.12f;

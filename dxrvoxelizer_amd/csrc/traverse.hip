@@ -155,9 +155,12 @@ __global__ __launch_bounds__(64) void k_parity_rows(VoxelizeParams p)
             oy, oz, oxMin,
             [&](int32_t i) {
                 const NodeSgpr n = load_node_scalar(sc.nodes, i);
-                NodePlanes q;
+                NodePlanes q;                           // Node32 is axis-major: {lo0 lo1 hi0 hi1} per axis
 #pragma unroll
-                for (int k = 0; k < 12; ++k) q.b[k] = sgpr_half(n.w[k >> 2], k & 3);
+                for (int a = 0; a < 3; ++a) {
+                    q.b[a] = sgpr_half(n.w[a], 0); q.b[6 + a] = sgpr_half(n.w[a], 1);
+                    q.b[3 + a] = sgpr_half(n.w[a], 2); q.b[9 + a] = sgpr_half(n.w[a], 3);
+                }
                 q.c0 = (int32_t)(uint32_t)n.w[3];
                 q.c1 = (int32_t)(uint32_t)(n.w[3] >> 32);
                 return q;

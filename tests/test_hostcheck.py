@@ -136,6 +136,8 @@ def test_compressed_nodes_contain_exact_boxes(orc, hostcheck, dragon):
     exact = h.nodes()[:, :12].view(np.float32)
     packed = h.nodes32()
     halves = packed[:, :6].copy().view(np.uint16).view(np.float16).astype(np.float32).reshape(-1, 12)
+    # Node32 is axis-major {lo0 lo1 hi0 hi1} x 3; the exact node is child-major lo.xyz hi.xyz x 2
+    halves = halves.reshape(-1, 3, 2, 2).transpose(0, 3, 2, 1).reshape(-1, 12)
     assert np.array_equal(packed[:, 6:8], h.nodes()[:, 12:14])     # links unchanged
     for c in (0, 6):
         assert np.all(halves[:, c:c + 3] <= exact[:, c:c + 3]) and np.all(halves[:, c + 3:c + 6] >= exact[:, c + 3:c + 6])
