@@ -15,6 +15,7 @@
 using namespace dxv;
 
 namespace {
+constexpr uint32_t kRedoCap = 1u << 16;   // rays per launch the redo pass takes before the column is grown instead
 thread_local std::string g_createError;
 
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -55,7 +56,10 @@ struct dxv_ctx {
     uint32_t* dTexels = nullptr;
     size_t texelCap = 0;
     bool texels = false;
-    uint32_t* dStatus = nullptr;
+    uint32_t* dStatus = nullptr;     // [0] status bits, [1], [2] redo-list counters (alternating launches)
+    uint64_t* dRedo = nullptr;       // voxels whose LDS column was too small, finished by the redo pass
+    uint32_t redoParity = 0;
+    int lastRedoParity = -1;         // counter of the last launch (-1: that launch has none)
     unsigned long long* dCount = nullptr;
     uint8_t* dPacked = nullptr;
     size_t packedCap = 0;
@@ -73,6 +77,8 @@ struct dxv_ctx {
     int optMorton = 1;       // Morton brick order
     int optQueue = 1;        // postponed-leaf traversal
     int optSubbox = 1;       // launch only the bricks around the scene's root box, memset the rest
+    int optWide = 0;         // reference rule: walk the wide (up to 4 boxes) nodes; measured -8 % on low-poly meshes,
+                             // +10 % on 1 M triangles at 256^3, so off unless asked for
     int optRows = 1;         // parity mode: one tree walk per grid row (k_parity_rows) instead of per voxel
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
     int optStack0 = 20;      // adaptive mode starts with this many entries (stack + leaf queue share them)
@@ -103,6 +109,7 @@ int fail(dxv_ctx* c, const char* fmt, ...)
 
 Node* scene_nodes(dxv_ctx* c) { return reinterpret_cast<Node*>(c->dScene + c->hdr.offNodes); }
 Node32* scene_nodes32(dxv_ctx* c) { return reinterpret_cast<Node32*>(c->dScene + c->hdr.offNodes32); }
+Node64* scene_nodes64(dxv_ctx* c) { return reinterpret_cast<Node64*>(c->dScene + c->hdr.offNodes64); }
 TriPos* scene_tripos(dxv_ctx* c) { return reinterpret_cast<TriPos*>(c->dScene + c->hdr.offTriPos); }
 TriNrm* scene_trinrm(dxv_ctx* c) { return reinterpret_cast<TriNrm*>(c->dScene + c->hdr.offTriNrm); }
 
@@ -116,7 +123,8 @@ void layout_scene(SceneHeader& h, uint32_t T, uint32_t V)
     h.numNodes = T > 1 ? T - 1 : 1;
     h.offNodes = align256(sizeof(SceneHeader));
     h.offNodes32 = align256(h.offNodes + sizeof(Node) * (size_t)h.numNodes);
-    h.offTriPos = align256(h.offNodes32 + sizeof(Node32) * (size_t)h.numNodes);
+    h.offNodes64 = align256(h.offNodes32 + sizeof(Node32) * (size_t)h.numNodes);
+    h.offTriPos = align256(h.offNodes64 + sizeof(Node64) * (size_t)h.numNodes);
     h.offTriNrm = align256(h.offTriPos + sizeof(TriPos) * (size_t)T);
     h.totalBytes = align256(h.offTriNrm + sizeof(TriNrm) * (size_t)T);
 }
@@ -167,15 +175,27 @@ float elapsed(hipEvent_t a, hipEvent_t b)
 // re-runs the launch with the next larger depth (up to the always-sufficient one) and keeps it for
 // this scene.
 // (+3: the postponed-leaf traversal keeps room for one push and two queued leaves)
-int safe_stack(const dxv_ctx* c) { return stack_round_up((int)c->hdr.treeHeight + 3); }
+// The wide walk pushes up to three entries per wide level (two binary levels) and keeps room for
+// four more slots: 3 * ceil(h / 2) + 5.  Trees too deep for the largest column use the binary walk.
+bool use_wide(const dxv_ctx* c, int mode)
+{
+    const int need = 3 * (((int)c->hdr.treeHeight + 1) / 2) + 5;
+    return mode == DXV_MODE_REFERENCE && c->optWide && c->optQueue && need <= 64;
+}
+int safe_stack(const dxv_ctx* c)
+{
+    if (use_wide(c, c->lastMode)) return stack_round_up(3 * (((int)c->hdr.treeHeight + 1) / 2) + 5);
+    return stack_round_up((int)c->hdr.treeHeight + 3);
+}
 
 int launch_now(dxv_ctx* c)
 {
     VoxelizeParams p{};
-    p.scene.nodes = scene_nodes32(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
+    p.scene.nodes = scene_nodes32(c); p.scene.wide = scene_nodes64(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
     memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
     p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
+    p.redo = c->dRedo; p.redoCap = kRedoCap; p.redoParity = c->redoParity;
     p.N = c->stats.grid_dim; p.z0 = c->stats.z0; p.nz = c->stats.nz; p.mode = c->lastMode;
     p.zBlock = c->lastZBlock; p.zPeriod = c->lastZPeriod;
     p.zShift = 0;
@@ -184,11 +204,19 @@ int launch_now(dxv_ctx* c)
     p.regionBits = (uint32_t)c->optRegion;
     p.queued = (uint32_t)c->optQueue;
     p.subbox = (uint32_t)c->optSubbox;
+    p.wide = use_wide(c, p.mode) ? 1u : 0u;
     const int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
-    if (p.mode == DXV_MODE_PARITY && c->optRows) DXV_HIP(c, launch_parity_rows(p, c->stream));
-    else DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
+    if (p.mode == DXV_MODE_PARITY && c->optRows) {
+        DXV_HIP(c, launch_parity_rows(p, c->stream));
+        c->lastRedoParity = -1;
+    } else {
+        DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
+        DXV_HIP(c, launch_voxelize_redo(p, c->stream));
+        c->lastRedoParity = (int)c->redoParity;
+        c->redoParity ^= 1u;
+    }
     DXV_HIP(c, hipEventRecord(c->ev[6], c->stream));
     c->pending = true;
     return 0;
@@ -219,6 +247,7 @@ int dxv_create(dxv_ctx** out, int device)
         if (hipEventCreate(&ev) != hipSuccess) { delete c; return fail(nullptr, "dxv_create: hipEventCreate failed"); }
     }
     if (hipMalloc(&c->dStatus, 256) != hipSuccess || hipMalloc(&c->dCount, 256) != hipSuccess ||
+        hipMalloc(&c->dRedo, sizeof(uint64_t) * kRedoCap) != hipSuccess ||
         hipMalloc(&c->dRootInfo, 256) != hipSuccess) {
         delete c;
         return fail(nullptr, "dxv_create: hipMalloc failed");
@@ -236,7 +265,7 @@ void dxv_destroy(dxv_ctx* c)
     free_scratch(c);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene); (void)hipFree(c->dGrid);
     (void)hipFree(c->dImage);
-    (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
+    (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dRedo); (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -307,7 +336,7 @@ void fill_build_buffers(dxv_ctx* c, BuildBuffers& b)
     memcpy(b.bound, c->bound, sizeof(c->bound));
     b.keys = c->dKeys; b.keysTmp = c->dKeysTmp; b.hist = c->dHist; b.parents = c->dParents;
     b.flags = c->dFlags; b.flags2 = c->dFlags2; b.rootInfo = c->dRootInfo;
-    b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
+    b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.nodes64 = scene_nodes64(c); b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
 }
 
 int finish_build(dxv_ctx* c, const char* who)
@@ -439,10 +468,14 @@ int dxv_sync(dxv_ctx* c)
     if (!c) return 1;
     DXV_HIP(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 8; ++attempt) {
-        uint32_t status = 0;
-        DXV_HIP(c, hipMemcpyAsync(&status, c->dStatus, sizeof(status), hipMemcpyDeviceToHost, c->stream));
+        uint32_t words[3] = {0, 0, 0};
+        DXV_HIP(c, hipMemcpyAsync(words, c->dStatus, sizeof(words), hipMemcpyDeviceToHost, c->stream));
         DXV_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->pending) c->stats.voxelize_ms = elapsed(c->ev[5], c->ev[6]);
+        const uint32_t status = words[0];
+        if (c->pending) {
+            c->stats.voxelize_ms = elapsed(c->ev[5], c->ev[6]);
+            c->stats.redo_rays = c->lastRedoParity < 0 ? 0u : words[1 + c->lastRedoParity];
+        }
         c->pending = false;
         if (!status) return 0;
         DXV_HIP(c, hipMemsetAsync(c->dStatus, 0, sizeof(uint32_t), c->stream));
@@ -586,7 +619,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     SceneHeader want;
     layout_scene(want, h.numTris, h.numVerts);
     if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
-        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.treeHeight == 0 || h.treeHeight > 64)
+        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.treeHeight == 0 || h.treeHeight > 64)
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     c->haveScene = false;
     if (alloc_scene(c, h.numTris, h.numVerts)) return 1;
@@ -626,6 +659,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "subbox")) {
         if (value != 0 && value != 1) return fail(c, "option subbox: %lld not in {0,1}", (long long)value);
         c->optSubbox = (int)value;
+    } else if (!strcmp(key, "wide")) {
+        if (value != 0 && value != 1) return fail(c, "option wide: %lld not in {0,1}", (long long)value);
+        c->optWide = (int)value;
     } else if (!strcmp(key, "rows")) {
         if (value != 0 && value != 1) return fail(c, "option rows: %lld not in {0,1}", (long long)value);
         c->optRows = (int)value;
@@ -657,6 +693,7 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     case DXV_DBG_PARENTS: src = c->dParents; want = sizeof(uint32_t) * (2 * T - 1); if (c->scratchT != c->T) src = nullptr; break;
     case DXV_DBG_NODES: if (c->haveScene) { src = scene_nodes(c); want = sizeof(Node) * (size_t)c->hdr.numNodes; } break;
     case DXV_DBG_NODES32: if (c->haveScene) { src = scene_nodes32(c); want = sizeof(Node32) * (size_t)c->hdr.numNodes; } break;
+    case DXV_DBG_NODES64: if (c->haveScene) { src = scene_nodes64(c); want = sizeof(Node64) * (size_t)c->hdr.numNodes; } break;
     case DXV_DBG_TRI_POS: if (c->haveScene) { src = scene_tripos(c); want = sizeof(TriPos) * T; } break;
     case DXV_DBG_TRI_NRM: if (c->haveScene) { src = scene_trinrm(c); want = sizeof(TriNrm) * T; } break;
     default: return fail(c, "dxv_debug_download: unknown selector %d", what);

@@ -26,6 +26,7 @@ struct BuildBuffers {
     uint32_t* rootInfo;     // 8 words: rootLo[3], rootHi[3] (float bits), height, done
     Node* nodes;            // max(T-1,1), exact boxes
     Node32* nodes32;        // max(T-1,1), traversal copy
+    Node64* nodes64;        // max(T-1,1), wide traversal copy
     TriPos* triPos;         // T
     TriNrm* triNrm;         // T
 };
@@ -39,7 +40,11 @@ struct VoxelizeParams {
     SceneView scene;
     uint8_t* grid;          // N*N*nz bytes
     uint32_t* texels;       // optional N*N*nz words
-    uint32_t* status;       // status word (bit 0: traversal stack overflow)
+    uint32_t* status;       // status[0] bit 0: a ray could not be finished (redo list full, or the redo pass itself ran out)
+                            // status[1 + parity], status[2 - parity]: rays on the redo list of this / the next launch
+    uint64_t* redo;         // voxel ids (local index into grid) whose LDS column was too small: finished by k_voxelize_redo
+    uint32_t redoCap;       // entries of `redo`
+    uint32_t redoParity;    // which of the two counters this launch appends to
     uint32_t N, z0, nz;     // nz = slices written by this launch (local index lz in [0, nz))
     uint32_t zBlock, zPeriod; // global slice of lz: z0 + (lz / zBlock) * zPeriod + lz % zBlock
     uint32_t zShift;          // log2(zBlock) when the partition is block-cyclic (zBlock is a power of two)
@@ -52,8 +57,10 @@ struct VoxelizeParams {
     uint32_t regionBits;    // log2 of the bricks per XCD region
     uint32_t queued;        // 1: postponed-leaf traversal (default), 0: leaves tested on the spot
     uint32_t subbox;        // 1: launch only bricks the root early-out cannot clear (default)
+    uint32_t wide;          // 1: reference rule walks the wide nodes (default when the stack bound allows)
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
+hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack
 int stack_round_up(int want);
 hipError_t launch_parity_rows(const VoxelizeParams& p, hipStream_t s);   // parity mode, one tree walk per row run
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);

@@ -367,6 +367,36 @@ DXV_HD Node32 compress_node(const Node& n)
     return c;
 }
 
+// Wide node of binary node i (dxv_types.h Node64).  `nodes` are the refitted exact nodes.
+DXV_HD Node64 widen_node(const Node* nodes, int32_t i)
+{
+    Node64 w;
+    int slot = 0;
+    auto emit = [&](const float* box, int32_t link) {      // box = lo.xyz hi.xyz
+        for (int a = 0; a < 3; ++a) {
+            w.b[a * 8 + slot] = half_down(box[a]);
+            w.b[a * 8 + 4 + slot] = half_up(box[3 + a]);
+        }
+        w.c[slot++] = link;
+    };
+    const Node n = nodes[i];
+    const float* nb = reinterpret_cast<const float*>(&n);  // child 0: floats 0..5, child 1: floats 6..11
+    const int32_t link[2] = {n.c0, n.c1};
+    for (int side = 0; side < 2; ++side) {
+        if (link[side] >= 0) {
+            const Node m = nodes[link[side]];
+            const float* mb = reinterpret_cast<const float*>(&m);
+            emit(mb, m.c0);
+            emit(mb + 6, m.c1);
+        } else emit(nb + 6 * side, link[side]);
+    }
+    for (; slot < 4; ++slot) {
+        for (int a = 0; a < 3; ++a) { w.b[a * 8 + slot] = 0x7c00u; w.b[a * 8 + 4 + slot] = 0xfc00u; }   // [+inf, -inf]
+        w.c[slot] = kNoChild;
+    }
+    return w;
+}
+
 // ------------------------------------------------------------------------------------------
 // Morton keys (30 bits over the centre of the padded box) and the Karras 2012 hierarchy rule.
 // Keys are (morton << 32) | triangle index: unique, so the tree is deterministic.

@@ -130,7 +130,7 @@ DXV_HD bool trace_reference(Ray& r, const Node32* nodes, const TriPos* tris, con
         if (both) {
             if (sp >= cap) { ok = false; break; }
             stk.put(sp++, swap ? c0 : c1);
-            if (STATS && (uint32_t)(sp - 1) > st->maxsp) st->maxsp = (uint32_t)(sp - 1);
+            if (STATS && sp - 1 > (int)st->maxsp) st->maxsp = (uint32_t)(sp - 1);
         }
         if (h0 || h1) node = (h0 && !(both && swap)) ? c0 : c1;
         else node = stk.get(--sp);
@@ -262,7 +262,7 @@ DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, c
                 node_step<PARITY>(r, negx ? n.w[1] : n.w[0], negx ? n.w[0] : n.w[1], negy ? n.w[3] : n.w[2], negy ? n.w[2] : n.w[3],
                                   negz ? n.w[5] : n.w[4], negz ? n.w[4] : n.w[5], n.c0, n.c1, stk, cap, bestT, node, sp, qn);
             }
-            if (STATS && (uint32_t)(sp - 1) > st->maxsp) st->maxsp = (uint32_t)(sp - 1);
+            if (STATS && sp - 1 > (int)st->maxsp) st->maxsp = (uint32_t)(sp - 1);
         }
         const bool walking = wave_any(node >= 0);
         if (walking && !wave_any(sp + qn + 3 > cap && qn > 0)) continue;
@@ -316,6 +316,133 @@ DXV_HD bool trace_reference_q(Ray& r, const Node32* nodes, const TriPos* tris, c
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
     return walk_queued<false, Stack, LeafReference, STATS>(r, nodes, tris, stk, cap, best.t, LeafReference{r, best}, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same walk over the WIDE nodes (dxv_types.h Node64): up to four boxes per visit, so a ray
+// waits for half as many dependent node fetches.  A visit queues the leaves it hits, goes on
+// with the nearest internal child it hits and pushes the others (their order does not change the
+// result and, measured, not the number of visits either).  Each of the four children ends up in
+// at most one slot of the column, so a step needs sp + qn + 4 < cap.
+// Plane words arrive as 64-bit pairs {children 0,1 | children 2,3}, already sorted by the ray.
+// ------------------------------------------------------------------------------------------
+constexpr int kWideRoom = 5;
+
+template <class Stack>
+DXV_HD void wide_step(const Ray& r, uint64_t inx, uint64_t outx, uint64_t iny, uint64_t outy, uint64_t inz, uint64_t outz,
+                      int32_t c0, int32_t c1, int32_t c2, int32_t c3, const Stack& stk, int cap, float bestT, int32_t& node,
+                      int& sp, int& qn)
+{
+    const int32_t c[4] = {c0, c1, c2, c3};
+    float key[4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+        float tn;
+        const bool h = slab_sorted(r, half_bits_to_float((uint32_t)(inx >> (16 * k)) & 0xffffu),
+                                   half_bits_to_float((uint32_t)(iny >> (16 * k)) & 0xffffu),
+                                   half_bits_to_float((uint32_t)(inz >> (16 * k)) & 0xffffu),
+                                   half_bits_to_float((uint32_t)(outx >> (16 * k)) & 0xffffu),
+                                   half_bits_to_float((uint32_t)(outy >> (16 * k)) & 0xffffu),
+                                   half_bits_to_float((uint32_t)(outz >> (16 * k)) & 0xffffu), tn) &&
+                       tn <= bestT;
+        if (h && c[k] < 0) stk.put(cap - 1 - qn++, ~c[k]);                  // leaf: postponed
+        key[k] = (h && c[k] >= 0) ? tn : __builtin_inff();                  // internal: entry distance
+    }
+    int32_t next = c[0];
+    float nearest = key[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 1; k < 4; ++k)
+        if (key[k] < nearest) { nearest = key[k]; next = c[k]; }
+    if (nearest < __builtin_inff()) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < 4; ++k)
+            if (key[k] < __builtin_inff() && c[k] != next) stk.put(sp++, c[k]);   // links of one node are distinct
+        node = next;
+    } else node = stk.get(--sp);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+struct WideSgpr { uint64_t w[8]; };
+__device__ __forceinline__ WideSgpr load_wide_scalar(const Node64* nodes, int32_t uniformIndex)
+{
+    const char* p = reinterpret_cast<const char*>(nodes) + ((uint64_t)(uint32_t)uniformIndex << 6);
+    WideSgpr n;
+    asm volatile("s_load_dwordx2 %0, %8, 0x0\n\ts_load_dwordx2 %1, %8, 0x8\n\ts_load_dwordx2 %2, %8, 0x10\n\t"
+                 "s_load_dwordx2 %3, %8, 0x18\n\ts_load_dwordx2 %4, %8, 0x20\n\ts_load_dwordx2 %5, %8, 0x28\n\t"
+                 "s_load_dwordx2 %6, %8, 0x30\n\ts_load_dwordx2 %7, %8, 0x38\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(n.w[0]), "=&s"(n.w[1]), "=&s"(n.w[2]), "=&s"(n.w[3]), "=&s"(n.w[4]), "=&s"(n.w[5]), "=&s"(n.w[6]),
+                   "=&s"(n.w[7])
+                 : "s"(p) : "memory");
+    return n;
+}
+#endif
+
+template <class Stack, class Leaf, bool STATS = false>
+DXV_HD bool walk_queued_wide(const Ray& r, const Node64* nodes, const TriPos* tris, const Stack& stk, int cap, const float& bestT,
+                             Leaf&& leaf, TraceStats* st = nullptr)
+{
+    stk.put(0, -1);
+    int sp = 1, qn = 0;
+    bool ok = true;
+    int32_t node = 0;
+    const bool negx = r.ox < 0.0f, negy = r.oy < 0.0f, negz = r.oz < 0.0f;   // as in walk_queued
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t active = __builtin_amdgcn_ballot_w64(true);
+    const uint64_t bx = __builtin_amdgcn_ballot_w64(negx), by = __builtin_amdgcn_ballot_w64(negy), bz = __builtin_amdgcn_ballot_w64(negz);
+    const bool octant = (bx == 0ull || bx == active) && (by == 0ull || by == active) && (bz == 0ull || bz == active);
+    const bool unx = bx != 0ull, uny = by != 0ull, unz = bz != 0ull;
+#endif
+    for (;;) {
+        if (node >= 0 && sp + qn + kWideRoom > cap) { ok = false; node = -1; }
+        if (node >= 0) {
+            if (STATS) st->nodes++;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int32_t n0 = __builtin_amdgcn_readfirstlane(node);
+            if (octant && __builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
+                const WideSgpr n = load_wide_scalar(nodes, n0);
+                wide_step(r, unx ? n.w[1] : n.w[0], unx ? n.w[0] : n.w[1], uny ? n.w[3] : n.w[2], uny ? n.w[2] : n.w[3],
+                          unz ? n.w[5] : n.w[4], unz ? n.w[4] : n.w[5], (int32_t)(uint32_t)n.w[6], (int32_t)(uint32_t)(n.w[6] >> 32),
+                          (int32_t)(uint32_t)n.w[7], (int32_t)(uint32_t)(n.w[7] >> 32), stk, cap, bestT, node, sp, qn);
+            } else
+#endif
+            {
+                const uint64_t* p = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(nodes) + ((uint32_t)node << 6));
+                struct alignas(16) U2 { uint64_t a, b; };
+                const U2 x = *reinterpret_cast<const U2*>(p), y = *reinterpret_cast<const U2*>(p + 2);
+                const U2 z = *reinterpret_cast<const U2*>(p + 4), l = *reinterpret_cast<const U2*>(p + 6);
+                wide_step(r, negx ? x.b : x.a, negx ? x.a : x.b, negy ? y.b : y.a, negy ? y.a : y.b, negz ? z.b : z.a,
+                          negz ? z.a : z.b, (int32_t)(uint32_t)l.a, (int32_t)(uint32_t)(l.a >> 32), (int32_t)(uint32_t)l.b,
+                          (int32_t)(uint32_t)(l.b >> 32), stk, cap, bestT, node, sp, qn);
+            }
+            if (STATS && sp - 1 > (int)st->maxsp) st->maxsp = (uint32_t)(sp - 1);
+        }
+        const bool walking = wave_any(node >= 0);
+        if (walking && !wave_any(sp + qn + kWideRoom > cap && qn > 0)) continue;
+        for (int i = 0; wave_any(i < qn); ++i) {
+            if (i < qn) {
+                const int32_t l = stk.get(cap - 1 - i);
+                if (STATS) st->leaves++;
+                leaf(l, load_tri(tris, l));
+            }
+        }
+        qn = 0;
+        if (!walking) break;
+    }
+    return ok;
+}
+
+template <class Stack, bool STATS = false>
+DXV_HD bool trace_reference_w(Ray& r, const Node64* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
+                              TraceStats* st = nullptr)
+{
+    best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
+    return walk_queued_wide<Stack, LeafReference, STATS>(r, nodes, tris, stk, cap, best.t, LeafReference{r, best}, st);
 }
 
 template <class Stack>
@@ -375,11 +502,14 @@ struct SceneView {
     const TriPos* triPos;
     const TriNrm* triNrm;
     float rootLo[3], rootHi[3];
+    const Node64* wide;     // wide copy of `nodes` (reference rule, WALK 2)
 };
 
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
-template <bool QUEUED, class Stack>
+// WALK: 0 = leaves tested as they are met, 1 = postponed-leaf walk, 2 = postponed-leaf walk over the
+// wide nodes.  All three return the same voxel.
+template <int WALK, class Stack>
 DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
                                const Stack& stk, int cap, uint32_t* texel, bool& overflow)
 {
@@ -389,8 +519,9 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
     finish_ray_reference(r);
     Hit best;
-    const bool ok = QUEUED ? trace_reference_q(r, sc.nodes, sc.triPos, stk, cap, best)
-                           : trace_reference(r, sc.nodes, sc.triPos, stk, cap, best);
+    const bool ok = WALK == 2 ? trace_reference_w(r, sc.wide, sc.triPos, stk, cap, best)
+                  : WALK == 1 ? trace_reference_q(r, sc.nodes, sc.triPos, stk, cap, best)
+                              : trace_reference(r, sc.nodes, sc.triPos, stk, cap, best);
     if (!ok) { overflow = true; return 0; }
     if (best.k == 0xffffffffu) return 0;                                         // missMain
     const TriNrm tn = sc.triNrm[best.leaf];

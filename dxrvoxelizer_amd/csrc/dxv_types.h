@@ -40,6 +40,21 @@ struct alignas(32) Node32 {
 };
 static_assert(sizeof(Node32) == 32, "compressed node is 32 B");
 
+// Wide traversal node (reference rule): binary node i with each INTERNAL child replaced by that
+// child's two children -- up to four boxes per visit, half the dependent fetches per ray (the
+// walk waits on those, not on arithmetic).  Same outward-rounded half planes, same axis-major
+// order as Node32: b[axis * 8 + side * 4 + child], i.e. twelve words {child 0 | child 1},
+// {child 2 | child 3} per (axis, side).  Links: >= 0 binary node index (whose wide node is entry
+// i of the same array), < 0 ~leaf.  Unused slots carry an inverted box (lo = +inf, hi = -inf: no
+// ray passes the slab test) and kNoChild.  Entries of binary nodes that were absorbed into their
+// parent are never reached.
+struct alignas(64) Node64 {
+    uint16_t b[24];
+    int32_t c[4];
+};
+static_assert(sizeof(Node64) == 64, "wide node is 64 B");
+constexpr int32_t kNoChild = (int32_t)0x80000000;
+
 // Leaf payload in Morton order.  Positions are pre-mapped to the reference's normalised space
 // p' = (p - c) / w (Content/Voxelizer.cpp:304-306).  v0.w carries the triangle's index in the
 // caller's index buffer (PrimitiveIndex(), hlsl:93) as raw bits.
@@ -47,7 +62,7 @@ struct alignas(16) TriPos { F4 v0, v1, v2; };
 // Vertex normals of the same triangle (hlsl:102-107, :114-116), fetched once per ray at the end.
 struct alignas(16) TriNrm { F4 n0, n1, n2; };
 
-// Relocatable scene blob: [SceneHeader | nodes | nodes32 | triPos | triNrm], sections 256-B aligned.
+// Relocatable scene blob: [SceneHeader | nodes | nodes32 | nodes64 | triPos | triNrm], sections 256-B aligned.
 struct SceneHeader {
     uint32_t magic;       // 'DXVS'
     uint32_t version;
@@ -59,12 +74,13 @@ struct SceneHeader {
     float rootLo[3], rootHi[3];
     uint64_t offNodes, offTriPos, offTriNrm, totalBytes;
     uint64_t offNodes32;
-    uint32_t pad[30];
+    uint64_t offNodes64;
+    uint32_t pad[28];
 };
 static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
 
 constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
-constexpr uint32_t kSceneVersion = 3;
+constexpr uint32_t kSceneVersion = 4;
 
 // canonical constants (hlsl:5, :76-77)
 constexpr float kThreshold = 0.12f;

@@ -8,6 +8,7 @@
 //   K3  k_hierarchy    Karras 2012, one thread per internal node, parent links
 //   K4  k_refit_*      bottom-up box merge; a node stores the boxes of BOTH children
 //   K5  k_compress_nodes  32-B traversal copy of every node (outward-rounded half-float boxes)
+//   K6  k_widen_nodes  64-B wide traversal copy: up to four boxes per node (reference rule)
 //
 // All kernels are HBM-streaming integer/float work: one thread per element, 16-B accesses where
 // the layout allows, no LDS needed outside the sort.
@@ -183,6 +184,14 @@ __global__ __launch_bounds__(kThreads) void k_compress_nodes(const Node* __restr
     if (i < n) out[i] = compress_node(nodes[i]);
 }
 
+// K6: wide traversal copy (dxv_types.h Node64): every binary node with its internal children
+// replaced by their children.  A pure gather from the refitted nodes, so a refit only re-runs it.
+__global__ __launch_bounds__(kThreads) void k_widen_nodes(const Node* __restrict__ nodes, uint32_t n, Node64* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) out[i] = widen_node(nodes, (int32_t)i);
+}
+
 // rootInfo: lo[3], hi[3] (float bits), height of the root, 1
 __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict__ rootInfo,
                             const uint32_t* __restrict__ rootReady)
@@ -239,6 +248,7 @@ static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t 
         }
     }
     k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes64);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, rootReadyFlag);
     return hipGetLastError();
 }

@@ -33,7 +33,8 @@ __device__ __forceinline__ uint32_t compact1by2(uint32_t x)
     return x;
 }
 
-template <class B, int STACK, int MODE, bool TEXELS, bool QUEUED>
+// WALK: 0 = leaves tested as met, 1 = postponed-leaf walk, 2 = the same over the wide nodes (MODE 0)
+template <class B, int STACK, int MODE, bool TEXELS, int WALK>
 __global__ __launch_bounds__(B::threads, 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs
 {
     __shared__ int32_t stack[STACK * B::threads];
@@ -74,13 +75,58 @@ __global__ __launch_bounds__(B::threads, 8) void k_voxelize(VoxelizeParams p)   
     uint8_t occ;
     if (MODE == 0) {
         uint32_t texel = 0;
-        occ = voxel_reference<QUEUED>(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
+        occ = voxel_reference<WALK>(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
         if (TEXELS) p.texels[id] = texel;
     } else {
-        occ = voxel_parity<QUEUED>(p.scene, N, ix, iy, iz, stk, STACK, overflow);
+        occ = voxel_parity<WALK != 0>(p.scene, N, ix, iy, iz, stk, STACK, overflow);
     }
-    if (overflow) atomicOr(p.status, 1u);
+    if (overflow) {
+        // this ray needs a deeper column than the launch has: hand the voxel to k_voxelize_redo
+        const uint32_t slot = atomicAdd(p.status + 1 + p.redoParity, 1u);
+        if (slot < p.redoCap) p.redo[slot] = (uint64_t)id;
+        else atomicOr(p.status, 1u);
+    }
     p.grid[id] = occ;
+}
+
+// The rays whose LDS column was too small in k_voxelize (a few per million: DESIGN.md), one per
+// lane with a column of kRedoStack entries -- enough for any tree the builder makes (height <= 62).
+// Plain binary walk, leaves tested where they are met; same voxel as every other walk.
+constexpr int kRedoStack = 64;
+template <int MODE, bool TEXELS>
+__global__ __launch_bounds__(64) void k_voxelize_redo(VoxelizeParams p)
+{
+    __shared__ int32_t stack[kRedoStack * 64];
+    const uint32_t mine = 1u + p.redoParity, other = 2u - p.redoParity;
+    uint32_t count = p.status[mine];
+    if (count > p.redoCap) count = p.redoCap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.status[other] = 0;      // the next launch appends there
+    const StridedStack stk{stack + threadIdx.x, 64};
+    const uint64_t plane = (uint64_t)p.N * p.N;
+    for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < count; i += gridDim.x * 64u) {
+        const uint64_t id = p.redo[i];
+        const uint32_t lz = (uint32_t)(id / plane), rem = (uint32_t)(id % plane), iy = rem / p.N, ix = rem % p.N;
+        const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
+        bool overflow = false;
+        uint8_t occ;
+        if (MODE == 0) {
+            uint32_t texel = 0;
+            occ = voxel_reference<0>(p.scene, p.N, ix, iy, iz, stk, kRedoStack, TEXELS ? &texel : nullptr, overflow);
+            if (TEXELS) p.texels[id] = texel;
+        } else occ = voxel_parity<false>(p.scene, p.N, ix, iy, iz, stk, kRedoStack, overflow);
+        if (overflow) atomicOr(p.status, 1u);
+        p.grid[id] = occ;
+    }
+}
+
+hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s)
+{
+    const dim3 g(128), b(64);
+    if (p.mode == 0) {
+        if (p.texels) k_voxelize_redo<0, true><<<g, b, 0, s>>>(p);
+        else k_voxelize_redo<0, false><<<g, b, 0, s>>>(p);
+    } else k_voxelize_redo<1, false><<<g, b, 0, s>>>(p);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -296,12 +342,15 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 g((uint32_t)grid), b(B::threads);
     if (p.mode == 0) {
-        if (p.texels) k_voxelize<B, STACK, 0, true, true><<<g, b, 0, s>>>(p);
-        else if (p.queued) k_voxelize<B, STACK, 0, false, true><<<g, b, 0, s>>>(p);
-        else k_voxelize<B, STACK, 0, false, false><<<g, b, 0, s>>>(p);
+        if (p.texels) {
+            if (p.wide) k_voxelize<B, STACK, 0, true, 2><<<g, b, 0, s>>>(p);
+            else k_voxelize<B, STACK, 0, true, 1><<<g, b, 0, s>>>(p);
+        } else if (p.wide) k_voxelize<B, STACK, 0, false, 2><<<g, b, 0, s>>>(p);
+        else if (p.queued) k_voxelize<B, STACK, 0, false, 1><<<g, b, 0, s>>>(p);
+        else k_voxelize<B, STACK, 0, false, 0><<<g, b, 0, s>>>(p);
     } else {
-        if (p.queued) k_voxelize<B, STACK, 1, false, true><<<g, b, 0, s>>>(p);
-        else k_voxelize<B, STACK, 1, false, false><<<g, b, 0, s>>>(p);
+        if (p.queued) k_voxelize<B, STACK, 1, false, 1><<<g, b, 0, s>>>(p);
+        else k_voxelize<B, STACK, 1, false, 0><<<g, b, 0, s>>>(p);
     }
     return hipGetLastError();
 }

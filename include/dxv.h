@@ -40,7 +40,8 @@ enum {
     DXV_DBG_TRI_POS = 2,     /* T x 48 B: 3 x {x,y,z,w}; w of vertex 0 = triangle index bits  */
     DXV_DBG_TRI_NRM = 3,     /* T x 48 B: 3 x {nx,ny,nz,0}                                    */
     DXV_DBG_PARENTS = 4,     /* (T-1) internal + T leaf parent words: (parent << 1) | side    */
-    DXV_DBG_NODES32 = 5      /* max(T-1,1) x 32 B traversal nodes (half-float boxes)          */
+    DXV_DBG_NODES32 = 5,     /* max(T-1,1) x 32 B traversal nodes (half-float boxes)          */
+    DXV_DBG_NODES64 = 6      /* max(T-1,1) x 64 B wide traversal nodes (up to 4 boxes each)   */
 };
 
 typedef struct dxv_stats {
@@ -52,7 +53,8 @@ typedef struct dxv_stats {
     uint32_t grid_dim, z0, nz; /* last dxv_voxelize                                            */
     uint32_t stack_entries;  /* LDS traversal stack entries per thread of the last launch      */
     float render_ms;         /* last dxv_render kernel, HIP events                                  */
-    uint32_t reserved[6];
+    uint32_t redo_rays;      /* rays of the last launch finished by the deep-stack redo pass       */
+    uint32_t reserved[5];
 } dxv_stats;
 
 /* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that

@@ -112,6 +112,7 @@ def hostcheck():
     L.hc_scene_nodes.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_scene_keys.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_scene_nodes32.argtypes = [C.c_void_p, C.c_void_p]
+    L.hc_scene_nodes64.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_half_down.argtypes = [C.c_float]
     L.hc_half_down.restype = C.c_uint32
     L.hc_half_up.argtypes = [C.c_float]
@@ -144,6 +145,11 @@ def hostcheck():
         def nodes32(self):
             out = np.empty((max(self.T - 1, 1), 8), np.uint32)
             L.hc_scene_nodes32(self.h, out.ctypes.data_as(C.c_void_p))
+            return out
+
+        def nodes64(self):
+            out = np.empty((max(self.T - 1, 1), 16), np.uint32)
+            L.hc_scene_nodes64(self.h, out.ctypes.data_as(C.c_void_p))
             return out
 
         def keys(self):

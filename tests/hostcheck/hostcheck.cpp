@@ -25,6 +25,7 @@ struct HcScene {
     std::vector<uint64_t> keys;
     std::vector<Node> nodes;
     std::vector<Node32> nodes32;
+    std::vector<Node64> nodes64;
     std::vector<TriPos> triPos;
     std::vector<TriNrm> triNrm;
     uint32_t height = 0;
@@ -106,6 +107,8 @@ __attribute__((visibility("default"))) void* hc_scene_create(const float* vb, ui
     }
     s->nodes32.resize(s->nodes.size());
     for (size_t i = 0; i < s->nodes.size(); ++i) s->nodes32[i] = compress_node(s->nodes[i]);
+    s->nodes64.resize(s->nodes.size());
+    for (size_t i = 0; i < s->nodes.size(); ++i) s->nodes64[i] = widen_node(s->nodes.data(), (int32_t)i);
     return s;
 }
 
@@ -115,6 +118,7 @@ __attribute__((visibility("default"))) uint32_t hc_half_up(float x) { return hal
 __attribute__((visibility("default"))) float hc_half_to_float(uint32_t h) { return half_to_float((uint16_t)h); }
 __attribute__((visibility("default"))) void hc_scene_destroy(void* p) { delete static_cast<HcScene*>(p); }
 __attribute__((visibility("default"))) uint32_t hc_scene_height(void* p) { return static_cast<HcScene*>(p)->height; }
+__attribute__((visibility("default"))) void hc_scene_nodes64(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes64.data(), s->nodes64.size() * sizeof(Node64)); }
 __attribute__((visibility("default"))) void hc_scene_nodes(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes.data(), s->nodes.size() * sizeof(Node)); }
 __attribute__((visibility("default"))) void hc_scene_keys(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->keys.data(), s->keys.size() * 8); }
 
@@ -146,7 +150,7 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
         return 0;
     }
     int overflow = 0;
-    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}, s->nodes64.data()};
     {   // root box = union of the root node's two child boxes (as k_root_info computes it)
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
@@ -160,8 +164,9 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
             const size_t id = ((size_t)lz * N + iy) * N + ix;
             bool ovf = false;
             uint32_t texel = 0;
-            out[id] = mode == 0 ? voxel_reference<false>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
-                      : mode == 2 ? voxel_reference<true>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
+            out[id] = mode == 0 ? voxel_reference<0>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
+                      : mode == 2 ? voxel_reference<1>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
+                      : mode == 6 ? voxel_reference<2>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
                       : mode == 3 ? voxel_parity<true>(sc, N, ix, iy, iz, stk, stackCap, ovf)
                                   : voxel_parity<false>(sc, N, ix, iy, iz, stk, stackCap, ovf);
             if (texels) texels[id] = texel;

@@ -42,10 +42,10 @@ def test_fuzz_host_code_vs_brute_force(orc, hostcheck, seed, n_tris):
     h = hostcheck(vb, ib, s.bound)
     want = {0: s.voxelize(N, algo=orc.ALGO_BRUTE), 1: s.voxelize(N, mode=1, algo=orc.ALGO_BRUTE)}
     assert np.array_equal(s.voxelize(N), want[0]) and np.array_equal(s.voxelize(N, mode=1), want[1])   # oracle BVH too
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 6):                      # 6 = postponed-leaf walk over the wide nodes
         g, ovf = h.voxelize(N, mode)
         assert not ovf
-        assert np.array_equal(g, want[0 if mode in (0, 2) else 1]), (seed, mode)
+        assert np.array_equal(g, want[0 if mode in (0, 2, 6) else 1]), (seed, mode)
 
 
 @pytest.mark.gpu
@@ -60,11 +60,13 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
             v.InitFromArrays(vb, ib)
             for mode in (0, 1):
                 want = s.voxelize(N, mode=mode, algo=orc.ALGO_BRUTE)
-                for rows, queue in (((1, 1),) if mode == 0 else ((1, 1), (0, 1), (0, 0))):
+                for rows, queue, wide in (((1, 1, 1), (1, 1, 0), (1, 0, 0)) if mode == 0 else ((1, 1, 1), (0, 1, 1), (0, 0, 1))):
                     v.set_option("rows", rows)
                     v.set_option("queue", queue)
+                    v.set_option("wide", wide)
                     v.Voxelize(N, mode)
-                    assert np.array_equal(v.Grid(), want), (seed, N, mode, rows, queue)
+                    assert np.array_equal(v.Grid(), want), (seed, N, mode, rows, queue, wide)
             v.set_option("rows", 1)
             v.set_option("queue", 1)
+            v.set_option("wide", 0)
     v.close()

@@ -15,7 +15,7 @@ from dxrvoxelizer_amd.slabs import gather_slabs, slab_range
 
 pytestmark = pytest.mark.gpu
 
-DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32 = range(6)
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64 = range(7)
 
 
 @pytest.fixture(scope="module")
@@ -55,6 +55,7 @@ def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
     assert np.array_equal(nodes[:, 14:16], want[:, 14:16]), "subtree heights differ"
     assert st["tree_height"] == h.height
     assert np.array_equal(vox.debug(DBG_NODES32), h.nodes32()), "compressed traversal nodes differ"
+    assert np.array_equal(vox.debug(DBG_NODES64), h.nodes64()), "wide traversal nodes differ"
     tp = vox.debug(DBG_TRI_POS)
     k = tp[:, 3].view(np.uint32)
     assert np.array_equal(np.sort(k), np.arange(len(k), dtype=np.uint32))
@@ -327,17 +328,28 @@ def test_errors_are_loud(dxv, bunny):
     deep = np.tile(np.arange(3, dtype=np.uint32), 140000)
     v.InitFromArrays(tri, deep)
     assert v.stats()["tree_height"] >= 17
-    v.set_option("stack", 8)                              # forced depth: overflow must be reported
-    with pytest.raises(dxv.DxvError) as e:
-        v.Voxelize(16)
-    assert "stack" in str(e.value)
-    v.set_option("stack", 0)                              # adaptive: grows once, then succeeds
     v.Voxelize(16)
-    assert v.stats()["stack_entries"] >= 20
+    want16 = v.Grid()
+    v.Voxelize(128)
+    want128 = v.Grid()
+    for wide in (1, 0):
+        v.set_option("wide", wide)
+        v.set_option("stack", 8)                          # forced shallow column: the rays that run out of it
+        v.Voxelize(16)                                    # are finished by the deep-stack redo pass
+        assert v.stats()["redo_rays"] > 0 and np.array_equal(v.Grid(), want16)
+        with pytest.raises(dxv.DxvError) as e:            # ... unless there are too many of them: reported
+            v.Voxelize(128)
+        assert "stack" in str(e.value)
+        v.set_option("stack", 0)                          # adaptive: the column grows instead, then succeeds
+        v.set_option("stack0", 8)
+        v.Voxelize(128)
+        assert v.stats()["stack_entries"] > 8 and np.array_equal(v.Grid(), want128)
+        v.set_option("stack0", 20)
+    v.set_option("wide", 0)
     one = dxv.Voxelizer(0)
     one.InitFromArrays(tri, np.arange(3, dtype=np.uint32))
     one.Voxelize(16)
-    assert np.array_equal(v.Grid(), one.Grid())           # 140000 coincident copies == one triangle
+    assert np.array_equal(want16, one.Grid())             # 140000 coincident copies == one triangle
     one.close()
     v.close()
 
@@ -465,3 +477,30 @@ def test_bit_packed_download_equals_packbits(vox, bunny, n, z0, nz):
     assert np.array_equal(bits, np.packbits(g.reshape(-1), bitorder="little"))
     with pytest.raises(Exception):
         vox.GridBits(np.empty(bits.size + 1, np.uint8))
+
+
+@pytest.mark.parametrize("name,n", [("bunny", 64), ("dragon", 64), ("turingbowl", 64), ("dragon", 256)])
+def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
+    """Option wide = 1: the reference rule over the four-box nodes (Node64) -- same grid, same texels,
+    and at 64^3 the oracle's grid."""
+    vb, ib, _ = request.getfixturevalue(name)
+    vox.InitFromArrays(vb, ib)
+    vox.EnableTexels(True)
+    vox.Voxelize(n)
+    g0, t0 = vox.Grid(), vox.Texels()
+    vox.set_option("wide", 1)
+    try:
+        vox.Voxelize(n)
+        g1, t1 = vox.Grid(), vox.Texels()
+        vox.set_option("stack", 8 if n == 64 else 12)     # shallow column: many rays take the redo pass
+        vox.Voxelize(n)
+        g2 = vox.Grid()
+        redo = vox.stats()["redo_rays"]
+    finally:
+        vox.set_option("stack", 0)
+        vox.set_option("wide", 0)
+        vox.EnableTexels(False)
+    assert np.array_equal(g0, g1) and np.array_equal(t0, t1) and np.array_equal(g0, g2)
+    assert redo > 0
+    if n == 64:
+        assert np.array_equal(g0, orc.Scene(vb, ib).voxelize(64))

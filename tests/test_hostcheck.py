@@ -37,8 +37,9 @@ def test_host_lbvh_equals_oracle_assets(orc, hostcheck, request, name):
     keys = h.keys()
     assert np.all(keys[1:] > keys[:-1])
     assert 1 <= h.height <= 62
-    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2), (64, 3), (64, 5)):   # 2/3 = postponed-leaf walks, 5 (-> 4) = parity rows
-        g, ovf = h.voxelize(N, 4 if mode == 5 else mode, stack=h.height + 3)
+    # 2/3 = postponed-leaf walks, 5 (-> 4) = parity rows, 6 = postponed-leaf walk over the wide nodes
+    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2), (64, 3), (64, 5), (64, 6)):
+        g, ovf = h.voxelize(N, 4 if mode == 5 else mode, stack=h.height + 3 if mode != 6 else 3 * ((h.height + 1) // 2) + 5)
         assert not ovf
         assert np.array_equal(g, s.voxelize(N, mode=mode % 2))
 
@@ -59,7 +60,7 @@ def test_host_lbvh_equals_oracle_brute_synthetic(orc, hostcheck, gen, args):
     s = orc.Scene(vb, ib)
     h = hostcheck(vb, ib, s.bound)
     check_tree(h.nodes(), h.T)
-    modes = (0, 2) if gen == "soup" else (0, 1, 2, 3, 5)
+    modes = (0, 2, 6) if gen == "soup" else (0, 1, 2, 3, 5, 6)
     for mode in modes:
         g, ovf = h.voxelize(16, 4 if mode == 5 else mode)
         assert not ovf
@@ -144,6 +145,37 @@ def test_compressed_nodes_contain_exact_boxes(orc, hostcheck, dragon):
     assert np.max(np.abs(halves - exact)) < 1e-3                   # half ulp near 1.0 is 2^-11
 
 
+def test_wide_nodes_hold_the_grandchildren(orc, hostcheck, dragon):
+    """Node64 of binary node i: every internal child replaced by its two children, boxes rounded
+    outward, unused slots inverted (never hit) -- and the same packing of the exact boxes as Node32."""
+    vb, ib, _ = dragon
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    nodes = h.nodes()
+    exact = nodes[:, :12].view(np.float32).reshape(-1, 2, 2, 3)     # [node][child][lo/hi][axis]
+    links = nodes[:, 12:14].view(np.int32)
+    wide = h.nodes64()
+    planes = wide[:, :12].copy().view(np.uint16).view(np.float16).astype(np.float32).reshape(-1, 3, 2, 4)   # [axis][side][slot]
+    wl = wide[:, 12:16].view(np.int32)
+    rng = np.random.default_rng(5)
+    for i in rng.integers(0, len(nodes), 400):
+        want = []
+        for side in range(2):
+            c = links[i, side]
+            if c >= 0:
+                want += [(exact[c, 0], links[c, 0]), (exact[c, 1], links[c, 1])]
+            else:
+                want.append((exact[i, side], c))
+        for slot in range(4):
+            lo, hi = planes[i, :, 0, slot], planes[i, :, 1, slot]
+            if slot < len(want):
+                box, link = want[slot]
+                assert wl[i, slot] == link
+                assert np.all(lo <= box[0]) and np.all(hi >= box[1]) and np.max(np.abs(lo - box[0])) < 1e-3
+            else:
+                assert wl[i, slot] == -2 ** 31 and np.all(np.isposinf(lo)) and np.all(np.isneginf(hi))
+
+
 def test_queued_walk_every_capacity_is_exact_or_reports_overflow(orc, hostcheck, dragon):
     """The stack and the postponed-leaf queue share one LDS column.  For every column size the walk
     must either report overflow or produce the exact grid -- never a silently wrong one (a lane whose
@@ -154,7 +186,7 @@ def test_queued_walk_every_capacity_is_exact_or_reports_overflow(orc, hostcheck,
     want = {0: s.voxelize(32), 1: s.voxelize(32, mode=1)}
     clean = 0
     for cap in range(5, 26):
-        for mode in (2, 3):
+        for mode in (2, 3, 6):
             g, ovf = h.voxelize(32, mode, stack=cap)
             if not ovf:
                 clean += 1
@@ -162,4 +194,4 @@ def test_queued_walk_every_capacity_is_exact_or_reports_overflow(orc, hostcheck,
             else:                                   # rays that did not overflow are still right
                 bad = g != want[mode % 2]
                 assert bad.mean() < 0.2, (cap, mode)
-    assert clean >= 10
+    assert clean >= 15
