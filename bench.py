@@ -39,6 +39,10 @@ def make_mesh(name):
         d = np.load(os.path.join(ROOT, "tests", "golden", "meshes", "dragon.npz"))
         vb, ib = meshes.trisect(d["vb"], d["ib"])
         return vb, ib, "dragon x9 (900,000 triangles)"
+    if name == "bunny16":
+        d = np.load(os.path.join(ROOT, "tests", "golden", "meshes", "bunny.npz"))
+        vb, ib = meshes.midpoint_subdivide(*meshes.midpoint_subdivide(d["vb"], d["ib"]))
+        return vb, ib, "bunny x16 (1,114,656 triangles)"
     raise SystemExit(f"unknown mesh {name}")
 
 

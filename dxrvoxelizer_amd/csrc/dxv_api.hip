@@ -113,7 +113,7 @@ Node64* scene_nodes64(dxv_ctx* c) { return reinterpret_cast<Node64*>(c->dScene +
 TriPos* scene_tripos(dxv_ctx* c) { return reinterpret_cast<TriPos*>(c->dScene + c->hdr.offTriPos); }
 TriNrm* scene_trinrm(dxv_ctx* c) { return reinterpret_cast<TriNrm*>(c->dScene + c->hdr.offTriNrm); }
 
-void layout_scene(SceneHeader& h, uint32_t T, uint32_t V)
+void layout_scene(SceneHeader& h, uint32_t T, uint32_t V, bool wide)
 {
     memset(&h, 0, sizeof(h));
     h.magic = kSceneMagic;
@@ -124,15 +124,16 @@ void layout_scene(SceneHeader& h, uint32_t T, uint32_t V)
     h.offNodes = align256(sizeof(SceneHeader));
     h.offNodes32 = align256(h.offNodes + sizeof(Node) * (size_t)h.numNodes);
     h.offNodes64 = align256(h.offNodes32 + sizeof(Node32) * (size_t)h.numNodes);
-    h.offTriPos = align256(h.offNodes64 + sizeof(Node64) * (size_t)h.numNodes);
+    h.hasWide = wide ? 1u : 0u;
+    h.offTriPos = align256(h.offNodes64 + (wide ? sizeof(Node64) * (size_t)h.numNodes : 0));
     h.offTriNrm = align256(h.offTriPos + sizeof(TriPos) * (size_t)T);
     h.totalBytes = align256(h.offTriNrm + sizeof(TriNrm) * (size_t)T);
 }
 
-int alloc_scene(dxv_ctx* c, uint32_t T, uint32_t V)
+int alloc_scene(dxv_ctx* c, uint32_t T, uint32_t V, bool wide)
 {
     SceneHeader h;
-    layout_scene(h, T, V);
+    layout_scene(h, T, V, wide);
     if (c->dScene && c->sceneBytes != h.totalBytes) { (void)hipFree(c->dScene); c->dScene = nullptr; }
     if (!c->dScene) DXV_HIP(c, hipMalloc(&c->dScene, h.totalBytes));
     c->sceneBytes = h.totalBytes;
@@ -180,7 +181,7 @@ float elapsed(hipEvent_t a, hipEvent_t b)
 bool use_wide(const dxv_ctx* c, int mode)
 {
     const int need = 3 * (((int)c->hdr.treeHeight + 1) / 2) + 5;
-    return mode == DXV_MODE_REFERENCE && c->optWide && c->optQueue && need <= 64;
+    return mode == DXV_MODE_REFERENCE && c->optWide && c->hdr.hasWide && c->optQueue && need <= 64;
 }
 int safe_stack(const dxv_ctx* c)
 {
@@ -336,7 +337,7 @@ void fill_build_buffers(dxv_ctx* c, BuildBuffers& b)
     memcpy(b.bound, c->bound, sizeof(c->bound));
     b.keys = c->dKeys; b.keysTmp = c->dKeysTmp; b.hist = c->dHist; b.parents = c->dParents;
     b.flags = c->dFlags; b.flags2 = c->dFlags2; b.rootInfo = c->dRootInfo;
-    b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.nodes64 = scene_nodes64(c); b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
+    b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.nodes64 = c->hdr.hasWide ? scene_nodes64(c) : nullptr; b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
 }
 
 int finish_build(dxv_ctx* c, const char* who)
@@ -395,7 +396,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     c->haveScene = false;
-    if (alloc_scene(c, c->T, c->V)) return 1;
+    if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     memcpy(c->hdr.bound, c->bound, sizeof(c->bound));
 
@@ -617,12 +618,12 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     if (h.magic != kSceneMagic || h.version != kSceneVersion) return fail(c, "dxv_scene_import: bad magic/version");
     SceneHeader want;
-    layout_scene(want, h.numTris, h.numVerts);
+    layout_scene(want, h.numTris, h.numVerts, h.hasWide != 0);
     if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
-        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.treeHeight == 0 || h.treeHeight > 64)
+        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.hasWide > 1u || h.treeHeight == 0 || h.treeHeight > 64)
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     c->haveScene = false;
-    if (alloc_scene(c, h.numTris, h.numVerts)) return 1;
+    if (alloc_scene(c, h.numTris, h.numVerts, h.hasWide != 0)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dScene, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->hdr = h;
@@ -662,6 +663,11 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "wide")) {
         if (value != 0 && value != 1) return fail(c, "option wide: %lld not in {0,1}", (long long)value);
         c->optWide = (int)value;
+        // the wide copy is a section of the scene: a scene built without it is built again
+        if (value && c->haveScene && !c->hdr.hasWide) {
+            if (!c->haveMesh) return fail(c, "option wide: this scene was imported without wide nodes; set the option on the exporting context before dxv_build");
+            return dxv_build(c);
+        }
     } else if (!strcmp(key, "rows")) {
         if (value != 0 && value != 1) return fail(c, "option rows: %lld not in {0,1}", (long long)value);
         c->optRows = (int)value;
@@ -693,7 +699,7 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     case DXV_DBG_PARENTS: src = c->dParents; want = sizeof(uint32_t) * (2 * T - 1); if (c->scratchT != c->T) src = nullptr; break;
     case DXV_DBG_NODES: if (c->haveScene) { src = scene_nodes(c); want = sizeof(Node) * (size_t)c->hdr.numNodes; } break;
     case DXV_DBG_NODES32: if (c->haveScene) { src = scene_nodes32(c); want = sizeof(Node32) * (size_t)c->hdr.numNodes; } break;
-    case DXV_DBG_NODES64: if (c->haveScene) { src = scene_nodes64(c); want = sizeof(Node64) * (size_t)c->hdr.numNodes; } break;
+    case DXV_DBG_NODES64: if (c->haveScene && c->hdr.hasWide) { src = scene_nodes64(c); want = sizeof(Node64) * (size_t)c->hdr.numNodes; } break;
     case DXV_DBG_TRI_POS: if (c->haveScene) { src = scene_tripos(c); want = sizeof(TriPos) * T; } break;
     case DXV_DBG_TRI_NRM: if (c->haveScene) { src = scene_trinrm(c); want = sizeof(TriNrm) * T; } break;
     default: return fail(c, "dxv_debug_download: unknown selector %d", what);

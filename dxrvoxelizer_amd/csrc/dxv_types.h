@@ -74,13 +74,14 @@ struct SceneHeader {
     float rootLo[3], rootHi[3];
     uint64_t offNodes, offTriPos, offTriNrm, totalBytes;
     uint64_t offNodes32;
-    uint64_t offNodes64;
-    uint32_t pad[28];
+    uint64_t offNodes64;  // wide nodes: present (numNodes entries) only when hasWide
+    uint32_t hasWide;
+    uint32_t pad[27];
 };
 static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
 
 constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
-constexpr uint32_t kSceneVersion = 4;
+constexpr uint32_t kSceneVersion = 5;
 
 // canonical constants (hlsl:5, :76-77)
 constexpr float kThreshold = 0.12f;

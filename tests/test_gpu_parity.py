@@ -55,7 +55,14 @@ def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
     assert np.array_equal(nodes[:, 14:16], want[:, 14:16]), "subtree heights differ"
     assert st["tree_height"] == h.height
     assert np.array_equal(vox.debug(DBG_NODES32), h.nodes32()), "compressed traversal nodes differ"
-    assert np.array_equal(vox.debug(DBG_NODES64), h.nodes64()), "wide traversal nodes differ"
+    with pytest.raises(Exception):
+        vox.debug(DBG_NODES64)                            # the wide copy is only built on request
+    vox.set_option("wide", 1)                             # ... which builds the scene again with it
+    try:
+        assert np.array_equal(vox.debug(DBG_NODES, ), nodes)
+        assert np.array_equal(vox.debug(DBG_NODES64), h.nodes64()), "wide traversal nodes differ"
+    finally:
+        vox.set_option("wide", 0)
     tp = vox.debug(DBG_TRI_POS)
     k = tp[:, 3].view(np.uint32)
     assert np.array_equal(np.sort(k), np.arange(len(k), dtype=np.uint32))
@@ -304,6 +311,21 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     bad[:4] = 0
     with pytest.raises(dxv.DxvError):
         b.scene_import(bad.data_ptr(), n)
+    # a scene built with the wide copy carries it in the blob; the importer walks it when asked to
+    a.set_option("wide", 1)
+    n2 = a.scene_bytes()
+    assert n2 > n
+    blob2 = torch.empty(n2, dtype=torch.uint8, device="cuda")
+    a.scene_export(blob2.data_ptr(), n2)
+    torch.cuda.synchronize()
+    b.scene_import(blob2.data_ptr(), n2)
+    b.set_option("wide", 1)
+    want = a.Grid()
+    a.Voxelize(64), b.Voxelize(64)
+    assert np.array_equal(a.Grid(), want) and np.array_equal(b.Grid(), want)
+    b.scene_import(blob.data_ptr(), n)                    # narrow blob with the option still on: binary walk
+    b.Voxelize(64)
+    assert np.array_equal(b.Grid(), want)
     a.close(), b.close()
 
 
