@@ -233,8 +233,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "compulsory HBM bytes are tiny: the measured limiter is VALU/SALU issue with waves "
-                                 "waiting on dependent L1/L2/scalar-cache fetches (profiles/r01/final/pmc_summary.json)"},
+                         "note": "compulsory HBM bytes are tiny: the measured limiters are VALU issue and the vector-L1 line "
+                                 "accesses of divergent node fetches, about 60 % busy each (profiles/r01/final/pmc_summary.json, "
+                                 "DESIGN.md section 4)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode)
