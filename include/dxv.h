@@ -162,7 +162,15 @@ DXV_API int dxv_scene_import(dxv_ctx* ctx, const void* device_src, size_t bytes)
 
 DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
 
-/* Tuning knobs (kernel variant selection etc.); unknown keys fail.  See DESIGN.md. */
+/* Tuning knobs (kernel variant selection etc.); unknown keys fail.  None changes a result.
+ *   brick  0..7   voxels per workgroup (default 4 = 4x4x4, one wavefront)
+ *   stack  0|8..64  LDS column entries per thread; 0 (default) = adaptive from stack0
+ *   stack0 8..64  starting depth of the adaptive column (default 20)
+ *   queue  0|1    postponed-leaf walk (default 1)
+ *   wide   0|1    reference rule over four-box nodes; builds the extra scene section (default 0)
+ *   rows   0|1    parity rule: one tree walk per grid row (default 1)
+ *   refit  0|1    box merge by level sweeps (1, default) or one atomic pass (0)
+ *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
 
 /* Test hook: copy an internal device array to the host (enum above). */
