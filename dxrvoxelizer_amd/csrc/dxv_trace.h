@@ -149,6 +149,19 @@ DXV_HD bool wave_any(bool x)
 #endif
 }
 
+// wave_any(a && b): the AND of two ballots (lane-wise) costs two compares and one scalar AND, the
+// ballot of the combined predicate an extra select and compare.
+DXV_HD bool wave_any_both(bool a, bool b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b)) != 0ull;
+#else
+    return a && b;
+#endif
+}
+
+constexpr int32_t kNodeOverflow = -2;   // a ray whose column ran out (-1 = walk finished)
+
 // Postponed-leaf traversal (default).  Walking internal nodes is cheap and coherent across the
 // wave; triangle tests are long and, done on the spot, run with a handful of lanes.  So hit leaf
 // children are only QUEUED (leaf index in the same LDS column as the stack: stack grows up from
@@ -224,7 +237,6 @@ DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, c
 {
     stk.put(0, -1);
     int sp = 1, qn = 0;
-    bool ok = true;
     int32_t node = 0;
     // The plane of each axis a box is entered through: hi where the direction is negative.  The
     // radial direction has the signs of the origin (never zero); the parity ray enters through lo.
@@ -242,7 +254,7 @@ DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, c
         // A step needs one free stack slot and two free queue slots: sp + qn + 3 <= cap.  The wave
         // flushes the queue whenever a queue is what is in the way (below), so no room here means
         // the stack alone is too deep for this column: stop the ray and report it.
-        if (node >= 0 && sp + qn + 3 > cap) { ok = false; node = -1; }
+        if (node >= 0 && sp + qn + 3 > cap) node = kNodeOverflow;
         if (node >= 0) {
             if (STATS) st->nodes++;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -265,7 +277,7 @@ DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, c
             if (STATS && sp - 1 > (int)st->maxsp) st->maxsp = (uint32_t)(sp - 1);
         }
         const bool walking = wave_any(node >= 0);
-        if (walking && !wave_any(sp + qn + 3 > cap && qn > 0)) continue;
+        if (walking && !wave_any_both(sp + qn + 3 > cap, qn > 0)) continue;
         for (int i = 0; wave_any(i < qn); ++i) {
             if (i < qn) {
                 const int32_t l = stk.get(cap - 1 - i);
@@ -276,7 +288,7 @@ DXV_HD bool walk_queued(const Ray& r, const Node32* nodes, const TriPos* tris, c
         qn = 0;
         if (!walking) break;
     }
-    return ok;
+    return node != kNodeOverflow;
 }
 
 // reference rule: candidacy by the triangle's own exact box, closest = min (t, k)
@@ -389,7 +401,6 @@ DXV_HD bool walk_queued_wide(const Ray& r, const Node64* nodes, const TriPos* tr
 {
     stk.put(0, -1);
     int sp = 1, qn = 0;
-    bool ok = true;
     int32_t node = 0;
     const bool negx = r.ox < 0.0f, negy = r.oy < 0.0f, negz = r.oz < 0.0f;   // as in walk_queued
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -399,7 +410,7 @@ DXV_HD bool walk_queued_wide(const Ray& r, const Node64* nodes, const TriPos* tr
     const bool unx = bx != 0ull, uny = by != 0ull, unz = bz != 0ull;
 #endif
     for (;;) {
-        if (node >= 0 && sp + qn + kWideRoom > cap) { ok = false; node = -1; }
+        if (node >= 0 && sp + qn + kWideRoom > cap) node = kNodeOverflow;
         if (node >= 0) {
             if (STATS) st->nodes++;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -423,7 +434,7 @@ DXV_HD bool walk_queued_wide(const Ray& r, const Node64* nodes, const TriPos* tr
             if (STATS && sp - 1 > (int)st->maxsp) st->maxsp = (uint32_t)(sp - 1);
         }
         const bool walking = wave_any(node >= 0);
-        if (walking && !wave_any(sp + qn + kWideRoom > cap && qn > 0)) continue;
+        if (walking && !wave_any_both(sp + qn + kWideRoom > cap, qn > 0)) continue;
         for (int i = 0; wave_any(i < qn); ++i) {
             if (i < qn) {
                 const int32_t l = stk.get(cap - 1 - i);
@@ -434,7 +445,7 @@ DXV_HD bool walk_queued_wide(const Ray& r, const Node64* nodes, const TriPos* tr
         qn = 0;
         if (!walking) break;
     }
-    return ok;
+    return node != kNodeOverflow;
 }
 
 template <class Stack, bool STATS = false>
