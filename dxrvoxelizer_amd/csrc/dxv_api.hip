@@ -80,6 +80,7 @@ struct dxv_ctx {
     int optWide = 0;         // reference rule: walk the wide (up to 4 boxes) nodes; measured -8 % on low-poly meshes,
                              // +10 % on 1 M triangles at 256^3, so off unless asked for
     int optRows = 1;         // parity mode: one tree walk per grid row (k_parity_rows) instead of per voxel
+    int optRowBlock = 0;     // rows per side of a wave's block of rows: 0 = by triangle size, 1, 2
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
     int optStack0 = 20;      // adaptive mode starts with this many entries (stack + leaf queue share them)
     int stackNow = 20;       // adaptive: LDS stack entries per thread currently in use for this scene
@@ -210,7 +211,13 @@ int launch_now(dxv_ctx* c)
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {
-        DXV_HIP(c, launch_parity_rows(p, c->stream));
+        // rows whose triangles span several voxels share a walk: 2 x 2 rows per wave above 1.2 voxels of
+        // mean triangle extent, 4 x 4 above 3.3 (measured crossovers, profiles/r01/final/rowblock.jsonl;
+        // voxel-sized triangles are 1.2-2x slower in blocks, 4-7 voxel ones 2.7-4x faster)
+        const float voxels = c->hdr.triExtent * 0.5f * (float)p.N;
+        const int rowBlock = c->optRowBlock ? c->optRowBlock : (voxels > 3.3f ? 4 : voxels > 1.2f ? 2 : 1);
+        c->stats.row_block = (uint32_t)rowBlock;
+        DXV_HIP(c, launch_parity_rows(p, rowBlock, c->stream));
         c->lastRedoParity = -1;
     } else {
         DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
@@ -342,13 +349,18 @@ void fill_build_buffers(dxv_ctx* c, BuildBuffers& b)
 
 int finish_build(dxv_ctx* c, const char* who)
 {
-    uint32_t rootInfo[8];
+    uint32_t rootInfo[16];
     DXV_HIP(c, hipMemcpyAsync(rootInfo, c->dRootInfo, sizeof(rootInfo), hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     if (rootInfo[7] != 1) return fail(c, "%s: did not complete", who);
     memcpy(c->hdr.rootLo, &rootInfo[0], 12);
     memcpy(c->hdr.rootHi, &rootInfo[3], 12);
     c->hdr.treeHeight = rootInfo[6];
+    {   // k_tri_keys: sum over triangles of (extent y + extent z) in 2^-20 units
+        unsigned long long ext;
+        memcpy(&ext, &rootInfo[8], sizeof(ext));
+        c->hdr.triExtent = (float)((double)ext / 1048576.0 / 2.0 / (double)c->T);
+    }
     for (int a = 0; a < 3; ++a)
         if (!(c->hdr.rootLo[a] <= c->hdr.rootHi[a]))
             return fail(c, "%s: refit produced an invalid root box (axis %d: %g > %g)", who, a,
@@ -360,6 +372,7 @@ int finish_build(dxv_ctx* c, const char* who)
     c->stackNow = stack_round_up((int)(c->hdr.treeHeight + 3 < (uint32_t)c->optStack0 ? c->hdr.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_nodes = c->hdr.numNodes;
     c->stats.tree_height = c->hdr.treeHeight;
+    c->stats.tri_extent = c->hdr.triExtent;
     return 0;
 }
 } // namespace
@@ -633,6 +646,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     c->stackNow = stack_round_up((int)(h.treeHeight + 3 < (uint32_t)c->optStack0 ? h.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_tris = h.numTris; c->stats.num_verts = h.numVerts; c->stats.num_nodes = h.numNodes;
     c->stats.tree_height = h.treeHeight;
+    c->stats.tri_extent = h.triExtent;
     memcpy(c->stats.bound, h.bound, sizeof(h.bound));
     return 0;
 }
@@ -668,6 +682,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
             if (!c->haveMesh) return fail(c, "option wide: this scene was imported without wide nodes; set the option on the exporting context before dxv_build");
             return dxv_build(c);
         }
+    } else if (!strcmp(key, "rowblock")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, "option rowblock: %lld not in {0,1,2,4}", (long long)value);
+        c->optRowBlock = (int)value;
     } else if (!strcmp(key, "rows")) {
         if (value != 0 && value != 1) return fail(c, "option rows: %lld not in {0,1}", (long long)value);
         c->optRows = (int)value;

@@ -220,6 +220,8 @@ DXV_HD ParityRowTri parity_row_setup(float oy, float oz, const F4& v0, const F4&
     tri_box(v0, v1, v2, lo, hi);
     s.hit = lo[1] <= oy && oy <= hi[1] && lo[2] <= oz && oz <= hi[2];
     s.hix = hi[0]; s.v0x = v0.x; s.v1x = v1.x; s.v2x = v2.x;
+    s.U = s.V = s.W = s.det = 0.0f;
+    if (!s.hit) return s;       // the row misses the triangle's own box: nothing below can turn hit back on
     const float Ax = v0.y - oy, Ay = v0.z - oz, Bx = v1.y - oy, By = v1.z - oz, Cx = v2.y - oy, Cy = v2.z - oz;
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;

@@ -557,21 +557,24 @@ DXV_HD uint8_t voxel_parity(const SceneView& sc, uint32_t N, uint32_t ix, uint32
 }
 
 // ------------------------------------------------------------------------------------------
-// Parity mode, row form: one walk of the tree for a run of voxels of one grid row.
-// `each(tri)` is called for every triangle whose exact box contains (oy, oz) in y/z and is not
-// entirely left of oxMin; node tests use the outward-rounded boxes (supersets).  The walk depends
-// only on (oy, oz, oxMin): on the device it is wave-uniform (scalar node and triangle fetches,
-// one LDS stack per wave).  `NodeFetch(i)` returns NodePlanes, `TriFetch(leaf)` a TriPos.
+// Parity mode, row form: one walk of the tree for a run of voxels of a few neighbouring grid rows
+// (the kernel takes 2 x 2 rows: they share most of their path through the tree).
+// `each(tri)` is called for every triangle whose box meets [ylo, yhi] x [zlo, zhi] in y/z and is
+// not entirely left of oxMin; node tests use the outward-rounded boxes (supersets), and the
+// caller applies the exact per-row test (parity_row_setup) to what it is handed.  The walk depends
+// only on the five bounds: on the device it is wave-uniform (scalar node and triangle fetches, one
+// LDS stack per wave).  `NodeFetch(i)` returns NodePlanes, `TriFetch(leaf)` a TriPos.
 // ------------------------------------------------------------------------------------------
 template <class NodeFetch, class TriFetch, class StackT, class Each>
-DXV_HD void walk_parity_row(float oy, float oz, float oxMin, NodeFetch&& nodeAt, TriFetch&& triAt, StackT& stk, Each&& each)
+DXV_HD void walk_parity_rows(float ylo, float yhi, float zlo, float zhi, float oxMin, NodeFetch&& nodeAt, TriFetch&& triAt,
+                             StackT& stk, Each&& each)
 {
     int sp = 0;
     int32_t node = 0;
     for (;;) {
         const NodePlanes n = nodeAt(node);
-        const bool h0 = n.b[1] <= oy && oy <= n.b[4] && n.b[2] <= oz && oz <= n.b[5] && n.b[3] >= oxMin;
-        const bool h1 = n.b[7] <= oy && oy <= n.b[10] && n.b[8] <= oz && oz <= n.b[11] && n.b[9] >= oxMin;
+        const bool h0 = n.b[1] <= yhi && ylo <= n.b[4] && n.b[2] <= zhi && zlo <= n.b[5] && n.b[3] >= oxMin;
+        const bool h1 = n.b[7] <= yhi && ylo <= n.b[10] && n.b[8] <= zhi && zlo <= n.b[11] && n.b[9] >= oxMin;
         if (h0 && n.c0 < 0) each(triAt(~n.c0));
         if (h1 && n.c1 < 0) each(triAt(~n.c1));
         const bool i0 = h0 && n.c0 >= 0, i1 = h1 && n.c1 >= 0;
@@ -583,6 +586,13 @@ DXV_HD void walk_parity_row(float oy, float oz, float oxMin, NodeFetch&& nodeAt,
             node = stk.pop(sp);
         }
     }
+}
+
+// one row: the degenerate intervals
+template <class NodeFetch, class TriFetch, class StackT, class Each>
+DXV_HD void walk_parity_row(float oy, float oz, float oxMin, NodeFetch&& nodeAt, TriFetch&& triAt, StackT& stk, Each&& each)
+{
+    walk_parity_rows(oy, oy, oz, oz, oxMin, nodeAt, triAt, stk, each);
 }
 
 } // namespace dxv

@@ -76,12 +76,13 @@ struct SceneHeader {
     uint64_t offNodes32;
     uint64_t offNodes64;  // wide nodes: present (numNodes entries) only when hasWide
     uint32_t hasWide;
-    uint32_t pad[27];
+    float triExtent;      // mean extent of a triangle's box along y and z, normalised units (parity row blocks)
+    uint32_t pad[26];
 };
 static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
 
 constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
-constexpr uint32_t kSceneVersion = 5;
+constexpr uint32_t kSceneVersion = 6;
 
 // canonical constants (hlsl:5, :76-77)
 constexpr float kThreshold = 0.12f;

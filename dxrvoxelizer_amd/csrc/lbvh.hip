@@ -31,17 +31,26 @@ __device__ __forceinline__ void gather_tri(const float* __restrict__ vb, const u
     c = normalise_pos(vb + 6ull * idx[2], bnd.c);
 }
 
+// Also sums the y and z extents of the triangle boxes (fixed point, so the sum does not depend on
+// the order of the atomics) into rootInfo[8..9]: the mean triangle size in voxels decides how many
+// grid rows share a walk in parity mode (traverse.hip, k_parity_rows).
 __global__ __launch_bounds__(kThreads) void k_tri_keys(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
-                                                       uint32_t T, Bound4 bnd, uint64_t* __restrict__ keys)
+                                                       uint32_t T, Bound4 bnd, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ rootInfo)
 {
     const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
-    if (k >= T) return;
-    F4 a, b, c;
-    uint32_t idx[3];
-    gather_tri(vb, ib, k, bnd, a, b, c, idx);
-    float lo[3], hi[3];
-    tri_box(a, b, c, lo, hi);
-    keys[k] = morton_key(lo, hi, k);
+    unsigned long long ext = 0;
+    if (k < T) {
+        F4 a, b, c;
+        uint32_t idx[3];
+        gather_tri(vb, ib, k, bnd, a, b, c, idx);
+        float lo[3], hi[3];
+        tri_box(a, b, c, lo, hi);
+        keys[k] = morton_key(lo, hi, k);
+        ext = (unsigned long long)(((hi[1] - lo[1]) + (hi[2] - lo[2])) * 1048576.0f);      // 2^-20 units
+    }
+    for (int off = 32; off; off >>= 1) ext += __shfl_down(ext, off);
+    if ((threadIdx.x & 63) == 0 && ext) atomicAdd(reinterpret_cast<unsigned long long*>(rootInfo + 8), ext);
 }
 
 __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
@@ -262,10 +271,10 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     hipError_t e;
     // poison the nodes (all-ones = NaN boxes): a box that was never merged cannot pass a slab test
     if ((e = hipMemsetAsync(b.nodes, 0xff, sizeof(Node) * (size_t)numNodes, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(b.rootInfo, 0, 16 * sizeof(uint32_t), s)) != hipSuccess) return e;
 
     (void)hipEventRecord(ev[0], s);
-    k_tri_keys<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys);
+    k_tri_keys<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.rootInfo);
     (void)hipEventRecord(ev[1], s);
     if (T > 1) {
         if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;

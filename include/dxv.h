@@ -54,7 +54,9 @@ typedef struct dxv_stats {
     uint32_t stack_entries;  /* LDS traversal stack entries per thread of the last launch      */
     float render_ms;         /* last dxv_render kernel, HIP events                                  */
     uint32_t redo_rays;      /* rays of the last launch finished by the deep-stack redo pass       */
-    uint32_t reserved[5];
+    uint32_t row_block;      /* parity rule: rows per side of a wave's block of rows (1, 2 or 4)   */
+    float tri_extent;        /* mean triangle box extent along y/z, normalised units               */
+    uint32_t reserved[3];
 } dxv_stats;
 
 /* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that
@@ -169,6 +171,7 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   queue  0|1    postponed-leaf walk (default 1)
  *   wide   0|1    reference rule over four-box nodes; builds the extra scene section (default 0)
  *   rows   0|1    parity rule: one tree walk per grid row (default 1)
+ *   rowblock 0|1|2|4  ... per row (1), per 2 x 2 or 4 x 4 rows; 0 (default) decides by triangle size
  *   refit  0|1    box merge by level sweeps (1, default) or one atomic pass (0)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);

@@ -126,26 +126,40 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
                                                          uint8_t* out, uint32_t* texels)
 {
     HcScene* s = static_cast<HcScene*>(p);
-    if (mode == 4) {   // parity, row form (what k_parity_rows computes), one walk per row
+    if (mode == 4 || mode == 7 || mode == 8) {   // parity, row form (what k_parity_rows computes): one walk per block of RB x RB rows
+        const uint32_t RB = mode == 4 ? 1u : mode == 7 ? 2u : 4u;
         SceneView scr{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { scr.rootLo[a] = min_(w[a], w[6 + a]); scr.rootHi[a] = max_(w[3 + a], w[9 + a]); }
+        const uint32_t by = (N + RB - 1) / RB, bz = (nz + RB - 1) / RB;
 #pragma omp parallel for schedule(dynamic, 4)
-        for (int64_t row = 0; row < (int64_t)nz * N; ++row) {
-            const uint32_t lz = (uint32_t)(row / N), iy = (uint32_t)(row % N), iz = z0 + lz;
+        for (int64_t blk = 0; blk < (int64_t)by * bz; ++blk) {
+            const uint32_t biy = (uint32_t)(blk % by), blz = (uint32_t)(blk / by);
+            uint32_t iy[4], lz[4];
+            float oy[4], oz[4], t0, t1;
             std::vector<float> ox(N);
-            std::vector<uint32_t> cnt(N, 0);
-            float oy = 0, oz = 0;
-            for (uint32_t ix = 0; ix < N; ++ix) ray_origin(N, ix, iy, iz, ox[ix], oy, oz);
+            for (uint32_t k = 0; k < RB; ++k) {
+                iy[k] = biy * RB + k < N ? biy * RB + k : N - 1;
+                lz[k] = blz * RB + k < nz ? blz * RB + k : nz - 1;
+                ray_origin(N, 0, iy[k], z0 + lz[k], t0, oy[k], t1);
+                ray_origin(N, 0, iy[0], z0 + lz[k], t0, t1, oz[k]);
+            }
+            for (uint32_t ix = 0; ix < N; ++ix) ray_origin(N, ix, iy[0], z0, ox[ix], t0, t1);
+            float ylo = oy[0], yhi = oy[0], zlo = oz[0], zhi = oz[0];
+            for (uint32_t k = 1; k < RB; ++k) { ylo = min_(ylo, oy[k]); yhi = max_(yhi, oy[k]); zlo = min_(zlo, oz[k]); zhi = max_(zhi, oz[k]); }
+            std::vector<uint32_t> cnt((size_t)RB * RB * N, 0);
             struct HostStack { int32_t e[128]; void push(int& sp, int32_t v) { e[sp++] = v; } int32_t pop(int& sp) { return e[--sp]; } } stk;
-            if (scr.rootLo[1] <= oy && oy <= scr.rootHi[1] && scr.rootLo[2] <= oz && oz <= scr.rootHi[2] && scr.rootHi[0] >= ox[0])
-                walk_parity_row(oy, oz, ox[0], [&](int32_t i) { return load_node(scr.nodes, i); },
-                                [&](int32_t leaf) { return load_tri(scr.triPos, leaf); }, stk,
-                                [&](const TriPos& tp) {
-                                    const ParityRowTri ps = parity_row_setup(oy, oz, tp.v0, tp.v1, tp.v2);
-                                    if (ps.hit) for (uint32_t ix = 0; ix < N; ++ix) cnt[ix] += parity_row_voxel(ps, ox[ix]) ? 1u : 0u;
-                                });
-            for (uint32_t ix = 0; ix < N; ++ix) out[((size_t)lz * N + iy) * N + ix] = (uint8_t)(cnt[ix] & 1u);
+            if (scr.rootLo[1] <= yhi && ylo <= scr.rootHi[1] && scr.rootLo[2] <= zhi && zlo <= scr.rootHi[2] && scr.rootHi[0] >= ox[0])
+                walk_parity_rows(ylo, yhi, zlo, zhi, ox[0], [&](int32_t i) { return load_node(scr.nodes, i); },
+                                 [&](int32_t leaf) { return load_tri(scr.triPos, leaf); }, stk,
+                                 [&](const TriPos& tp) {
+                                     for (uint32_t r = 0; r < RB * RB; ++r) {
+                                         const ParityRowTri ps = parity_row_setup(oy[r % RB], oz[r / RB], tp.v0, tp.v1, tp.v2);
+                                         if (ps.hit) for (uint32_t ix = 0; ix < N; ++ix) cnt[(size_t)r * N + ix] += parity_row_voxel(ps, ox[ix]) ? 1u : 0u;
+                                     }
+                                 });
+            for (uint32_t r = 0; r < RB * RB; ++r)
+                for (uint32_t ix = 0; ix < N; ++ix) out[((size_t)lz[r / RB] * N + iy[r % RB]) * N + ix] = (uint8_t)(cnt[(size_t)r * N + ix] & 1u);
         }
         return 0;
     }

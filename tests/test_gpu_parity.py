@@ -526,3 +526,35 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
     assert redo > 0
     if n == 64:
         assert np.array_equal(g0, orc.Scene(vb, ib).voxelize(64))
+
+
+@pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
+def test_parity_row_blocks_equal_single_rows(vox, orc, request, name):
+    """k_parity_rows with one row per wave and with 2 x 2 rows per wave (one walk over the union of
+    the rows): same grid as the per-voxel kernel and the oracle -- whole grids, odd slabs (the last
+    slice is repeated inside a block), offsets, and the block-cyclic partition."""
+    vb, ib, _ = request.getfixturevalue(name)
+    vox.InitFromArrays(vb, ib)
+    s = orc.Scene(vb, ib)
+    want = s.voxelize(64, mode=1)
+    try:
+        for rowblock in (1, 2, 4):
+            vox.set_option("rowblock", rowblock)
+            vox.Voxelize(64, 1)
+            assert vox.stats()["row_block"] == rowblock
+            assert np.array_equal(vox.Grid(), want), rowblock
+            for z0, nz in ((0, 1), (5, 3), (17, 7), (62, 2), (31, 33)):
+                vox.Voxelize(64, 1, z0, nz)
+                assert np.array_equal(vox.Grid(), want[z0:z0 + nz]), (rowblock, z0, nz)
+            for rank in range(4):
+                vox.VoxelizeInterleaved(64, rank, 4, 2, 1)
+                zs = np.concatenate([np.arange(b, b + 2) for b in range(rank * 2, 64, 8)])
+                assert np.array_equal(vox.Grid(), want[zs]), (rowblock, rank)
+            vox.Voxelize(30, 1)                                   # rows that do not fill a wave, tiles that do not divide
+            assert np.array_equal(vox.Grid(), s.voxelize(30, mode=1)), rowblock
+        vox.set_option("rowblock", 0)
+        vox.Voxelize(64, 1)
+        assert vox.stats()["row_block"] in (1, 2, 4) and vox.stats()["tri_extent"] > 0
+        assert np.array_equal(vox.Grid(), want)
+    finally:
+        vox.set_option("rowblock", 0)
