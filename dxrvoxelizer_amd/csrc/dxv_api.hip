@@ -356,11 +356,11 @@ int finish_build(dxv_ctx* c, const char* who)
     memcpy(c->hdr.rootLo, &rootInfo[0], 12);
     memcpy(c->hdr.rootHi, &rootInfo[3], 12);
     c->hdr.treeHeight = rootInfo[6];
-    {   // k_tri_keys: sum over triangles of (extent y + extent z) in 2^-20 units
+    if (rootInfo[10]) {   // k_tri_keys: sum over the sampled triangles of (extent y + extent z) in 2^-20 units, and their number
         unsigned long long ext;
         memcpy(&ext, &rootInfo[8], sizeof(ext));
-        c->hdr.triExtent = (float)((double)ext / 1048576.0 / 2.0 / (double)c->T);
-    }
+        c->hdr.triExtent = (float)((double)ext / 1048576.0 / 2.0 / (double)rootInfo[10]);
+    }                     // (a refit keeps the figure of the build)
     for (int a = 0; a < 3; ++a)
         if (!(c->hdr.rootLo[a] <= c->hdr.rootHi[a]))
             return fail(c, "%s: refit produced an invalid root box (axis %d: %g > %g)", who, a,

@@ -31,13 +31,15 @@ __device__ __forceinline__ void gather_tri(const float* __restrict__ vb, const u
     c = normalise_pos(vb + 6ull * idx[2], bnd.c);
 }
 
-// Also sums the y and z extents of the triangle boxes (fixed point, so the sum does not depend on
-// the order of the atomics) into rootInfo[8..9]: the mean triangle size in voxels decides how many
-// grid rows share a walk in parity mode (traverse.hip, k_parity_rows).
+// Also samples the y and z extents of the triangle boxes (about 256 workgroups' worth, fixed point,
+// so the sum depends neither on the order of the atomics nor on the run) into rootInfo[8..9] with
+// the number of triangles sampled in rootInfo[10]: the mean triangle size in voxels decides how
+// many grid rows share a walk in parity mode (traverse.hip, k_parity_rows).
 __global__ __launch_bounds__(kThreads) void k_tri_keys(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
                                                        uint32_t T, Bound4 bnd, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ rootInfo)
+                                                       uint32_t* __restrict__ rootInfo, uint32_t sampleStride)
 {
+    __shared__ unsigned long long part[kThreads / 64];
     const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
     unsigned long long ext = 0;
     if (k < T) {
@@ -49,8 +51,17 @@ __global__ __launch_bounds__(kThreads) void k_tri_keys(const float* __restrict__
         keys[k] = morton_key(lo, hi, k);
         ext = (unsigned long long)(((hi[1] - lo[1]) + (hi[2] - lo[2])) * 1048576.0f);      // 2^-20 units
     }
+    if (blockIdx.x % sampleStride) return;
     for (int off = 32; off; off >>= 1) ext += __shfl_down(ext, off);
-    if ((threadIdx.x & 63) == 0 && ext) atomicAdd(reinterpret_cast<unsigned long long*>(rootInfo + 8), ext);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ext;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+        for (int w = 0; w < kThreads / 64; ++w) sum += part[w];
+        atomicAdd(reinterpret_cast<unsigned long long*>(rootInfo + 8), sum);
+        const uint32_t first = blockIdx.x * kThreads;
+        atomicAdd(rootInfo + 10, T - first < (uint32_t)kThreads ? T - first : (uint32_t)kThreads);
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
@@ -141,17 +152,23 @@ __global__ __launch_bounds__(kThreads) void k_refit_atomic(const TriPos* __restr
     }
 }
 
-// K4, level-synchronous alternative: a node is finished in the sweep after both children are.
-// `ready` of the previous sweep is read-only; kernel boundaries give the visibility.
+// K4, level-synchronous: sweep number `epoch` (1, 2, ...) merges every node whose children were
+// finished by an EARLIER sweep and stamps it with its own number; a stamp of this very sweep, racing
+// in from another thread, reads as "not yet" (0 or >= epoch), so one array of stamps does for all
+// sweeps and kernel boundaries give the visibility of the boxes.
 __global__ __launch_bounds__(kThreads) void k_refit_sweep(const TriPos* __restrict__ triPos, uint32_t T,
-                                                          Node* __restrict__ nodes, const uint32_t* __restrict__ readyPrev,
-                                                          uint32_t* __restrict__ readyNext)
+                                                          Node* __restrict__ nodes, uint32_t* ready, uint32_t epoch)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T - 1) return;
-    if (readyPrev[i]) { readyNext[i] = 1; return; }
+    if (ready[i]) return;
     const int32_t c[2] = {nodes[i].c0, nodes[i].c1};
-    if ((c[0] >= 0 && !readyPrev[c[0]]) || (c[1] >= 0 && !readyPrev[c[1]])) { readyNext[i] = 0; return; }
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        if (c[side] < 0) continue;
+        const uint32_t stamp = ready[c[side]];
+        if (stamp == 0 || stamp >= epoch) return;
+    }
 #pragma unroll
     for (uint32_t side = 0; side < 2; ++side) {
         float lo[3], hi[3];
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void k_refit_sweep(const TriPos* __restri
         }
         store_child(&nodes[i], side, lo, hi, h);
     }
-    readyNext[i] = 1;
+    ready[i] = epoch;
 }
 
 // T == 1: one node, the second child is a far-away dummy that no ray accepts.
@@ -214,7 +231,7 @@ __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict
         rootInfo[3 + a] = __builtin_bit_cast(uint32_t, max_(hi[a], hi1[a]));
     }
     rootInfo[6] = (h0 > h1 ? h0 : h1) + 1;
-    rootInfo[7] = rootReady ? *rootReady : 1u;      // sweep refit: the root's ready flag of the last sweep
+    rootInfo[7] = rootReady ? (*rootReady != 0u ? 1u : 0u) : 1u;      // sweep refit: the root has been stamped
 }
 
 // K4 + K5 + root info over an existing hierarchy (links and parent words in place).
@@ -231,29 +248,24 @@ static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t 
         if (refitMode == 0) {
             k_refit_atomic<<<blocks_for(T), kThreads, 0, s>>>(b.triPos, T, b.nodes, b.parents, b.flags);
         } else {
-            uint32_t* prev = b.flags;
-            uint32_t* next = b.flags2;
-            uint32_t rootReady = 0;
+            uint32_t* ready = b.flags;
+            uint32_t rootReady = 0, epoch = 0;
             if (knownHeight) {
                 // same hierarchy as before (dxv_refit): a node of height h is ready after h sweeps, so
                 // exactly `height` sweeps finish the root; no host round trips, the stream stays async
-                for (uint32_t it = 0; it < knownHeight; ++it) {
-                    k_refit_sweep<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, b.nodes, prev, next);
-                    uint32_t* t = prev; prev = next; next = t;
-                }
-                rootReady = 1;      // verified on the device: k_root_info copies the root's ready flag
+                for (uint32_t it = 0; it < knownHeight; ++it)
+                    k_refit_sweep<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, b.nodes, ready, ++epoch);
+                rootReady = 1;      // verified on the device: k_root_info copies the root's stamp
             }
             // first build: tree height unknown (<= 62: distinct 62-bit keys); sweep in batches until the root is ready
             for (int batch = 0; batch < 16 && !rootReady; ++batch) {
-                for (int it = 0; it < 8; ++it) {
-                    k_refit_sweep<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, b.nodes, prev, next);
-                    uint32_t* t = prev; prev = next; next = t;
-                }
-                if ((e = hipMemcpyAsync(&rootReady, prev, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+                for (int it = 0; it < 8; ++it)
+                    k_refit_sweep<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, b.nodes, ready, ++epoch);
+                if ((e = hipMemcpyAsync(&rootReady, ready, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
                 if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
             }
             if (!rootReady) return hipErrorUnknown;
-            rootReadyFlag = prev;
+            rootReadyFlag = ready;
         }
     }
     k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
@@ -274,7 +286,8 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     if ((e = hipMemsetAsync(b.rootInfo, 0, 16 * sizeof(uint32_t), s)) != hipSuccess) return e;
 
     (void)hipEventRecord(ev[0], s);
-    k_tri_keys<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.rootInfo);
+    const uint32_t keyBlocks = blocks_for(T);
+    k_tri_keys<<<keyBlocks, kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.rootInfo, keyBlocks > 256u ? keyBlocks / 256u : 1u);
     (void)hipEventRecord(ev[1], s);
     if (T > 1) {
         if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;
