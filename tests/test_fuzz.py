@@ -78,3 +78,15 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
             v.set_option("queue", 1)
             v.set_option("wide", 0)
     v.close()
+
+
+@pytest.mark.gpu
+def test_randomised_soak_short(dxvlib, orc):
+    """tools/gpu_soak.py for a few seconds: random meshes x grids x partitions x every option."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_soak.py"), "12", "777"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and '"soak": "ok"' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
