@@ -563,21 +563,31 @@ DXV_HD uint8_t voxel_parity(const SceneView& sc, uint32_t N, uint32_t ix, uint32
 // not entirely left of oxMin; node tests use the outward-rounded boxes (supersets), and the
 // caller applies the exact per-row test (parity_row_setup) to what it is handed.  The walk depends
 // only on the five bounds: on the device it is wave-uniform (scalar node and triangle fetches, one
-// LDS stack per wave).  `NodeFetch(i)` returns NodePlanes, `TriFetch(leaf)` a TriPos.
+// LDS stack per wave).  `TriFetch(leaf)` returns a TriPos.
 // ------------------------------------------------------------------------------------------
-template <class NodeFetch, class TriFetch, class StackT, class Each>
-DXV_HD void walk_parity_rows(float ylo, float yhi, float zlo, float zhi, float oxMin, NodeFetch&& nodeAt, TriFetch&& triAt,
-                             StackT& stk, Each&& each)
+struct NodeHits { bool h0, h1; int32_t c0, c1; };
+
+// the node test of the row walk on decoded planes (host replay; the kernel tests in the half domain)
+DXV_HD NodeHits parity_rows_node(const NodePlanes& n, float ylo, float yhi, float zlo, float zhi, float oxMin)
+{
+    NodeHits r;
+    r.h0 = n.b[1] <= yhi && ylo <= n.b[4] && n.b[2] <= zhi && zlo <= n.b[5] && n.b[3] >= oxMin;
+    r.h1 = n.b[7] <= yhi && ylo <= n.b[10] && n.b[8] <= zhi && zlo <= n.b[11] && n.b[9] >= oxMin;
+    r.c0 = n.c0; r.c1 = n.c1;
+    return r;
+}
+
+// `visit(node)` returns which children of a node the rows may meet (NodeHits).
+template <class Visit, class TriFetch, class StackT, class Each>
+DXV_HD void walk_parity_rows(Visit&& visit, TriFetch&& triAt, StackT& stk, Each&& each)
 {
     int sp = 0;
     int32_t node = 0;
     for (;;) {
-        const NodePlanes n = nodeAt(node);
-        const bool h0 = n.b[1] <= yhi && ylo <= n.b[4] && n.b[2] <= zhi && zlo <= n.b[5] && n.b[3] >= oxMin;
-        const bool h1 = n.b[7] <= yhi && ylo <= n.b[10] && n.b[8] <= zhi && zlo <= n.b[11] && n.b[9] >= oxMin;
-        if (h0 && n.c0 < 0) each(triAt(~n.c0));
-        if (h1 && n.c1 < 0) each(triAt(~n.c1));
-        const bool i0 = h0 && n.c0 >= 0, i1 = h1 && n.c1 >= 0;
+        const NodeHits n = visit(node);
+        if (n.h0 && n.c0 < 0) each(triAt(~n.c0));
+        if (n.h1 && n.c1 < 0) each(triAt(~n.c1));
+        const bool i0 = n.h0 && n.c0 >= 0, i1 = n.h1 && n.c1 >= 0;
         if (i0 && i1) { stk.push(sp, n.c1); node = n.c0; }
         else if (i0) node = n.c0;
         else if (i1) node = n.c1;
@@ -586,13 +596,6 @@ DXV_HD void walk_parity_rows(float ylo, float yhi, float zlo, float zhi, float o
             node = stk.pop(sp);
         }
     }
-}
-
-// one row: the degenerate intervals
-template <class NodeFetch, class TriFetch, class StackT, class Each>
-DXV_HD void walk_parity_row(float oy, float oz, float oxMin, NodeFetch&& nodeAt, TriFetch&& triAt, StackT& stk, Each&& each)
-{
-    walk_parity_rows(oy, oy, oz, oz, oxMin, nodeAt, triAt, stk, each);
 }
 
 } // namespace dxv

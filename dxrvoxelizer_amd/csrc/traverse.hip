@@ -216,19 +216,26 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : RB == 2 ? 7 : 6) void k_parity_ro
     const SceneView& sc = p.scene;
     if (sc.rootLo[1] <= yhi && ylo <= sc.rootHi[1] && sc.rootLo[2] <= zhi && zlo <= sc.rootHi[2] && sc.rootHi[0] >= oxMin) {
         WaveStack stk{stack};
+        // Node tests in the half domain: a stored plane a is a half, so a <= y holds exactly when
+        // a <= half_down(y), and y <= a exactly when half_up(y) <= a.  The five bounds are rounded
+        // once per wave; a test is then one v_cmp_*_f16 on SGPR operands whose lane mask is ANDed on
+        // the scalar unit (the same comparisons written on floats compile to a convert, a compare,
+        // a select and a readfirstlane each).
+        const uint32_t Ydn = half_down(yhi), Yup = half_up(ylo), Zdn = half_down(zhi), Zup = half_up(zlo), Xup = half_up(oxMin);
+        auto le = [](uint32_t a, uint32_t b) {             // a <= b on the low 16 bits, as a lane mask
+            return __builtin_amdgcn_ballot_w64(__builtin_bit_cast(_Float16, (uint16_t)a) <= __builtin_bit_cast(_Float16, (uint16_t)b));
+        };
         walk_parity_rows(
-            ylo, yhi, zlo, zhi, oxMin,
             [&](int32_t i) {
-                const NodeSgpr n = load_node_scalar(sc.nodes, i);
-                NodePlanes q;                           // Node32 is axis-major: {lo0 lo1 hi0 hi1} per axis
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    q.b[a] = sgpr_half(n.w[a], 0); q.b[6 + a] = sgpr_half(n.w[a], 1);
-                    q.b[3 + a] = sgpr_half(n.w[a], 2); q.b[9 + a] = sgpr_half(n.w[a], 3);
-                }
-                q.c0 = (int32_t)(uint32_t)n.w[3];
-                q.c1 = (int32_t)(uint32_t)(n.w[3] >> 32);
-                return q;
+                const NodeSgpr n = load_node_scalar(sc.nodes, i);      // words: x lo, x hi | y lo, y hi | z lo, z hi | links
+                const uint32_t xh = (uint32_t)(n.w[0] >> 32), yl = (uint32_t)n.w[1], yh = (uint32_t)(n.w[1] >> 32);
+                const uint32_t zl = (uint32_t)n.w[2], zh = (uint32_t)(n.w[2] >> 32);
+                NodeHits r;
+                r.h0 = (le(yl, Ydn) & le(Yup, yh) & le(zl, Zdn) & le(Zup, zh) & le(Xup, xh)) != 0ull;
+                r.h1 = (le(yl >> 16, Ydn) & le(Yup, yh >> 16) & le(zl >> 16, Zdn) & le(Zup, zh >> 16) & le(Xup, xh >> 16)) != 0ull;
+                r.c0 = (int32_t)(uint32_t)n.w[3];
+                r.c1 = (int32_t)(uint32_t)(n.w[3] >> 32);
+                return r;
             },
             [&](int32_t leaf) { return load_tri_scalar(sc.triPos, leaf); }, stk,
             [&](const TriPos& tp) {

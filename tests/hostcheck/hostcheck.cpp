@@ -150,7 +150,7 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
             std::vector<uint32_t> cnt((size_t)RB * RB * N, 0);
             struct HostStack { int32_t e[128]; void push(int& sp, int32_t v) { e[sp++] = v; } int32_t pop(int& sp) { return e[--sp]; } } stk;
             if (scr.rootLo[1] <= yhi && ylo <= scr.rootHi[1] && scr.rootLo[2] <= zhi && zlo <= scr.rootHi[2] && scr.rootHi[0] >= ox[0])
-                walk_parity_rows(ylo, yhi, zlo, zhi, ox[0], [&](int32_t i) { return load_node(scr.nodes, i); },
+                walk_parity_rows([&](int32_t i) { return parity_rows_node(load_node(scr.nodes, i), ylo, yhi, zlo, zhi, ox[0]); },
                                  [&](int32_t leaf) { return load_tri(scr.triPos, leaf); }, stk,
                                  [&](const TriPos& tp) {
                                      for (uint32_t r = 0; r < RB * RB; ++r) {
