@@ -45,6 +45,7 @@ struct dxv_ctx {
     uint64_t* dKeysTmp = nullptr;
     uint32_t* dHist = nullptr;
     uint32_t* dParents = nullptr;
+    void* dPyramid = nullptr;        // min/max pyramid over the leaf boxes (dxv_refit), allocated on the first refit
     uint32_t* dFlags = nullptr;
     uint32_t* dFlags2 = nullptr;
     uint32_t* dRootInfo = nullptr;
@@ -145,6 +146,7 @@ int alloc_scene(dxv_ctx* c, uint32_t T, uint32_t V, bool wide)
 void free_scratch(dxv_ctx* c)
 {
     (void)hipFree(c->dKeys); (void)hipFree(c->dKeysTmp); (void)hipFree(c->dHist); (void)hipFree(c->dParents);
+    (void)hipFree(c->dPyramid); c->dPyramid = nullptr;
     (void)hipFree(c->dFlags); (void)hipFree(c->dFlags2);
     c->dKeys = c->dKeysTmp = nullptr; c->dHist = c->dParents = c->dFlags = c->dFlags2 = nullptr;
     c->scratchT = 0;
@@ -343,7 +345,7 @@ void fill_build_buffers(dxv_ctx* c, BuildBuffers& b)
     b.vb = c->dVb; b.ib = c->dIb; b.T = c->T; b.V = c->V;
     memcpy(b.bound, c->bound, sizeof(c->bound));
     b.keys = c->dKeys; b.keysTmp = c->dKeysTmp; b.hist = c->dHist; b.parents = c->dParents;
-    b.flags = c->dFlags; b.flags2 = c->dFlags2; b.rootInfo = c->dRootInfo;
+    b.flags = c->dFlags; b.flags2 = c->dFlags2; b.rootInfo = c->dRootInfo; b.pyramid = c->dPyramid;
     b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.nodes64 = c->hdr.hasWide ? scene_nodes64(c) : nullptr; b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
 }
 
@@ -395,8 +397,11 @@ int dxv_refit(dxv_ctx* c)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
     c->haveScene = false;
+    if (!c->dPyramid && c->optRefit == 1 && c->T > 1)      // refit=2 keeps the level sweeps for the refit as well
+        DXV_HIP(c, hipMalloc(&c->dPyramid, sizeof(float) * 6 * (size_t)pyramid_slots(c->T)));
     BuildBuffers b{};
     fill_build_buffers(c, b);
+    if (c->optRefit != 1) b.pyramid = nullptr;
     DXV_HIP(c, lbvh_refit(b, c->optRefit, c->hdr.treeHeight, c->stream, c->ev + 3));
     if (finish_build(c, "dxv_refit")) return 1;
     c->stats.refit_ms = elapsed(c->ev[3], c->ev[4]);
@@ -669,7 +674,7 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
             return fail(c, "option stack: %lld not in {0,8,12,16,24,32,48,64}", (long long)value);
         c->optStack = (int)value;
     } else if (!strcmp(key, "refit")) {
-        if (value != 0 && value != 1) return fail(c, "option refit: %lld not in {0,1}", (long long)value);
+        if (value < 0 || value > 2) return fail(c, "option refit: %lld not in {0,1,2}", (long long)value);
         c->optRefit = (int)value;
     } else if (!strcmp(key, "subbox")) {
         if (value != 0 && value != 1) return fail(c, "option subbox: %lld not in {0,1}", (long long)value);

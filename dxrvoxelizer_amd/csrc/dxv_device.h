@@ -22,7 +22,8 @@ struct BuildBuffers {
     uint32_t* hist;         // radix_sort_hist_words(T)
     uint32_t* parents;      // (T-1) internal + T leaf words: (parent << 1) | side
     uint32_t* flags;        // T-1 arrival counters (atomic refit) / ready flags (sweep refit)
-    uint32_t* flags2;       // T-1 (sweep refit ping-pong)
+    uint32_t* flags2;       // T-1: far end of every node's run of leaves (k_hierarchy -> pyramid refit)
+    void* pyramid;          // pyramid_slots(T) x 24 B min/max pyramid over the leaf boxes, or NULL (refit by sweeps)
     uint32_t* rootInfo;     // 8 words: rootLo[3], rootHi[3] (float bits), height, done
     Node* nodes;            // max(T-1,1), exact boxes
     Node32* nodes32;        // max(T-1,1), traversal copy
@@ -33,6 +34,7 @@ struct BuildBuffers {
 struct BuildTimes { float prep, sort, hierarchy, refit; };
 // refitMode: 0 = one pass, bottom-up with per-node arrival counters; 1 = level-synchronous sweeps
 hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[5]);
+uint32_t pyramid_slots(uint32_t T);
 hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight, hipStream_t s, hipEvent_t ev[2]);
 
 // traverse.hip

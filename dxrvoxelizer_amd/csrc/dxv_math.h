@@ -437,7 +437,9 @@ DXV_HD int key_delta(const uint64_t* keys, int64_t T, int64_t i, int64_t j)
 }
 
 // Internal node i of T-1 (T >= 2): children as links (>= 0 internal, < 0 ~leaf).
-DXV_HD void karras_node(const uint64_t* keys, int64_t T, int64_t i, int32_t& left, int32_t& right)
+// left/right: children links (>= 0 internal node, < 0 ~leaf); other: the far end of the node's
+// range of leaves [min(i, other), max(i, other)]; the left child ends at gamma = left >= 0 ? left : ~left.
+DXV_HD void karras_node(const uint64_t* keys, int64_t T, int64_t i, int32_t& left, int32_t& right, uint32_t& other)
 {
     const int d = key_delta(keys, T, i, i + 1) - key_delta(keys, T, i, i - 1) >= 0 ? 1 : -1;
     const int dmin = key_delta(keys, T, i, i - d);
@@ -457,6 +459,13 @@ DXV_HD void karras_node(const uint64_t* keys, int64_t T, int64_t i, int32_t& lef
     const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
     left = lo == gamma ? ~(int32_t)gamma : (int32_t)gamma;
     right = hi == gamma + 1 ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
+    other = (uint32_t)j;
+}
+
+DXV_HD void karras_node(const uint64_t* keys, int64_t T, int64_t i, int32_t& left, int32_t& right)
+{
+    uint32_t other;
+    karras_node(keys, T, i, left, right, other);
 }
 
 } // namespace dxv

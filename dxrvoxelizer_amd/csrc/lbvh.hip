@@ -89,14 +89,17 @@ __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict
 
 // parents[0 .. T-2]: internal nodes, parents[T-1 .. 2T-2]: leaves; word = (parent << 1) | side.
 __global__ __launch_bounds__(kThreads) void k_hierarchy(const uint64_t* __restrict__ keys, uint32_t T,
-                                                        Node* __restrict__ nodes, uint32_t* __restrict__ parents)
+                                                        Node* __restrict__ nodes, uint32_t* __restrict__ parents,
+                                                        uint32_t* __restrict__ rangeEnd)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T - 1) return;
     int32_t l, r;
-    karras_node(keys, (int64_t)T, (int64_t)i, l, r);
+    uint32_t other;
+    karras_node(keys, (int64_t)T, (int64_t)i, l, r, other);
     nodes[i].c0 = l;
     nodes[i].c1 = r;
+    rangeEnd[i] = other;              // node i covers the leaves between i and rangeEnd[i] (pyramid refit)
     parents[l >= 0 ? (uint32_t)l : (T - 1) + (uint32_t)~l] = (i << 1);
     parents[r >= 0 ? (uint32_t)r : (T - 1) + (uint32_t)~r] = (i << 1) | 1u;
     if (i == 0) parents[0] = 0xffffffffu;
@@ -294,10 +297,118 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     }
     (void)hipEventRecord(ev[2], s);
     k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm);
-    if (T > 1) k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents);
+    if (T > 1) k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents, b.flags2);
     (void)hipEventRecord(ev[3], s);
     if ((e = refit_stage(b, refitMode, s)) != hipSuccess) return e;
     (void)hipEventRecord(ev[4], s);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Refit of a known hierarchy without level sweeps.  Node i covers a contiguous run of leaves of
+// the Morton order (rangeEnd from k_hierarchy), so each child box is a range union: a min/max
+// pyramid over the leaf boxes (an implicit segment tree over P = 2^k >= T slots, heap order,
+// 24 B per entry, leaves recomputed from triPos) is built in two launches -- ten levels per
+// workgroup through LDS, the top by one workgroup -- and one launch over the nodes queries it,
+// at most 2 log2(run) entries per child.  Unions of the same leaf boxes by min/max: the same
+// bits as the bottom-up merge.  Heights are a property of the hierarchy and stay.
+// ---------------------------------------------------------------------------------------------
+struct Box6 { float lo[3], hi[3]; };
+__device__ __forceinline__ void box_empty(Box6& b) { for (int a = 0; a < 3; ++a) { b.lo[a] = __builtin_inff(); b.hi[a] = -__builtin_inff(); } }
+__device__ __forceinline__ void box_union(Box6& b, const Box6& o) { for (int a = 0; a < 3; ++a) { b.lo[a] = min_(b.lo[a], o.lo[a]); b.hi[a] = max_(b.hi[a], o.hi[a]); } }
+__device__ __forceinline__ Box6 leaf_box(const TriPos* __restrict__ triPos, uint32_t T, uint32_t leaf)
+{
+    Box6 b;
+    if (leaf < T) { const TriPos tp = triPos[leaf]; tri_box(tp.v0, tp.v1, tp.v2, b.lo, b.hi); }
+    else box_empty(b);
+    return b;
+}
+
+constexpr uint32_t kPyrLeaves = 1024;         // leaves per workgroup of k_pyramid_low = 10 levels
+__global__ __launch_bounds__(kThreads) void k_pyramid_low(const TriPos* __restrict__ triPos, uint32_t T, uint32_t P,
+                                                          Box6* __restrict__ pyr)
+{
+    __shared__ Box6 lds[kPyrLeaves / 2];                         // level 1 .. : at most 512 entries live at a time
+    const uint32_t j0 = blockIdx.x * kPyrLeaves;
+    // level 1 from the leaves
+    for (uint32_t e = threadIdx.x; e < kPyrLeaves / 2; e += kThreads) {
+        Box6 b = leaf_box(triPos, T, j0 + 2 * e);
+        box_union(b, leaf_box(triPos, T, j0 + 2 * e + 1));
+        lds[e] = b;
+        pyr[(P >> 1) + (j0 >> 1) + e] = b;
+    }
+    __syncthreads();
+    uint32_t n = kPyrLeaves / 4;
+    for (uint32_t level = 2; level <= 10; ++level, n >>= 1) {
+        Box6 b;
+        const bool mine = threadIdx.x < n;
+        if (mine) { b = lds[2 * threadIdx.x]; box_union(b, lds[2 * threadIdx.x + 1]); }
+        __syncthreads();
+        if (mine) { lds[threadIdx.x] = b; pyr[(P >> level) + (j0 >> level) + threadIdx.x] = b; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_pyramid_high(uint32_t P, Box6* pyr)
+{
+    for (uint32_t level = 11; (P >> level) >= 1u; ++level) {
+        const uint32_t n = P >> level;
+        for (uint32_t e = threadIdx.x; e < n; e += 1024u) {
+            Box6 b = pyr[(P >> (level - 1)) + 2 * e];
+            box_union(b, pyr[(P >> (level - 1)) + 2 * e + 1]);
+            pyr[n + e] = b;
+        }
+        __syncthreads();      // one workgroup: what it stored before the barrier is what it loads after
+    }
+}
+
+__device__ __forceinline__ Box6 range_box(const TriPos* __restrict__ triPos, uint32_t T, uint32_t P, const Box6* __restrict__ pyr,
+                                          uint32_t lo, uint32_t hi)
+{
+    Box6 b;
+    box_empty(b);
+    uint32_t l = lo + P, r = hi + P + 1u;
+    while (l < r) {
+        if (l & 1u) { box_union(b, l >= P ? leaf_box(triPos, T, l - P) : pyr[l]); ++l; }
+        if (r & 1u) { --r; box_union(b, r >= P ? leaf_box(triPos, T, r - P) : pyr[r]); }
+        l >>= 1; r >>= 1;
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(kThreads) void k_refit_ranges(const TriPos* __restrict__ triPos, uint32_t T, uint32_t P,
+                                                           const Box6* __restrict__ pyr, const uint32_t* __restrict__ rangeEnd,
+                                                           Node* __restrict__ nodes)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= T - 1) return;
+    const uint32_t j = rangeEnd[i], lo = i < j ? i : j, hi = i < j ? j : i;
+    const int32_t c0 = nodes[i].c0;
+    const uint32_t gamma = c0 >= 0 ? (uint32_t)c0 : (uint32_t)~c0;
+    const Box6 b0 = range_box(triPos, T, P, pyr, lo, gamma), b1 = range_box(triPos, T, P, pyr, gamma + 1u, hi);
+    float* w = reinterpret_cast<float*>(&nodes[i]);      // words 0..5: child 0 box, 6..11: child 1 box; links and heights stay
+    w[0] = b0.lo[0]; w[1] = b0.lo[1]; w[2] = b0.lo[2]; w[3] = b0.hi[0]; w[4] = b0.hi[1]; w[5] = b0.hi[2];
+    w[6] = b1.lo[0]; w[7] = b1.lo[1]; w[8] = b1.lo[2]; w[9] = b1.hi[0]; w[10] = b1.hi[1]; w[11] = b1.hi[2];
+}
+
+uint32_t pyramid_slots(uint32_t T)            // entries (24 B each) of the pyramid scratch for T leaves
+{
+    uint32_t P = kPyrLeaves;
+    while (P < T) P <<= 1;
+    return P;
+}
+
+static hipError_t refit_pyramid(const BuildBuffers& b, hipStream_t s)
+{
+    const uint32_t T = b.T, P = pyramid_slots(T);
+    const uint32_t numNodes = T > 1 ? T - 1 : 1;
+    Box6* pyr = reinterpret_cast<Box6*>(b.pyramid);
+    k_pyramid_low<<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr);
+    if (P > kPyrLeaves) k_pyramid_high<<<1, 1024, 0, s>>>(P, pyr);
+    k_refit_ranges<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes);
+    k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes64);
+    k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
     return hipGetLastError();
 }
 
@@ -312,7 +423,9 @@ hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight,
     if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
     (void)hipEventRecord(ev[0], s);
     k_tri_gather<<<blocks_for(b.T), kThreads, 0, s>>>(b.vb, b.ib, b.T, bnd, b.keys, b.triPos, b.triNrm);
-    if ((e = refit_stage(b, refitMode, s, treeHeight)) != hipSuccess) return e;
+    if (b.pyramid && refitMode != 0 && b.T > 1) e = refit_pyramid(b, s);
+    else e = refit_stage(b, refitMode, s, treeHeight);
+    if (e != hipSuccess) return e;
     (void)hipEventRecord(ev[1], s);
     return hipGetLastError();
 }

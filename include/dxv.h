@@ -172,7 +172,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   wide   0|1    reference rule over four-box nodes; builds the extra scene section (default 0)
  *   rows   0|1    parity rule: one tree walk per grid row (default 1)
  *   rowblock 0|1|2|4  ... per row (1), per 2 x 2 or 4 x 4 rows; 0 (default) decides by triangle size
- *   refit  0|1    box merge by level sweeps (1, default) or one atomic pass (0)
+ *   refit  0|1|2  build: box merge by level sweeps (1, 2) or one atomic pass (0); dxv_refit: min/max
+ *                 pyramid over the leaf order (1, default), sweeps (2), atomic pass (0)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
 

@@ -558,3 +558,30 @@ def test_parity_row_blocks_equal_single_rows(vox, orc, request, name):
         assert np.array_equal(vox.Grid(), want)
     finally:
         vox.set_option("rowblock", 0)
+
+
+def test_pyramid_refit_equals_sweep_refit_word_for_word(dxv, bunny):
+    """dxv_refit builds the boxes from a min/max pyramid over the Morton-ordered leaves (refit=1);
+    the level sweeps (refit=2) and the atomic climb (refit=0) must produce the same node words --
+    boxes, links, heights -- for tiny, odd-sized and asset meshes."""
+    rng = np.random.default_rng(11)
+    vbB, ibB, _ = bunny
+    cases = [meshes.soup(n, seed=77 + n, edge=0.2) for n in (1, 2, 3, 5, 17, 1023, 1024, 1025, 3000)] + [(vbB, ibB)]
+    for vb, ib in cases:
+        vb = np.ascontiguousarray(vb, np.float32)
+        moved = vb.copy()
+        moved[:, :3] += rng.uniform(-0.01, 0.01, size=(len(vb), 3)).astype(np.float32)
+        lo, hi = vb[:, :3].min(0) - 1, vb[:, :3].max(0) + 1
+        pins = np.zeros((2, 6), np.float32)
+        pins[0, :3], pins[1, :3] = lo, hi                        # unreferenced vertices pin the bound
+        vb0, vb1 = np.concatenate([vb, pins]), np.concatenate([moved, pins])
+        words = []
+        for refit in (1, 2, 0):
+            v = dxv.Voxelizer(0)
+            v.set_option("refit", refit)
+            v.InitFromArrays(vb0, ib)
+            v.UpdateVertices(vb1)
+            words.append((v.debug(DBG_NODES).copy(), v.debug(DBG_NODES32).copy(), v.stats()["tree_height"]))
+            v.close()
+        for other in words[1:]:
+            assert np.array_equal(words[0][0], other[0]) and np.array_equal(words[0][1], other[1]) and words[0][2] == other[2], len(ib) // 3
