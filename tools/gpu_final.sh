@@ -36,6 +36,7 @@ python tools/ab_option.py stack0 12,16,20,24 --rounds 2 > $OUT/ab_stack0.jsonl 2
 python tools/rowblock_table.py > $OUT/rowblock.jsonl 2>&1
 python tools/small_grid_latency.py > $OUT/small_grid_latency.jsonl 2>&1
 python tools/texel_time.py > $OUT/texel_time.jsonl 2>&1
+python tools/frame_loop.py > $OUT/frame_loop.jsonl 2>&1
 python tools/sweep.py --meshes torus1m,bunny,dragon --grids 256,512 --bricks 4 --stacks 0 --modes reference,parity --reps 5 > $OUT/sweep.jsonl 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/prof_bench.log 2>&1
