@@ -174,10 +174,11 @@ float elapsed(hipEvent_t a, hipEvent_t b)
 }
 
 // Stack policy.  The stack never needs more than treeHeight entries, but rays rarely push more
-// than a dozen, and LDS (entries * 4 B * threads) is what limits resident waves.  Adaptive mode
-// starts at 20 entries; a kernel that runs out reports it through the status word and dxv_sync
-// re-runs the launch with the next larger depth (up to the always-sufficient one) and keeps it for
-// this scene.
+// than a dozen, and LDS (entries * 4 B * threads) is what limits resident waves.  Launches use 20
+// entries; the few rays that run out of them are listed and finished by k_voxelize_redo with a
+// 64-entry column right behind the launch.  Only when a launch fills that list does it report
+// through the status word, and dxv_sync then re-runs it with the next larger depth (up to the
+// always-sufficient one) and keeps that depth for this scene.
 // (+3: the postponed-leaf traversal keeps room for one push and two queued leaves)
 // The wide walk pushes up to three entries per wide level (two binary levels) and keeps room for
 // four more slots: 3 * ceil(h / 2) + 5.  Trees too deep for the largest column use the binary walk.
