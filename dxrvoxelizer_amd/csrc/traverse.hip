@@ -9,9 +9,9 @@
 // private L2 sees compact regions while the uneven per-region cost balances.  Only the bricks the
 // exact root early-out cannot clear are launched when that removes a good part of the grid.
 // The per-thread traversal stack (shared with the postponed-leaf queue) is an LDS column
-// (stack[entry][thread]: consecutive lanes hit consecutive banks); its depth adapts (dxv_api.hip)
-// and an overflow is reported through the status word, never ignored.
-// Parity mode normally runs k_parity_rows (one wave-uniform walk per grid row, below).
+// (stack[entry][thread]: consecutive lanes hit consecutive banks); a ray that runs out of it is
+// listed and finished by k_voxelize_redo with a deep column, never ignored (dxv_api.hip).
+// Parity mode normally runs k_parity_rows (one wave-uniform walk per block of grid rows, below).
 #include "dxv_device.h"
 #include "dxv_trace.h"
 
