@@ -209,7 +209,7 @@ int launch_now(dxv_ctx* c)
     p.regionBits = (uint32_t)c->optRegion;
     p.queued = (uint32_t)c->optQueue;
     p.subbox = (uint32_t)c->optSubbox;
-    p.wide = use_wide(c, p.mode) ? 1u : 0u;
+    p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     const int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
@@ -681,7 +681,7 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
         if (value != 0 && value != 1) return fail(c, "option subbox: %lld not in {0,1}", (long long)value);
         c->optSubbox = (int)value;
     } else if (!strcmp(key, "wide")) {
-        if (value != 0 && value != 1) return fail(c, "option wide: %lld not in {0,1}", (long long)value);
+        if (value < 0 || value > 2) return fail(c, "option wide: %lld not in {0,1,2}", (long long)value);
         c->optWide = (int)value;
         // the wide copy is a section of the scene: a scene built without it is built again
         if (value && c->haveScene && !c->hdr.hasWide) {

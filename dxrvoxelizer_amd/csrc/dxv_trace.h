@@ -448,6 +448,65 @@ DXV_HD bool walk_queued_wide(const Ray& r, const Node64* nodes, const TriPos* tr
     return node != kNodeOverflow;
 }
 
+// Hybrid: wave-uniform visits take the four-box node (scalar fetch: half as many dependent
+// fetches where the wave walks together), divergent visits the binary node (the wide one would
+// double their vector loads).  Both copies are indexed by the binary node, so the walk switches
+// from visit to visit.  Host builds (one ray at a time) take the binary node throughout.
+template <class Stack, class Leaf>
+DXV_HD bool walk_queued_hybrid(const Ray& r, const Node32* nodes, const Node64* wide, const TriPos* tris, const Stack& stk, int cap,
+                               const float& bestT, Leaf&& leaf)
+{
+    stk.put(0, -1);
+    int sp = 1, qn = 0;
+    int32_t node = 0;
+    const bool negx = r.ox < 0.0f, negy = r.oy < 0.0f, negz = r.oz < 0.0f;   // as in walk_queued
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t active = __builtin_amdgcn_ballot_w64(true);
+    const uint64_t bx = __builtin_amdgcn_ballot_w64(negx), by = __builtin_amdgcn_ballot_w64(negy), bz = __builtin_amdgcn_ballot_w64(negz);
+    const bool octant = (bx == 0ull || bx == active) && (by == 0ull || by == active) && (bz == 0ull || bz == active);
+    const bool unx = bx != 0ull, uny = by != 0ull, unz = bz != 0ull;
+#else
+    (void)wide;
+#endif
+    for (;;) {
+        if (node >= 0 && sp + qn + kWideRoom > cap) node = kNodeOverflow;
+        if (node >= 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int32_t n0 = __builtin_amdgcn_readfirstlane(node);
+            if (octant && __builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
+                const WideSgpr n = load_wide_scalar(wide, n0);
+                wide_step(r, unx ? n.w[1] : n.w[0], unx ? n.w[0] : n.w[1], uny ? n.w[3] : n.w[2], uny ? n.w[2] : n.w[3],
+                          unz ? n.w[5] : n.w[4], unz ? n.w[4] : n.w[5], (int32_t)(uint32_t)n.w[6], (int32_t)(uint32_t)(n.w[6] >> 32),
+                          (int32_t)(uint32_t)n.w[7], (int32_t)(uint32_t)(n.w[7] >> 32), stk, cap, bestT, node, sp, qn);
+            } else
+#endif
+            {
+                const NodeWords n = load_node_words(nodes, node);
+                node_step<false>(r, negx ? n.w[1] : n.w[0], negx ? n.w[0] : n.w[1], negy ? n.w[3] : n.w[2], negy ? n.w[2] : n.w[3],
+                                 negz ? n.w[5] : n.w[4], negz ? n.w[4] : n.w[5], n.c0, n.c1, stk, cap, bestT, node, sp, qn);
+            }
+        }
+        const bool walking = wave_any(node >= 0);
+        if (walking && !wave_any_both(sp + qn + kWideRoom > cap, qn > 0)) continue;
+        for (int i = 0; wave_any(i < qn); ++i) {
+            if (i < qn) {
+                const int32_t l = stk.get(cap - 1 - i);
+                leaf(l, load_tri(tris, l));
+            }
+        }
+        qn = 0;
+        if (!walking) break;
+    }
+    return node != kNodeOverflow;
+}
+
+template <class Stack>
+DXV_HD bool trace_reference_h(Ray& r, const Node32* nodes, const Node64* wide, const TriPos* tris, const Stack& stk, int cap, Hit& best)
+{
+    best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
+    return walk_queued_hybrid<Stack, LeafReference>(r, nodes, wide, tris, stk, cap, best.t, LeafReference{r, best});
+}
+
 template <class Stack, bool STATS = false>
 DXV_HD bool trace_reference_w(Ray& r, const Node64* nodes, const TriPos* tris, const Stack& stk, int cap, Hit& best,
                               TraceStats* st = nullptr)
@@ -519,7 +578,7 @@ struct SceneView {
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
 // WALK: 0 = leaves tested as they are met, 1 = postponed-leaf walk, 2 = postponed-leaf walk over the
-// wide nodes.  All three return the same voxel.
+// wide nodes, 3 = wide nodes on wave-uniform visits only.  All return the same voxel.
 template <int WALK, class Stack>
 DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
                                const Stack& stk, int cap, uint32_t* texel, bool& overflow)
@@ -530,7 +589,8 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
     finish_ray_reference(r);
     Hit best;
-    const bool ok = WALK == 2 ? trace_reference_w(r, sc.wide, sc.triPos, stk, cap, best)
+    const bool ok = WALK == 3 ? trace_reference_h(r, sc.nodes, sc.wide, sc.triPos, stk, cap, best)
+                  : WALK == 2 ? trace_reference_w(r, sc.wide, sc.triPos, stk, cap, best)
                   : WALK == 1 ? trace_reference_q(r, sc.nodes, sc.triPos, stk, cap, best)
                               : trace_reference(r, sc.nodes, sc.triPos, stk, cap, best);
     if (!ok) { overflow = true; return 0; }

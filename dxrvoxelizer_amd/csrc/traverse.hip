@@ -391,7 +391,8 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
         if (p.texels) {
             if (p.wide) k_voxelize<B, STACK, 0, true, 2><<<g, b, 0, s>>>(p);
             else k_voxelize<B, STACK, 0, true, 1><<<g, b, 0, s>>>(p);
-        } else if (p.wide) k_voxelize<B, STACK, 0, false, 2><<<g, b, 0, s>>>(p);
+        } else if (p.wide == 2) k_voxelize<B, STACK, 0, false, 3><<<g, b, 0, s>>>(p);
+        else if (p.wide) k_voxelize<B, STACK, 0, false, 2><<<g, b, 0, s>>>(p);
         else if (p.queued) k_voxelize<B, STACK, 0, false, 1><<<g, b, 0, s>>>(p);
         else k_voxelize<B, STACK, 0, false, 0><<<g, b, 0, s>>>(p);
     } else {

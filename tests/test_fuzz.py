@@ -65,7 +65,7 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
             v.InitFromArrays(vb, ib)
             for mode in (0, 1):
                 want = s.voxelize(N, mode=mode, algo=orc.ALGO_BRUTE)
-                for rows, queue, wide in (((1, 1, 1), (1, 1, 0), (1, 0, 0)) if mode == 0 else ((1, 1, 1), (0, 1, 1), (0, 0, 1))):
+                for rows, queue, wide in (((1, 1, 1), (1, 1, 2), (1, 1, 0), (1, 0, 0)) if mode == 0 else ((1, 1, 1), (0, 1, 1), (0, 0, 1))):
                     v.set_option("rows", rows)
                     v.set_option("queue", queue)
                     v.set_option("wide", wide)

@@ -518,6 +518,11 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
         vox.Voxelize(n)
         g2 = vox.Grid()
         redo = vox.stats()["redo_rays"]
+        vox.set_option("stack", 0)
+        vox.set_option("wide", 2)                         # four-box nodes on wave-uniform visits only
+        vox.EnableTexels(False)
+        vox.Voxelize(n)
+        assert np.array_equal(vox.Grid(), g0)
     finally:
         vox.set_option("stack", 0)
         vox.set_option("wide", 0)

@@ -53,7 +53,7 @@ def main():
             s = orc.Scene(vb, ib)
         except Exception:
             continue
-        v.set_option("wide", int(rng.integers(0, 2)))
+        v.set_option("wide", int(rng.integers(0, 3)))
         v.InitFromArrays(vb, ib)
         cases += 1
         for _ in range(4):
@@ -62,7 +62,7 @@ def main():
             mode = int(rng.integers(0, 2))
             want = s.voxelize(N, mode=mode, algo=orc.ALGO_BRUTE if T * N ** 3 < 3e8 else orc.ALGO_BVH)
             opts = {"queue": int(rng.integers(0, 2)), "rows": int(rng.integers(0, 2)), "rowblock": int(rng.choice([0, 1, 2, 4])),
-                    "wide": int(rng.integers(0, 2)), "brick": int(rng.integers(0, 8)), "stack": int(rng.choice([0, 0, 12, 16, 32])),
+                    "wide": int(rng.integers(0, 3)), "brick": int(rng.integers(0, 8)), "stack": int(rng.choice([0, 0, 12, 16, 32])),
                     "subbox": int(rng.integers(0, 2)), "morton": int(rng.integers(0, 2))}
             for k, val in opts.items():
                 v.set_option(k, val)
