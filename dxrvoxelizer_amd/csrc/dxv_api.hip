@@ -78,8 +78,8 @@ struct dxv_ctx {
     int optMorton = 1;       // Morton brick order
     int optQueue = 1;        // postponed-leaf traversal
     int optSubbox = 1;       // launch only the bricks around the scene's root box, memset the rest
-    int optWide = 0;         // reference rule: walk the wide (up to 4 boxes) nodes; measured -8 % on low-poly meshes,
-                             // +10 % on 1 M triangles at 256^3, so off unless asked for
+    int optWide = 2;         // reference rule: 2 = four-box nodes on wave-uniform visits (-2...-7 % everywhere measured),
+                             // 1 = on every visit (-8 % on low-poly meshes, +10 % on 1 M triangles at 256^3), 0 = binary only
     int optRows = 1;         // parity mode: one tree walk per grid row (k_parity_rows) instead of per voxel
     int optRowBlock = 0;     // rows per side of a wave's block of rows: 0 = by triangle size, 1, 2
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)

@@ -469,11 +469,12 @@ DXV_HD bool walk_queued_hybrid(const Ray& r, const Node32* nodes, const Node64* 
     (void)wide;
 #endif
     for (;;) {
-        if (node >= 0 && sp + qn + kWideRoom > cap) node = kNodeOverflow;
+        if (node >= 0 && sp + qn + 3 > cap) node = kNodeOverflow;       // room for a binary step, as in walk_queued
         if (node >= 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const int32_t n0 = __builtin_amdgcn_readfirstlane(node);
-            if (octant && __builtin_amdgcn_ballot_w64(node != n0) == 0ull) {
+            // (a four-box step needs up to four free slots: taken only while every lane has them)
+            if (octant && __builtin_amdgcn_ballot_w64(node != n0) == 0ull && !wave_any(sp + qn + kWideRoom > cap)) {
                 const WideSgpr n = load_wide_scalar(wide, n0);
                 wide_step(r, unx ? n.w[1] : n.w[0], unx ? n.w[0] : n.w[1], uny ? n.w[3] : n.w[2], uny ? n.w[2] : n.w[3],
                           unz ? n.w[5] : n.w[4], unz ? n.w[4] : n.w[5], (int32_t)(uint32_t)n.w[6], (int32_t)(uint32_t)(n.w[6] >> 32),
@@ -487,7 +488,7 @@ DXV_HD bool walk_queued_hybrid(const Ray& r, const Node32* nodes, const Node64* 
             }
         }
         const bool walking = wave_any(node >= 0);
-        if (walking && !wave_any_both(sp + qn + kWideRoom > cap, qn > 0)) continue;
+        if (walking && !wave_any_both(sp + qn + 3 > cap, qn > 0)) continue;
         for (int i = 0; wave_any(i < qn); ++i) {
             if (i < qn) {
                 const int32_t l = stk.get(cap - 1 - i);

@@ -215,10 +215,13 @@ __global__ __launch_bounds__(kThreads) void k_compress_nodes(const Node* __restr
 
 // K6: wide traversal copy (dxv_types.h Node64): every binary node with its internal children
 // replaced by their children.  A pure gather from the refitted nodes, so a refit only re-runs it.
-__global__ __launch_bounds__(kThreads) void k_widen_nodes(const Node* __restrict__ nodes, uint32_t n, Node64* __restrict__ out)
+__global__ __launch_bounds__(kThreads) void k_widen_nodes(const Node* __restrict__ nodes, uint32_t n, Node32* __restrict__ out32,
+                                                          Node64* __restrict__ out)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i < n) out[i] = widen_node(nodes, (int32_t)i);
+    if (i >= n) return;
+    out32[i] = compress_node(nodes[i]);         // K5 in the same pass when both copies are wanted
+    out[i] = widen_node(nodes, (int32_t)i);
 }
 
 // rootInfo: lo[3], hi[3] (float bits), height of the root, 1
@@ -271,8 +274,8 @@ static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t 
             rootReadyFlag = ready;
         }
     }
-    k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
-    if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes64);
+    if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
+    else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, rootReadyFlag);
     return hipGetLastError();
 }
@@ -406,8 +409,8 @@ static hipError_t refit_pyramid(const BuildBuffers& b, hipStream_t s)
     k_pyramid_low<<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr);
     if (P > kPyrLeaves) k_pyramid_high<<<1, 1024, 0, s>>>(P, pyr);
     k_refit_ranges<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes);
-    k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
-    if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes64);
+    if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
+    else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
     return hipGetLastError();
 }

@@ -76,7 +76,7 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
                     v.set_option("rowblock", 0)
             v.set_option("rows", 1)
             v.set_option("queue", 1)
-            v.set_option("wide", 0)
+            v.set_option("wide", 2)
     v.close()
 
 

@@ -55,14 +55,17 @@ def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
     assert np.array_equal(nodes[:, 14:16], want[:, 14:16]), "subtree heights differ"
     assert st["tree_height"] == h.height
     assert np.array_equal(vox.debug(DBG_NODES32), h.nodes32()), "compressed traversal nodes differ"
-    with pytest.raises(Exception):
-        vox.debug(DBG_NODES64)                            # the wide copy is only built on request
-    vox.set_option("wide", 1)                             # ... which builds the scene again with it
+    assert np.array_equal(vox.debug(DBG_NODES64), h.nodes64()), "wide traversal nodes differ"
+    vox.set_option("wide", 0)                             # the wide copy is a section of the scene: built on request
     try:
-        assert np.array_equal(vox.debug(DBG_NODES, ), nodes)
-        assert np.array_equal(vox.debug(DBG_NODES64), h.nodes64()), "wide traversal nodes differ"
+        vox.InitFromArrays(vb, ib)
+        with pytest.raises(Exception):
+            vox.debug(DBG_NODES64)
+        assert np.array_equal(vox.debug(DBG_NODES), nodes)
+        vox.set_option("wide", 1)                         # ... asking for it builds the scene again with it
+        assert np.array_equal(vox.debug(DBG_NODES64), h.nodes64())
     finally:
-        vox.set_option("wide", 0)
+        vox.set_option("wide", 2)
     tp = vox.debug(DBG_TRI_POS)
     k = tp[:, 3].view(np.uint32)
     assert np.array_equal(np.sort(k), np.arange(len(k), dtype=np.uint32))
@@ -298,6 +301,7 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     import torch
     vb, ib, _ = dragon
     a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
+    a.set_option("wide", 0)                               # first a scene without the wide copy
     a.InitFromArrays(vb, ib)
     n = a.scene_bytes()
     blob = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -367,7 +371,7 @@ def test_errors_are_loud(dxv, bunny):
         v.Voxelize(128)
         assert v.stats()["stack_entries"] > 8 and np.array_equal(v.Grid(), want128)
         v.set_option("stack0", 20)
-    v.set_option("wide", 0)
+    v.set_option("wide", 2)
     one = dxv.Voxelizer(0)
     one.InitFromArrays(tri, np.arange(3, dtype=np.uint32))
     one.Voxelize(16)
@@ -506,6 +510,7 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
     """Option wide = 1: the reference rule over the four-box nodes (Node64) -- same grid, same texels,
     and at 64^3 the oracle's grid."""
     vb, ib, _ = request.getfixturevalue(name)
+    vox.set_option("wide", 0)
     vox.InitFromArrays(vb, ib)
     vox.EnableTexels(True)
     vox.Voxelize(n)
@@ -525,7 +530,7 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
         assert np.array_equal(vox.Grid(), g0)
     finally:
         vox.set_option("stack", 0)
-        vox.set_option("wide", 0)
+        vox.set_option("wide", 2)
         vox.EnableTexels(False)
     assert np.array_equal(g0, g1) and np.array_equal(t0, t1) and np.array_equal(g0, g2)
     assert redo > 0
