@@ -218,21 +218,29 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : RB == 2 ? 7 : 6) void k_parity_ro
         WaveStack stk{stack};
         // Node tests in the half domain: a stored plane a is a half, so a <= y holds exactly when
         // a <= half_down(y), and y <= a exactly when half_up(y) <= a.  The five bounds are rounded
-        // once per wave; a test is then one v_cmp_*_f16 on SGPR operands whose lane mask is ANDed on
-        // the scalar unit (the same comparisons written on floats compile to a convert, a compare,
-        // a select and a readfirstlane each).
-        const uint32_t Ydn = half_down(yhi), Yup = half_up(ylo), Zdn = half_down(zhi), Zup = half_up(zlo), Xup = half_up(oxMin);
-        auto le = [](uint32_t a, uint32_t b) {             // a <= b on the low 16 bits, as a lane mask
-            return __builtin_amdgcn_ballot_w64(__builtin_bit_cast(_Float16, (uint16_t)a) <= __builtin_bit_cast(_Float16, (uint16_t)b));
-        };
+        // once per wave.  A word of the node holds one plane of BOTH children, so the five
+        // differences "how far outside" are five packed half subtractions, their maximum four packed
+        // max, and a child is met when its half of the result is <= 0 (the difference of two halves is
+        // a multiple of 2^-24, so rounding never turns a non-zero difference into zero or flips its
+        // sign).  9 vector + 7 scalar instructions per node; written as ten float comparisons the
+        // test was a convert, a compare, a select and a readfirstlane each.
+        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+        auto H2 = [](uint32_t w) { return __builtin_bit_cast(half2_t, w); };
+        auto both = [](uint32_t h) { return (h & 0xffffu) | (h << 16); };
+        const half2_t ydn = H2(both(half_down(yhi))), yup = H2(both(half_up(ylo))), zdn = H2(both(half_down(zhi)));
+        const half2_t zup = H2(both(half_up(zlo))), xup = H2(both(half_up(oxMin)));
         walk_parity_rows(
             [&](int32_t i) {
                 const NodeSgpr n = load_node_scalar(sc.nodes, i);      // words: x lo, x hi | y lo, y hi | z lo, z hi | links
                 const uint32_t xh = (uint32_t)(n.w[0] >> 32), yl = (uint32_t)n.w[1], yh = (uint32_t)(n.w[1] >> 32);
                 const uint32_t zl = (uint32_t)n.w[2], zh = (uint32_t)(n.w[2] >> 32);
+                half2_t m = __builtin_elementwise_max(__builtin_elementwise_max(H2(yl) - ydn, yup - H2(yh)),
+                                                      __builtin_elementwise_max(H2(zl) - zdn, zup - H2(zh)));
+                m = __builtin_elementwise_max(m, xup - H2(xh));
+                const uint32_t out = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, m));   // > 0: outside
                 NodeHits r;
-                r.h0 = (le(yl, Ydn) & le(Yup, yh) & le(zl, Zdn) & le(Zup, zh) & le(Xup, xh)) != 0ull;
-                r.h1 = (le(yl >> 16, Ydn) & le(Yup, yh >> 16) & le(zl >> 16, Zdn) & le(Zup, zh >> 16) & le(Xup, xh >> 16)) != 0ull;
+                r.h0 = (out & 0x8000u) != 0u || (out & 0x7fffu) == 0u;
+                r.h1 = (out & 0x80000000u) != 0u || (out & 0x7fff0000u) == 0u;
                 r.c0 = (int32_t)(uint32_t)n.w[3];
                 r.c1 = (int32_t)(uint32_t)(n.w[3] >> 32);
                 return r;
