@@ -223,10 +223,6 @@ __device__ __forceinline__ NodeSgpr load_node_scalar(const Node32* nodes, int32_
                  : "=&s"(n.w[0]), "=&s"(n.w[1]), "=&s"(n.w[2]), "=&s"(n.w[3]) : "s"(p) : "memory");
     return n;
 }
-__device__ __forceinline__ float sgpr_half(uint64_t v, int which)   // which = 0..3: 16-bit field of the pair
-{
-    return half_bits_to_float((uint32_t)(v >> (16 * which)) & 0xffffu);
-}
 #endif
 
 // The walk shared by both occupancy rules.  `Leaf` is called once per queued triangle:
