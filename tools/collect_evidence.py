@@ -15,8 +15,8 @@ DST = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def newest(pattern):
-    files = glob.glob(pattern)
-    return max(files, key=lambda f: int(os.path.basename(f).split("_")[0])) if files else None
+    files = glob.glob(pattern)            # (run directories are named after a PID: the newest is the last one written)
+    return max(files, key=os.path.getmtime) if files else None
 
 
 def short(name):
