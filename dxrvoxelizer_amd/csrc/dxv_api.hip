@@ -214,11 +214,18 @@ int launch_now(dxv_ctx* c)
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {
-        // rows whose triangles span several voxels share a walk: 2 x 2 rows per wave above 1.2 voxels of
-        // mean triangle extent, 4 x 4 above 3.3 (measured crossovers, profiles/r01/final/rowblock.jsonl;
-        // voxel-sized triangles are 1.2-2x slower in blocks, 4-7 voxel ones 2.7-4x faster)
+        // rows whose triangles span several voxels share a walk: 4 x 4 rows per wave above 1.5 voxels of
+        // mean triangle extent, 2 x 2 above 1.2 -- as long as the launch still has enough waves to fill
+        // the GPU twice (blocks of a small grid or a thin slab leave it idle).  Measured crossovers:
+        // profiles/r01/final/rowblock.jsonl; voxel-sized triangles are 1.2-2x slower in blocks, 4-7
+        // voxel ones 3-5x faster.
         const float voxels = c->hdr.triExtent * 0.5f * (float)p.N;
-        const int rowBlock = c->optRowBlock ? c->optRowBlock : (voxels > 3.3f ? 4 : voxels > 1.2f ? 2 : 1);
+        const uint64_t nseg = (p.N + 511u) / 512u;
+        auto waves = [&](uint32_t rb) { return (uint64_t)((p.N + rb - 1u) / rb) * ((p.nz + rb - 1u) / rb) * nseg; };
+        int rowBlock = 1;
+        if (voxels > 1.5f && waves(4) >= 12288u) rowBlock = 4;
+        else if (voxels > 1.2f && waves(2) >= 12288u) rowBlock = 2;
+        if (c->optRowBlock) rowBlock = c->optRowBlock;
         c->stats.row_block = (uint32_t)rowBlock;
         DXV_HIP(c, launch_parity_rows(p, rowBlock, c->stream));
         c->lastRedoParity = -1;

@@ -167,7 +167,7 @@ struct WaveStack {
 // voxels, slower where they are voxel sized (every visited triangle is set up once per row it
 // might cross) -- the launcher decides by the mean triangle extent.
 template <int CH, int RB>
-__global__ __launch_bounds__(64, RB == 1 ? 8 : RB == 2 ? 7 : 6) void k_parity_rows(VoxelizeParams p)   // <= 64 / 72 / 80 VGPRs
+__global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizeParams p)   // <= 64 / 80 VGPRs
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the stub: the body uses SGPR inline asm)
     static_assert(RB == 1 || RB == 2 || RB == 4, "1, 2 x 2 or 4 x 4 rows");
@@ -207,6 +207,13 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : RB == 2 ? 7 : 6) void k_parity_ro
     float ox[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) ray_origin(N, x0 + 64u * c + lane, iy[0], p.z0, ox[c], t0, t1);
+    // lane r < ROWS carries the origin of row r = ry + RB * rz (the other lanes repeat rows; RB > 1 only)
+    float oyLane = oy[0], ozLane = oz[0];
+#pragma unroll
+    for (int k = 1; k < RB; ++k) {
+        if ((lane % ROWS) % RB == (uint32_t)k) oyLane = oy[k];
+        if ((lane % ROWS) / RB == (uint32_t)k) ozLane = oz[k];
+    }
     uint32_t bits[WORDS];                              // parity of voxel (row r = ry + RB * rz, run c) in bit r * CH + c
 #pragma unroll
     for (int w = 0; w < WORDS; ++w) bits[w] = 0;
@@ -247,17 +254,35 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : RB == 2 ? 7 : 6) void k_parity_ro
             },
             [&](int32_t leaf) { return load_tri_scalar(sc.triPos, leaf); }, stk,
             [&](const TriPos& tp) {
-                // one row after the other: the scheduling barrier keeps the set-ups from being interleaved
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const ParityRowTri s = parity_row_setup(oy[r % RB], oz[r / RB], tp.v0, tp.v1, tp.v2);
+                if (RB == 1) {
+                    const ParityRowTri s = parity_row_setup(oy[0], oz[0], tp.v0, tp.v1, tp.v2);
                     if (s.hit) {
                         uint32_t hits = 0;
 #pragma unroll
                         for (int c = 0; c < CH; ++c) hits |= (parity_row_voxel(s, ox[c]) ? 1u : 0u) << c;
-                        bits[(r * CH) / 32] ^= hits << ((r * CH) % 32);
+                        bits[0] ^= hits;
                     }
-                    if (RB > 1) __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    // The per-row set-up is the same arithmetic for every row of the block: lane r does it
+                    // for row r (all at once, instead of once per row on wave-uniform values), the rows
+                    // that the triangle can cross are then taken one by one, their eight set-up values
+                    // broadcast from their lane.
+                    const ParityRowTri mine = parity_row_setup(oyLane, ozLane, tp.v0, tp.v1, tp.v2);
+                    uint64_t rows = __builtin_amdgcn_ballot_w64(mine.hit) & ((1ull << ROWS) - 1ull);
+                    while (rows) {
+                        const int r = __builtin_ctzll(rows);
+                        rows &= rows - 1ull;
+                        auto bc = [r](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+                        ParityRowTri s;
+                        s.U = bc(mine.U); s.V = bc(mine.V); s.W = bc(mine.W); s.det = bc(mine.det);
+                        s.v0x = tp.v0.x; s.v1x = tp.v1.x; s.v2x = tp.v2.x; s.hix = bc(mine.hix); s.hit = true;
+                        uint32_t hits = 0;
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) hits |= (parity_row_voxel(s, ox[c]) ? 1u : 0u) << c;
+                        const uint32_t at = (uint32_t)r * CH, word = at >> 5, contrib = hits << (at & 31u);
+#pragma unroll
+                        for (int w = 0; w < WORDS; ++w) bits[w] ^= word == (uint32_t)w ? contrib : 0u;
+                    }
                 }
             });
     }

@@ -21,7 +21,7 @@ def test_default_kernels_do_not_spill_and_keep_full_occupancy(dxvlib):
     default_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi1E" in k]      # 512-voxel runs, one row per wave
     block_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi2E" in k]        # ... 2 x 2 rows per wave
     assert len(default_ref) == 1 and len(binary_ref) == 1 and len(default_par) == 1 and len(block_par) == 1
-    assert block_par[0]["scratch"] == 0 and block_par[0]["occupancy"] >= 7
+    assert block_par[0]["scratch"] == 0 and block_par[0]["occupancy"] >= 6
     for r in (default_ref[0], binary_ref[0]):
         assert r["scratch"] == 0 and r["vgprs"] <= 64 and r["occupancy"] == 8 and r["lds"] == 20 * 64 * 4
     assert default_par[0]["scratch"] == 0 and default_par[0]["lds"] == 256
