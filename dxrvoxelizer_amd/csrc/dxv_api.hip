@@ -196,7 +196,7 @@ int safe_stack(const dxv_ctx* c)
 int launch_now(dxv_ctx* c)
 {
     VoxelizeParams p{};
-    p.scene.nodes = scene_nodes32(c); p.scene.wide = scene_nodes64(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
+    p.scene.nodes = scene_nodes32(c); p.scene.wide = c->hdr.hasWide ? scene_nodes64(c) : nullptr; p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
     memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
     p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;

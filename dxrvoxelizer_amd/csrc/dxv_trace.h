@@ -655,4 +655,44 @@ DXV_HD void walk_parity_rows(Visit&& visit, TriFetch&& triAt, StackT& stk, Each&
     }
 }
 
+// The same walk over the four-box nodes (Node64): half as many dependent fetches.  `visit(node)`
+// returns the up to four children the rows may meet.
+struct WideHits { bool h[4]; int32_t c[4]; };
+
+// host replay of the node test on decoded planes (b = Node64::b, axis-major: [axis * 8 + side * 4 + child])
+DXV_HD WideHits parity_rows_wide_node(const Node64& n, float ylo, float yhi, float zlo, float zhi, float oxMin)
+{
+    WideHits r;
+    for (int k = 0; k < 4; ++k) {
+        const float hix = half_bits_to_float(n.b[0 * 8 + 4 + k]);
+        const float loy = half_bits_to_float(n.b[1 * 8 + k]), hiy = half_bits_to_float(n.b[1 * 8 + 4 + k]);
+        const float loz = half_bits_to_float(n.b[2 * 8 + k]), hiz = half_bits_to_float(n.b[2 * 8 + 4 + k]);
+        r.h[k] = loy <= yhi && ylo <= hiy && loz <= zhi && zlo <= hiz && hix >= oxMin;     // an unused slot is [+inf, -inf]: never met
+        r.c[k] = n.c[k];
+    }
+    return r;
+}
+
+template <class Visit, class TriFetch, class StackT, class Each>
+DXV_HD void walk_parity_rows_wide(Visit&& visit, TriFetch&& triAt, StackT& stk, Each&& each)
+{
+    int sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        const WideHits n = visit(node);
+        int32_t next = -1;
+        for (int k = 0; k < 4; ++k) {
+            if (!n.h[k]) continue;
+            if (n.c[k] < 0) each(triAt(~n.c[k]));
+            else if (next < 0) next = n.c[k];
+            else stk.push(sp, n.c[k]);
+        }
+        if (next < 0) {
+            if (sp == 0) break;
+            next = stk.pop(sp);
+        }
+        node = next;
+    }
+}
+
 } // namespace dxv

@@ -166,7 +166,9 @@ struct WaveStack {
 // share one walk over the union of their y/z: up to 2.7x faster where triangles span several
 // voxels, slower where they are voxel sized (every visited triangle is set up once per row it
 // might cross) -- the launcher decides by the mean triangle extent.
-template <int CH, int RB>
+// WIDE: the walk takes the four-box nodes (Node64) -- half as many dependent scalar fetches, which is
+// what the walk waits on (triangle arithmetic is 6 % of the kernel).
+template <int CH, int RB, bool WIDE>
 __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizeParams p)   // <= 64 / 80 VGPRs
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the stub: the body uses SGPR inline asm)
@@ -236,24 +238,7 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizePar
         auto both = [](uint32_t h) { return (h & 0xffffu) | (h << 16); };
         const half2_t ydn = H2(both(half_down(yhi))), yup = H2(both(half_up(ylo))), zdn = H2(both(half_down(zhi)));
         const half2_t zup = H2(both(half_up(zlo))), xup = H2(both(half_up(oxMin)));
-        walk_parity_rows(
-            [&](int32_t i) {
-                const NodeSgpr n = load_node_scalar(sc.nodes, i);      // words: x lo, x hi | y lo, y hi | z lo, z hi | links
-                const uint32_t xh = (uint32_t)(n.w[0] >> 32), yl = (uint32_t)n.w[1], yh = (uint32_t)(n.w[1] >> 32);
-                const uint32_t zl = (uint32_t)n.w[2], zh = (uint32_t)(n.w[2] >> 32);
-                half2_t m = __builtin_elementwise_max(__builtin_elementwise_max(H2(yl) - ydn, yup - H2(yh)),
-                                                      __builtin_elementwise_max(H2(zl) - zdn, zup - H2(zh)));
-                m = __builtin_elementwise_max(m, xup - H2(xh));
-                const uint32_t out = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, m));   // > 0: outside
-                NodeHits r;
-                r.h0 = (out & 0x8000u) != 0u || (out & 0x7fffu) == 0u;
-                r.h1 = (out & 0x80000000u) != 0u || (out & 0x7fff0000u) == 0u;
-                r.c0 = (int32_t)(uint32_t)n.w[3];
-                r.c1 = (int32_t)(uint32_t)(n.w[3] >> 32);
-                return r;
-            },
-            [&](int32_t leaf) { return load_tri_scalar(sc.triPos, leaf); }, stk,
-            [&](const TriPos& tp) {
+        auto triangle = [&](const TriPos& tp) {
                 if (RB == 1) {
                     const ParityRowTri s = parity_row_setup(oy[0], oz[0], tp.v0, tp.v1, tp.v2);
                     if (s.hit) {
@@ -284,7 +269,46 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizePar
                         for (int w = 0; w < WORDS; ++w) bits[w] ^= word == (uint32_t)w ? contrib : 0u;
                     }
                 }
-            });
+        };
+        auto triAt = [&](int32_t leaf) { return load_tri_scalar(sc.triPos, leaf); };
+        auto outside = [&](uint32_t xh, uint32_t yl, uint32_t yh, uint32_t zl, uint32_t zh) {   // two children per word; > 0: outside
+            half2_t m = __builtin_elementwise_max(__builtin_elementwise_max(H2(yl) - ydn, yup - H2(yh)),
+                                                  __builtin_elementwise_max(H2(zl) - zdn, zup - H2(zh)));
+            m = __builtin_elementwise_max(m, xup - H2(xh));
+            return (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, m));
+        };
+        if (WIDE) {
+            walk_parity_rows_wide(
+                [&](int32_t i) {
+                    const WideSgpr n = load_wide_scalar(sc.wide, i);   // words: x lo, x hi, y lo, y hi, z lo, z hi (children 0,1 | 2,3), links
+                    const uint32_t o01 = outside((uint32_t)n.w[1], (uint32_t)n.w[2], (uint32_t)n.w[3], (uint32_t)n.w[4], (uint32_t)n.w[5]);
+                    const uint32_t o23 = outside((uint32_t)(n.w[1] >> 32), (uint32_t)(n.w[2] >> 32), (uint32_t)(n.w[3] >> 32),
+                                                 (uint32_t)(n.w[4] >> 32), (uint32_t)(n.w[5] >> 32));
+                    WideHits r;
+                    r.h[0] = (o01 & 0x8000u) != 0u || (o01 & 0x7fffu) == 0u;
+                    r.h[1] = (o01 & 0x80000000u) != 0u || (o01 & 0x7fff0000u) == 0u;
+                    r.h[2] = (o23 & 0x8000u) != 0u || (o23 & 0x7fffu) == 0u;
+                    r.h[3] = (o23 & 0x80000000u) != 0u || (o23 & 0x7fff0000u) == 0u;
+                    r.c[0] = (int32_t)(uint32_t)n.w[6]; r.c[1] = (int32_t)(uint32_t)(n.w[6] >> 32);
+                    r.c[2] = (int32_t)(uint32_t)n.w[7]; r.c[3] = (int32_t)(uint32_t)(n.w[7] >> 32);
+                    return r;
+                },
+                triAt, stk, triangle);
+        } else {
+            walk_parity_rows(
+                [&](int32_t i) {
+                    const NodeSgpr n = load_node_scalar(sc.nodes, i);  // words: x lo, x hi | y lo, y hi | z lo, z hi | links
+                    const uint32_t out = outside((uint32_t)(n.w[0] >> 32), (uint32_t)n.w[1], (uint32_t)(n.w[1] >> 32), (uint32_t)n.w[2],
+                                                 (uint32_t)(n.w[2] >> 32));
+                    NodeHits r;
+                    r.h0 = (out & 0x8000u) != 0u || (out & 0x7fffu) == 0u;
+                    r.h1 = (out & 0x80000000u) != 0u || (out & 0x7fff0000u) == 0u;
+                    r.c0 = (int32_t)(uint32_t)n.w[3];
+                    r.c1 = (int32_t)(uint32_t)(n.w[3] >> 32);
+                    return r;
+                },
+                triAt, stk, triangle);
+        }
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -300,7 +324,7 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizePar
 #endif
 }
 
-template <int CH, int RB>
+template <int CH, int RB, bool WIDE>
 static hipError_t launch_parity_rows_ch(const VoxelizeParams& pin, hipStream_t s)
 {
     VoxelizeParams p = pin;
@@ -312,25 +336,30 @@ static hipError_t launch_parity_rows_ch(const VoxelizeParams& pin, hipStream_t s
     const uint64_t span = 8ull << rb;
     const uint64_t grid = (nwaves + span - 1) / span * span;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    k_parity_rows<CH, RB><<<dim3((uint32_t)grid), dim3(64), 0, s>>>(p);
+    k_parity_rows<CH, RB, WIDE><<<dim3((uint32_t)grid), dim3(64), 0, s>>>(p);
     return hipGetLastError();
 }
 
-template <int RB>
+template <int RB, bool WIDE>
 static hipError_t launch_parity_rows_rb(const VoxelizeParams& p, hipStream_t s)
 {
-    if (p.N <= 64) return launch_parity_rows_ch<1, RB>(p, s);
-    if (p.N <= 128) return launch_parity_rows_ch<2, RB>(p, s);
-    if (p.N <= 256) return launch_parity_rows_ch<4, RB>(p, s);
-    return launch_parity_rows_ch<8, RB>(p, s);          // 512 voxels per wave; longer rows take several waves
+    if (p.N <= 64) return launch_parity_rows_ch<1, RB, WIDE>(p, s);
+    if (p.N <= 128) return launch_parity_rows_ch<2, RB, WIDE>(p, s);
+    if (p.N <= 256) return launch_parity_rows_ch<4, RB, WIDE>(p, s);
+    return launch_parity_rows_ch<8, RB, WIDE>(p, s);    // 512 voxels per wave; longer rows take several waves
 }
 
-// rowBlock: rows per side of a wave's block of rows (1, 2 or 4)
+// rowBlock: rows per side of a wave's block of rows (1, 2 or 4); the walk takes the four-box nodes when the scene has them
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s)
 {
-    if (rowBlock == 4) return launch_parity_rows_rb<4>(p, s);
-    if (rowBlock == 2) return launch_parity_rows_rb<2>(p, s);
-    return launch_parity_rows_rb<1>(p, s);
+    if (p.scene.wide) {
+        if (rowBlock == 4) return launch_parity_rows_rb<4, true>(p, s);
+        if (rowBlock == 2) return launch_parity_rows_rb<2, true>(p, s);
+        return launch_parity_rows_rb<1, true>(p, s);
+    }
+    if (rowBlock == 4) return launch_parity_rows_rb<4, false>(p, s);
+    if (rowBlock == 2) return launch_parity_rows_rb<2, false>(p, s);
+    return launch_parity_rows_rb<1, false>(p, s);
 }
 
 // brick shapes: (x, y, z) voxels per workgroup; a wavefront owns 64 consecutive threads of it

@@ -18,8 +18,8 @@ def test_default_kernels_do_not_spill_and_keep_full_occupancy(dxvlib):
     # <4x4x4 brick, 20-entry column, reference rule, no texels, WALK 2 (wide) and 1 (binary postponed-leaf)>
     default_ref = [v for k, v in res.items() if "k_voxelizeINS_5BrickILi4ELi4ELi4EEELi20ELi0ELb0ELi2E" in k]
     binary_ref = [v for k, v in res.items() if "k_voxelizeINS_5BrickILi4ELi4ELi4EEELi20ELi0ELb0ELi1E" in k]
-    default_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi1E" in k]      # 512-voxel runs, one row per wave
-    block_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi2E" in k]        # ... 2 x 2 rows per wave
+    default_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi1ELb1E" in k]   # 512-voxel runs, one row per wave, four-box nodes
+    block_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi2ELb1E" in k]     # ... 2 x 2 rows per wave
     assert len(default_ref) == 1 and len(binary_ref) == 1 and len(default_par) == 1 and len(block_par) == 1
     assert block_par[0]["scratch"] == 0 and block_par[0]["occupancy"] >= 6
     for r in (default_ref[0], binary_ref[0]):
