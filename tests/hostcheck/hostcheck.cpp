@@ -126,8 +126,9 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
                                                          uint8_t* out, uint32_t* texels)
 {
     HcScene* s = static_cast<HcScene*>(p);
-    if (mode == 4 || mode == 7 || mode == 8) {   // parity, row form (what k_parity_rows computes): one walk per block of RB x RB rows
-        const uint32_t RB = mode == 4 ? 1u : mode == 7 ? 2u : 4u;
+    if (mode == 4 || mode == 7 || mode == 8 || mode == 10 || mode == 11) {   // parity, row form (what k_parity_rows computes): one walk per block of RB x RB rows
+        const uint32_t RB = (mode == 4 || mode == 10) ? 1u : (mode == 7 || mode == 11) ? 2u : 4u;
+        const bool wideWalk = mode >= 10;          // ... over the four-box nodes
         SceneView scr{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { scr.rootLo[a] = min_(w[a], w[6 + a]); scr.rootHi[a] = max_(w[3 + a], w[9 + a]); }
@@ -149,15 +150,19 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
             for (uint32_t k = 1; k < RB; ++k) { ylo = min_(ylo, oy[k]); yhi = max_(yhi, oy[k]); zlo = min_(zlo, oz[k]); zhi = max_(zhi, oz[k]); }
             std::vector<uint32_t> cnt((size_t)RB * RB * N, 0);
             struct HostStack { int32_t e[128]; void push(int& sp, int32_t v) { e[sp++] = v; } int32_t pop(int& sp) { return e[--sp]; } } stk;
-            if (scr.rootLo[1] <= yhi && ylo <= scr.rootHi[1] && scr.rootLo[2] <= zhi && zlo <= scr.rootHi[2] && scr.rootHi[0] >= ox[0])
-                walk_parity_rows([&](int32_t i) { return parity_rows_node(load_node(scr.nodes, i), ylo, yhi, zlo, zhi, ox[0]); },
-                                 [&](int32_t leaf) { return load_tri(scr.triPos, leaf); }, stk,
-                                 [&](const TriPos& tp) {
-                                     for (uint32_t r = 0; r < RB * RB; ++r) {
-                                         const ParityRowTri ps = parity_row_setup(oy[r % RB], oz[r / RB], tp.v0, tp.v1, tp.v2);
-                                         if (ps.hit) for (uint32_t ix = 0; ix < N; ++ix) cnt[(size_t)r * N + ix] += parity_row_voxel(ps, ox[ix]) ? 1u : 0u;
-                                     }
-                                 });
+            auto tri = [&](const TriPos& tp) {
+                for (uint32_t r = 0; r < RB * RB; ++r) {
+                    const ParityRowTri ps = parity_row_setup(oy[r % RB], oz[r / RB], tp.v0, tp.v1, tp.v2);
+                    if (ps.hit) for (uint32_t ix = 0; ix < N; ++ix) cnt[(size_t)r * N + ix] += parity_row_voxel(ps, ox[ix]) ? 1u : 0u;
+                }
+            };
+            auto triAt = [&](int32_t leaf) { return load_tri(scr.triPos, leaf); };
+            if (scr.rootLo[1] <= yhi && ylo <= scr.rootHi[1] && scr.rootLo[2] <= zhi && zlo <= scr.rootHi[2] && scr.rootHi[0] >= ox[0]) {
+                if (wideWalk)
+                    walk_parity_rows_wide([&](int32_t i) { return parity_rows_wide_node(s->nodes64[i], ylo, yhi, zlo, zhi, ox[0]); }, triAt, stk, tri);
+                else
+                    walk_parity_rows([&](int32_t i) { return parity_rows_node(load_node(scr.nodes, i), ylo, yhi, zlo, zhi, ox[0]); }, triAt, stk, tri);
+            }
             for (uint32_t r = 0; r < RB * RB; ++r)
                 for (uint32_t ix = 0; ix < N; ++ix) out[((size_t)lz[r / RB] * N + iy[r % RB]) * N + ix] = (uint8_t)(cnt[(size_t)r * N + ix] & 1u);
         }

@@ -43,12 +43,12 @@ def test_fuzz_host_code_vs_brute_force(orc, hostcheck, seed, n_tris):
     want = {0: s.voxelize(N, algo=orc.ALGO_BRUTE), 1: s.voxelize(N, mode=1, algo=orc.ALGO_BRUTE)}
     assert np.array_equal(s.voxelize(N), want[0]) and np.array_equal(s.voxelize(N, mode=1), want[1])   # oracle BVH too
     # 6 = postponed-leaf walk over the wide nodes; 4, 7, 8 = parity rows, one walk per 1, 2 x 2, 4 x 4 rows
-    for mode in (0, 1, 2, 3, 4, 6, 7, 8):
+    for mode in (0, 1, 2, 3, 4, 6, 7, 8, 10, 11):           # 10, 11: parity rows over the four-box nodes
         g, ovf = h.voxelize(N, mode)
         assert not ovf
         assert np.array_equal(g, want[0 if mode in (0, 2, 6) else 1]), (seed, mode)
     for z0, nz in ((3, 5), (10, 1)):                     # odd slabs: a block repeats its last slice
-        for mode in (7, 8):
+        for mode in (7, 8, 11):
             g, _ = h.voxelize(N, mode, z0, nz)
             assert np.array_equal(g, want[1][z0:z0 + nz]), (seed, mode, z0, nz)
 

@@ -38,8 +38,8 @@ def test_host_lbvh_equals_oracle_assets(orc, hostcheck, request, name):
     assert np.all(keys[1:] > keys[:-1])
     assert 1 <= h.height <= 62
     # 2/3 = postponed-leaf walks, 5 (-> 4) = parity rows, 6 = postponed-leaf walk over the wide nodes
-    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2), (64, 3), (64, 5), (64, 6), (64, 7), (30, 9)):   # 7, 9 (-> 8): row blocks
-        g, ovf = h.voxelize(N, {5: 4, 9: 8}.get(mode, mode), stack=h.height + 3 if mode != 6 else 3 * ((h.height + 1) // 2) + 5)
+    for N, mode in ((32, 0), (32, 1), (64, 0), (64, 2), (64, 3), (64, 5), (64, 6), (64, 7), (30, 9), (64, 11), (30, 13)):   # 7, 9 (-> 8): row blocks; 11, 13 (-> 10): four-box walk
+        g, ovf = h.voxelize(N, {5: 4, 9: 8, 13: 10}.get(mode, mode), stack=h.height + 3 if mode != 6 else 3 * ((h.height + 1) // 2) + 5)
         assert not ovf
         assert np.array_equal(g, s.voxelize(N, mode=mode % 2))
 
