@@ -538,12 +538,13 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
         assert np.array_equal(g0, orc.Scene(vb, ib).voxelize(64))
 
 
-@pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
-def test_parity_row_blocks_equal_single_rows(vox, orc, request, name):
+@pytest.mark.parametrize("name,wide", [("bunny", 2), ("dragon", 2), ("turingbowl", 2), ("dragon", 0)])
+def test_parity_row_blocks_equal_single_rows(vox, orc, request, name, wide):
     """k_parity_rows with one row per wave and with 2 x 2 rows per wave (one walk over the union of
     the rows): same grid as the per-voxel kernel and the oracle -- whole grids, odd slabs (the last
     slice is repeated inside a block), offsets, and the block-cyclic partition."""
     vb, ib, _ = request.getfixturevalue(name)
+    vox.set_option("wide", wide)                      # 0: the scene has no four-box nodes, the rows walk the binary ones
     vox.InitFromArrays(vb, ib)
     s = orc.Scene(vb, ib)
     want = s.voxelize(64, mode=1)
@@ -568,6 +569,7 @@ def test_parity_row_blocks_equal_single_rows(vox, orc, request, name):
         assert np.array_equal(vox.Grid(), want)
     finally:
         vox.set_option("rowblock", 0)
+        vox.set_option("wide", 2)
 
 
 def test_pyramid_refit_equals_sweep_refit_word_for_word(dxv, bunny):
