@@ -66,6 +66,9 @@ struct dxv_ctx {
     size_t packedCap = 0;
     uint32_t* dImage = nullptr;
     size_t imageCap = 0;
+    uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
+    size_t emptyCap = 0;
+    int optSkipEmpty = 1;    // display pass: skip the samples of empty 8^3 bricks (same image)
     float renderMs = 0.0f;
 
     hipEvent_t ev[10] = {};
@@ -282,7 +285,7 @@ void dxv_destroy(dxv_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     free_scratch(c);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene); (void)hipFree(c->dGrid);
-    (void)hipFree(c->dImage);
+    (void)hipFree(c->dImage); (void)hipFree(c->dEmpty);
     (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dRedo); (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -546,9 +549,15 @@ int dxv_render(dxv_ctx* c, const float eye[3], const float viewProj[16], const f
         DXV_HIP(c, hipMalloc(&c->dImage, pixels * 4));
         c->imageCap = pixels;
     }
+    if (c->optSkipEmpty && empty_brick_bytes(N) > c->emptyCap) {
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->dEmpty); c->dEmpty = nullptr; c->emptyCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dEmpty, align256(empty_brick_bytes(N))));
+        c->emptyCap = empty_brick_bytes(N);
+    }
     if (dxv_sync(c)) return 1;                                       // the grid must be complete and valid
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
-    DXV_HIP(c, launch_raycast(cb, c->dGrid, N, width, height, c->dImage, c->stream));
+    DXV_HIP(c, launch_raycast(cb, c->dGrid, N, width, height, c->dImage, c->optSkipEmpty ? c->dEmpty : nullptr, c->stream));
     DXV_HIP(c, hipEventRecord(c->ev[9], c->stream));
     DXV_HIP(c, hipMemcpyAsync(rgbaHost, c->dImage, pixels * 4, hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
@@ -695,6 +704,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
             if (!c->haveMesh) return fail(c, "option wide: this scene was imported without wide nodes; set the option on the exporting context before dxv_build");
             return dxv_build(c);
         }
+    } else if (!strcmp(key, "skipempty")) {
+        if (value != 0 && value != 1) return fail(c, "option skipempty: %lld not in {0,1}", (long long)value);
+        c->optSkipEmpty = (int)value;
     } else if (!strcmp(key, "rowblock")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return fail(c, "option rowblock: %lld not in {0,1,2,4}", (long long)value);
         c->optRowBlock = (int)value;

@@ -72,6 +72,7 @@ int num_brick_shapes();
 // raycast.hip
 struct RayCastCB;
 hipError_t launch_raycast(const RayCastCB& cb, const uint8_t* grid, uint32_t N, uint32_t width, uint32_t height,
-                          uint32_t* rgba8, hipStream_t s);
+                          uint32_t* rgba8, uint8_t* empty, hipStream_t s);
+size_t empty_brick_bytes(uint32_t N);
 
 } // namespace dxv

@@ -26,7 +26,14 @@ constexpr float kZeroThreshold = 0.01f; // :10
 // Texture3D.SampleLevel(LINEAR_CLAMP, tex, 0).w of the R10G10B10A2 grid: alpha is 1 where the voxel
 // is occupied, 0 elsewhere (Content/Shaders/DXRVoxelizer.hlsl:84).  Texel (ix,iy,iz) centre sits at
 // (i + 0.5) / N.
-DXV_HD float sample_alpha(const uint8_t* grid, uint32_t N, float tx, float ty, float tz)
+// `empty` (optional): one byte per 8 x 8 x 8 brick of the grid, 1 where the voxels [8b, 8b+8] per axis
+// -- the brick and the first plane of its +x/+y/+z neighbours -- are all 0 (raycast.hip k_brick_empty).
+// The eight texels of a sample whose low corner lies in the brick are among those voxels, so a flagged
+// brick means the interpolation below would return exactly 0.0f: returning it at once changes no bit
+// of the image and spares the eight loads for the samples that march through empty space (most of them).
+constexpr uint32_t kEmptyBrick = 8;
+
+DXV_HD float sample_alpha(const uint8_t* grid, uint32_t N, float tx, float ty, float tz, const uint8_t* empty = nullptr)
 {
     const float fn = (float)N;
     const float ux = tx * fn - 0.5f, uy = ty * fn - 0.5f, uz = tz * fn - 0.5f;
@@ -36,6 +43,10 @@ DXV_HD float sample_alpha(const uint8_t* grid, uint32_t N, float tx, float ty, f
     auto clampi = [n1](float f) { int32_t i = (int32_t)f; return i < 0 ? 0 : (i > n1 ? n1 : i); };
     const int32_t x0 = clampi(fx0), x1 = clampi(fx0 + 1.0f), y0 = clampi(fy0), y1 = clampi(fy0 + 1.0f);
     const int32_t z0 = clampi(fz0), z1 = clampi(fz0 + 1.0f);
+    if (empty) {
+        const uint32_t M = (N + kEmptyBrick - 1) / kEmptyBrick;
+        if (empty[(((uint32_t)z0 / kEmptyBrick) * M + (uint32_t)y0 / kEmptyBrick) * M + (uint32_t)x0 / kEmptyBrick]) return 0.0f;
+    }
     auto at = [grid, N](int32_t x, int32_t y, int32_t z) { return grid[((size_t)z * N + y) * N + x] ? 1.0f : 0.0f; };
     const float c00 = at(x0, y0, z0) + wx * (at(x1, y0, z0) - at(x0, y0, z0));
     const float c10 = at(x0, y1, z0) + wx * (at(x1, y1, z0) - at(x0, y1, z0));
@@ -45,10 +56,10 @@ DXV_HD float sample_alpha(const uint8_t* grid, uint32_t N, float tx, float ty, f
     return c0 + wz * (c1 - c0);
 }
 
-DXV_HD float get_sample(const uint8_t* grid, uint32_t N, float px, float py, float pz)
+DXV_HD float get_sample(const uint8_t* grid, uint32_t N, float px, float py, float pz, const uint8_t* empty = nullptr)
 {
     // tex = float3(0.5, -0.5, 0.5) * pos + 0.5 (PSRayCast.hlsl:137), GetSample :104-113
-    const float d = sample_alpha(grid, N, 0.5f * px + 0.5f, -0.5f * py + 0.5f, 0.5f * pz + 0.5f);
+    const float d = sample_alpha(grid, N, 0.5f * px + 0.5f, -0.5f * py + 0.5f, 0.5f * pz + 0.5f, empty);
     return min_(d * 8.0f, 16.0f);
 }
 
@@ -77,7 +88,8 @@ DXV_HD bool compute_start_point(float pos[3], const float dir[3])
 }
 
 // One pixel, sspos = (px + 0.5, py + 0.5) (SV_POSITION).  rgba in [0,1] (PSRayCast.hlsl:118-187).
-DXV_HD void raycast_pixel(const RayCastCB& cb, const uint8_t* grid, uint32_t N, float sx, float sy, float rgba[4])
+DXV_HD void raycast_pixel(const RayCastCB& cb, const uint8_t* grid, uint32_t N, float sx, float sy, float rgba[4],
+                          const uint8_t* empty = nullptr)
 {
     const float clear[3] = {0.0f, 0.2f, 0.4f};                                  // SharedConst.h:8
     const float maxDist = 2.0f * __builtin_sqrtf(3.0f);
@@ -97,7 +109,7 @@ DXV_HD void raycast_pixel(const RayCastCB& cb, const uint8_t* grid, uint32_t N, 
     float transmit = 1.0f, scatter = 0.0f;
     for (int i = 0; i < kNumSamples; ++i) {
         if (outside_unit(pos[0], pos[1], pos[2])) break;
-        const float density = get_sample(grid, N, pos[0], pos[1], pos[2]);
+        const float density = get_sample(grid, N, pos[0], pos[1], pos[2], empty);
         if (density > kZeroThreshold) {
             const float scaledDens = density * stepScale;
             transmit *= min_(max_(1.0f - scaledDens * kAbsorption, 0.0f), 1.0f);
@@ -106,7 +118,7 @@ DXV_HD void raycast_pixel(const RayCastCB& cb, const uint8_t* grid, uint32_t N, 
             float lp[3] = {pos[0] + lstep[0], pos[1] + lstep[1], pos[2] + lstep[2]};
             for (int j = 0; j < kNumLightSamples; ++j) {
                 if (outside_unit(lp[0], lp[1], lp[2])) break;
-                const float lightDens = get_sample(grid, N, lp[0], lp[1], lp[2]);
+                const float lightDens = get_sample(grid, N, lp[0], lp[1], lp[2], empty);
                 lightTrans *= min_(max_(1.0f - kAbsorption * lightStepScale * lightDens, 0.0f), 1.0f);
                 if (lightTrans < kZeroThreshold) break;
                 lp[0] += lstep[0]; lp[1] += lstep[1]; lp[2] += lstep[2];

@@ -169,12 +169,13 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   stack  0|8..64  LDS column entries per thread; 0 (default) = adaptive from stack0
  *   stack0 8..64  starting depth of the adaptive column (default 20)
  *   queue  0|1    postponed-leaf walk (default 1)
- *   wide   0|1|2  reference rule over four-box nodes (1) or on wave-uniform visits only (2); builds
- *                 the extra scene section (default 0)
+ *   wide   0|1|2  reference rule over four-box nodes (1) or on wave-uniform visits only (2, default);
+ *                 0 = binary nodes only and no four-box scene section
  *   rows   0|1    parity rule: one tree walk per grid row (default 1)
  *   rowblock 0|1|2|4  ... per row (1), per 2 x 2 or 4 x 4 rows; 0 (default) decides by triangle size
  *   refit  0|1|2  build: box merge by level sweeps (1, 2) or one atomic pass (0); dxv_refit: min/max
  *                 pyramid over the leaf order (1, default), sweeps (2), atomic pass (0)
+ *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
 

@@ -98,3 +98,26 @@ def test_gpu_render_equals_oracle(dxvlib, orc, bunny, tmp_path):
     with pytest.raises(dxv.DxvError):
         v.Render(eye, vp, w, h)
     v.close()
+
+
+@pytest.mark.gpu
+def test_gpu_empty_brick_skip_changes_no_pixel(dxvlib, bunny):
+    """The display pass skips the samples of empty 8^3 bricks (option skipempty, default on): the image
+    must equal the plain march byte for byte, also at grid sizes that are not multiples of the brick."""
+    import dxrvoxelizer_amd as dxv
+    vb, ib, _ = bunny
+    v = dxv.Voxelizer(0)
+    v.InitFromArrays(vb, ib)
+    for n in (16, 50, 64, 100):
+        v.Voxelize(n)
+        for (w, h), eye_pos in (((320, 180), camera.DEFAULT_EYE), ((128, 128), (-6.0, 3.0, 13.0)), ((96, 64), (0.5, 0.2, 1.5))):
+            eye, vp = camera.default_view_proj(w, h, eye=eye_pos)
+            v.set_option("skipempty", 1)
+            a = v.Render(eye, vp, w, h)
+            v.set_option("skipempty", 0)
+            b = v.Render(eye, vp, w, h)
+            assert np.array_equal(a, b), (n, w, h)
+        assert a.any()
+    with pytest.raises(dxv.DxvError):
+        v.set_option("skipempty", 2)
+    v.close()

@@ -34,10 +34,11 @@ def main():
     for mesh, N, frames in (("bunny", 64, 300), ("bunny", 256, 200), ("torus1m", 512, 60)):
         vb, ib, _ = make_mesh(mesh)
         v.InitFromArrays(vb, ib)
-        for animate in (False, True):
+        for animate, skip in ((False, 1), (True, 1), (False, 0)):
+            v.set_option("skipempty", skip)
             ms = loop(v, N, np.ascontiguousarray(vb, np.float32), animate, frames)
             st = v.stats()
-            print(json.dumps({"scene": mesh, "N": N, "animated_vertices": animate, "frame_ms": round(ms, 3), "fps": round(1e3 / ms, 1),
+            print(json.dumps({"scene": mesh, "N": N, "animated_vertices": animate, "skipempty": skip, "frame_ms": round(ms, 3), "fps": round(1e3 / ms, 1),
                               "voxelize_ms": round(st["voxelize_ms"], 3), "render_ms": round(st["render_ms"], 3),
                               "refit_ms": round(st["refit_ms"], 3) if animate else None}))
 
