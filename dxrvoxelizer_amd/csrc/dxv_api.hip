@@ -45,7 +45,7 @@ struct dxv_ctx {
     uint64_t* dKeysTmp = nullptr;
     uint32_t* dHist = nullptr;
     uint32_t* dParents = nullptr;
-    void* dPyramid = nullptr;        // min/max pyramid over the leaf boxes (dxv_refit), allocated on the first refit
+    void* dPyramid = nullptr;        // min/max pyramid over the leaf boxes (refit = 1: dxv_build and dxv_refit)
     uint32_t* dFlags = nullptr;
     uint32_t* dFlags2 = nullptr;
     uint32_t* dRootInfo = nullptr;
@@ -360,6 +360,14 @@ void fill_build_buffers(dxv_ctx* c, BuildBuffers& b)
     b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.nodes64 = c->hdr.hasWide ? scene_nodes64(c) : nullptr; b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
 }
 
+// min/max pyramid of the box merge (refit = 1): 24 B box + 4 B deepest leaf per slot
+int alloc_pyramid(dxv_ctx* c)
+{
+    if (!c->dPyramid && c->optRefit == 1 && c->T > 1)      // refit=2 keeps the level sweeps, refit=0 the atomic pass
+        DXV_HIP(c, hipMalloc(&c->dPyramid, 28 * (size_t)pyramid_slots(c->T)));
+    return 0;
+}
+
 int finish_build(dxv_ctx* c, const char* who)
 {
     uint32_t rootInfo[16];
@@ -408,8 +416,7 @@ int dxv_refit(dxv_ctx* c)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
     c->haveScene = false;
-    if (!c->dPyramid && c->optRefit == 1 && c->T > 1)      // refit=2 keeps the level sweeps for the refit as well
-        DXV_HIP(c, hipMalloc(&c->dPyramid, sizeof(float) * 6 * (size_t)pyramid_slots(c->T)));
+    if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
     fill_build_buffers(c, b);
     if (c->optRefit != 1) b.pyramid = nullptr;
@@ -427,10 +434,12 @@ int dxv_build(dxv_ctx* c)
     c->haveScene = false;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
+    if (alloc_pyramid(c)) return 1;
     memcpy(c->hdr.bound, c->bound, sizeof(c->bound));
 
     BuildBuffers b{};
     fill_build_buffers(c, b);
+    if (c->optRefit != 1) b.pyramid = nullptr;
     DXV_HIP(c, lbvh_build(b, c->optRefit, c->stream, c->ev));
     if (finish_build(c, "dxv_build")) return 1;
     c->stats.prep_ms = elapsed(c->ev[0], c->ev[1]);

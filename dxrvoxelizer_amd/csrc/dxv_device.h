@@ -23,7 +23,7 @@ struct BuildBuffers {
     uint32_t* parents;      // (T-1) internal + T leaf words: (parent << 1) | side
     uint32_t* flags;        // T-1 arrival counters (atomic refit) / ready flags (sweep refit)
     uint32_t* flags2;       // T-1: far end of every node's run of leaves (k_hierarchy -> pyramid refit)
-    void* pyramid;          // pyramid_slots(T) x 24 B min/max pyramid over the leaf boxes, or NULL (refit by sweeps)
+    void* pyramid;          // pyramid_slots(T) x 28 B: min/max pyramid over the leaf boxes + deepest leaf, or NULL (sweeps)
     uint32_t* rootInfo;     // 8 words: rootLo[3], rootHi[3] (float bits), height, done
     Node* nodes;            // max(T-1,1), exact boxes
     Node32* nodes32;        // max(T-1,1), traversal copy

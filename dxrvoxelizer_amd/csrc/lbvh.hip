@@ -240,6 +240,8 @@ __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict
     rootInfo[7] = rootReady ? (*rootReady != 0u ? 1u : 0u) : 1u;      // sweep refit: the root has been stamped
 }
 
+static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStream_t s);
+
 // K4 + K5 + root info over an existing hierarchy (links and parent words in place).
 static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t s, uint32_t knownHeight = 0)
 {
@@ -302,7 +304,9 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm);
     if (T > 1) k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents, b.flags2);
     (void)hipEventRecord(ev[3], s);
-    if ((e = refit_stage(b, refitMode, s)) != hipSuccess) return e;
+    if (b.pyramid && refitMode == 1 && T > 1) e = refit_pyramid(b, true, s);
+    else e = refit_stage(b, refitMode, s);
+    if (e != hipSuccess) return e;
     (void)hipEventRecord(ev[4], s);
     return hipGetLastError();
 }
@@ -314,8 +318,30 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
 // 24 B per entry, leaves recomputed from triPos) is built in two launches -- ten levels per
 // workgroup through LDS, the top by one workgroup -- and one launch over the nodes queries it,
 // at most 2 log2(run) entries per child.  Unions of the same leaf boxes by min/max: the same
-// bits as the bottom-up merge.  Heights are a property of the hierarchy and stay.
+// bits as the bottom-up merge.  Heights are a property of the hierarchy: a refit keeps them, the
+// first build (DEPTH = true) gets them from the same pyramid -- k_depths climbs the parent links
+// once per leaf, which gives the depth of leaf j and, because node j is always an ancestor of
+// leaf j, the depth of node j on the way; a seventh pyramid channel holds the deepest leaf of each
+// run, and height(child) = deepest leaf of its run - depth(child).  No level-by-level pass, no
+// host round trip.
 // ---------------------------------------------------------------------------------------------
+// depthLeaf[j] = internal nodes above leaf j; depthNode[i] = internal nodes above node i (root: 0)
+__global__ __launch_bounds__(kThreads) void k_depths(const uint32_t* __restrict__ parents, uint32_t T,
+                                                     uint32_t* __restrict__ depthLeaf, uint32_t* __restrict__ depthNode)
+{
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= T) return;
+    uint32_t p = parents[(T - 1) + j] >> 1, steps = 1, mine = 0;
+    for (;;) {
+        if (p == j) mine = steps;           // node j covers leaf j: met exactly once on the way up
+        if (p == 0u) break;
+        p = parents[p] >> 1;
+        ++steps;
+    }
+    depthLeaf[j] = steps;
+    if (j < T - 1) depthNode[j] = steps - mine;
+}
+
 struct Box6 { float lo[3], hi[3]; };
 __device__ __forceinline__ void box_empty(Box6& b) { for (int a = 0; a < 3; ++a) { b.lo[a] = __builtin_inff(); b.hi[a] = -__builtin_inff(); } }
 __device__ __forceinline__ void box_union(Box6& b, const Box6& o) { for (int a = 0; a < 3; ++a) { b.lo[a] = min_(b.lo[a], o.lo[a]); b.hi[a] = max_(b.hi[a], o.hi[a]); } }
@@ -328,10 +354,14 @@ __device__ __forceinline__ Box6 leaf_box(const TriPos* __restrict__ triPos, uint
 }
 
 constexpr uint32_t kPyrLeaves = 1024;         // leaves per workgroup of k_pyramid_low = 10 levels
+// pyrD (DEPTH only): the deepest leaf under each pyramid entry, same heap order
+template <bool DEPTH>
 __global__ __launch_bounds__(kThreads) void k_pyramid_low(const TriPos* __restrict__ triPos, uint32_t T, uint32_t P,
-                                                          Box6* __restrict__ pyr)
+                                                          Box6* __restrict__ pyr, const uint32_t* __restrict__ depthLeaf,
+                                                          uint32_t* __restrict__ pyrD)
 {
     __shared__ Box6 lds[kPyrLeaves / 2];                         // level 1 .. : at most 512 entries live at a time
+    __shared__ uint32_t ldsD[DEPTH ? kPyrLeaves / 2 : 1];
     const uint32_t j0 = blockIdx.x * kPyrLeaves;
     // level 1 from the leaves
     for (uint32_t e = threadIdx.x; e < kPyrLeaves / 2; e += kThreads) {
@@ -339,20 +369,32 @@ __global__ __launch_bounds__(kThreads) void k_pyramid_low(const TriPos* __restri
         box_union(b, leaf_box(triPos, T, j0 + 2 * e + 1));
         lds[e] = b;
         pyr[(P >> 1) + (j0 >> 1) + e] = b;
+        if (DEPTH) {
+            const uint32_t l = j0 + 2 * e, d0 = l < T ? depthLeaf[l] : 0u, d1 = l + 1 < T ? depthLeaf[l + 1] : 0u;
+            ldsD[e] = pyrD[(P >> 1) + (j0 >> 1) + e] = d0 > d1 ? d0 : d1;
+        }
     }
     __syncthreads();
     uint32_t n = kPyrLeaves / 4;
     for (uint32_t level = 2; level <= 10; ++level, n >>= 1) {
         Box6 b;
+        uint32_t d = 0;
         const bool mine = threadIdx.x < n;
-        if (mine) { b = lds[2 * threadIdx.x]; box_union(b, lds[2 * threadIdx.x + 1]); }
+        if (mine) {
+            b = lds[2 * threadIdx.x]; box_union(b, lds[2 * threadIdx.x + 1]);
+            if (DEPTH) { const uint32_t d0 = ldsD[2 * threadIdx.x], d1 = ldsD[2 * threadIdx.x + 1]; d = d0 > d1 ? d0 : d1; }
+        }
         __syncthreads();
-        if (mine) { lds[threadIdx.x] = b; pyr[(P >> level) + (j0 >> level) + threadIdx.x] = b; }
+        if (mine) {
+            lds[threadIdx.x] = b; pyr[(P >> level) + (j0 >> level) + threadIdx.x] = b;
+            if (DEPTH) ldsD[threadIdx.x] = pyrD[(P >> level) + (j0 >> level) + threadIdx.x] = d;
+        }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(1024) void k_pyramid_high(uint32_t P, Box6* pyr)
+template <bool DEPTH>
+__global__ __launch_bounds__(1024) void k_pyramid_high(uint32_t P, Box6* pyr, uint32_t* pyrD)
 {
     for (uint32_t level = 11; (P >> level) >= 1u; ++level) {
         const uint32_t n = P >> level;
@@ -360,55 +402,84 @@ __global__ __launch_bounds__(1024) void k_pyramid_high(uint32_t P, Box6* pyr)
             Box6 b = pyr[(P >> (level - 1)) + 2 * e];
             box_union(b, pyr[(P >> (level - 1)) + 2 * e + 1]);
             pyr[n + e] = b;
+            if (DEPTH) { const uint32_t d0 = pyrD[(P >> (level - 1)) + 2 * e], d1 = pyrD[(P >> (level - 1)) + 2 * e + 1]; pyrD[n + e] = d0 > d1 ? d0 : d1; }
         }
         __syncthreads();      // one workgroup: what it stored before the barrier is what it loads after
     }
 }
 
+// union over the leaves lo..hi; DEPTH: also their greatest depth
+template <bool DEPTH>
 __device__ __forceinline__ Box6 range_box(const TriPos* __restrict__ triPos, uint32_t T, uint32_t P, const Box6* __restrict__ pyr,
-                                          uint32_t lo, uint32_t hi)
+                                          uint32_t lo, uint32_t hi, const uint32_t* __restrict__ depthLeaf,
+                                          const uint32_t* __restrict__ pyrD, uint32_t& deepest)
 {
     Box6 b;
     box_empty(b);
+    deepest = 0;
+    auto take = [&](uint32_t e) {
+        box_union(b, e >= P ? leaf_box(triPos, T, e - P) : pyr[e]);
+        if (DEPTH) { const uint32_t d = e >= P ? (e - P < T ? depthLeaf[e - P] : 0u) : pyrD[e]; deepest = d > deepest ? d : deepest; }
+    };
     uint32_t l = lo + P, r = hi + P + 1u;
     while (l < r) {
-        if (l & 1u) { box_union(b, l >= P ? leaf_box(triPos, T, l - P) : pyr[l]); ++l; }
-        if (r & 1u) { --r; box_union(b, r >= P ? leaf_box(triPos, T, r - P) : pyr[r]); }
+        if (l & 1u) { take(l); ++l; }
+        if (r & 1u) { --r; take(r); }
         l >>= 1; r >>= 1;
     }
     return b;
 }
 
+template <bool DEPTH>
 __global__ __launch_bounds__(kThreads) void k_refit_ranges(const TriPos* __restrict__ triPos, uint32_t T, uint32_t P,
                                                            const Box6* __restrict__ pyr, const uint32_t* __restrict__ rangeEnd,
-                                                           Node* __restrict__ nodes)
+                                                           Node* __restrict__ nodes, const uint32_t* __restrict__ depthLeaf,
+                                                           const uint32_t* __restrict__ depthNode, const uint32_t* __restrict__ pyrD)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T - 1) return;
     const uint32_t j = rangeEnd[i], lo = i < j ? i : j, hi = i < j ? j : i;
     const int32_t c0 = nodes[i].c0;
     const uint32_t gamma = c0 >= 0 ? (uint32_t)c0 : (uint32_t)~c0;
-    const Box6 b0 = range_box(triPos, T, P, pyr, lo, gamma), b1 = range_box(triPos, T, P, pyr, gamma + 1u, hi);
-    float* w = reinterpret_cast<float*>(&nodes[i]);      // words 0..5: child 0 box, 6..11: child 1 box; links and heights stay
+    uint32_t deep0, deep1;
+    const Box6 b0 = range_box<DEPTH>(triPos, T, P, pyr, lo, gamma, depthLeaf, pyrD, deep0);
+    const Box6 b1 = range_box<DEPTH>(triPos, T, P, pyr, gamma + 1u, hi, depthLeaf, pyrD, deep1);
+    float* w = reinterpret_cast<float*>(&nodes[i]);      // words 0..5: child 0 box, 6..11: child 1 box; links stay
     w[0] = b0.lo[0]; w[1] = b0.lo[1]; w[2] = b0.lo[2]; w[3] = b0.hi[0]; w[4] = b0.hi[1]; w[5] = b0.hi[2];
     w[6] = b1.lo[0]; w[7] = b1.lo[1]; w[8] = b1.lo[2]; w[9] = b1.hi[0]; w[10] = b1.hi[1]; w[11] = b1.hi[2];
+    if (DEPTH) {                                         // a child sits one level below node i; a leaf child has height 0
+        const uint32_t below = depthNode[i] + 1u;
+        nodes[i].h0 = deep0 - below;
+        nodes[i].h1 = deep1 - below;
+    }
 }
 
-uint32_t pyramid_slots(uint32_t T)            // entries (24 B each) of the pyramid scratch for T leaves
+uint32_t pyramid_slots(uint32_t T)            // entries (24 B box + 4 B depth each) of the pyramid scratch for T leaves
 {
     uint32_t P = kPyrLeaves;
     while (P < T) P <<= 1;
     return P;
 }
 
-static hipError_t refit_pyramid(const BuildBuffers& b, hipStream_t s)
+// withHeights: first build -- subtree heights from the parent links as well (scratch: keysTmp, free after the sort)
+static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStream_t s)
 {
     const uint32_t T = b.T, P = pyramid_slots(T);
     const uint32_t numNodes = T > 1 ? T - 1 : 1;
     Box6* pyr = reinterpret_cast<Box6*>(b.pyramid);
-    k_pyramid_low<<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr);
-    if (P > kPyrLeaves) k_pyramid_high<<<1, 1024, 0, s>>>(P, pyr);
-    k_refit_ranges<<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes);
+    if (withHeights) {
+        uint32_t* depthLeaf = reinterpret_cast<uint32_t*>(b.keysTmp);
+        uint32_t* depthNode = depthLeaf + T;
+        uint32_t* pyrD = reinterpret_cast<uint32_t*>(pyr + P);
+        k_depths<<<blocks_for(T), kThreads, 0, s>>>(b.parents, T, depthLeaf, depthNode);
+        k_pyramid_low<true><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, depthLeaf, pyrD);
+        if (P > kPyrLeaves) k_pyramid_high<true><<<1, 1024, 0, s>>>(P, pyr, pyrD);
+        k_refit_ranges<true><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, depthLeaf, depthNode, pyrD);
+    } else {
+        k_pyramid_low<false><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, nullptr, nullptr);
+        if (P > kPyrLeaves) k_pyramid_high<false><<<1, 1024, 0, s>>>(P, pyr, nullptr);
+        k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr);
+    }
     if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
     else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
@@ -426,7 +497,7 @@ hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight,
     if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
     (void)hipEventRecord(ev[0], s);
     k_tri_gather<<<blocks_for(b.T), kThreads, 0, s>>>(b.vb, b.ib, b.T, bnd, b.keys, b.triPos, b.triNrm);
-    if (b.pyramid && refitMode != 0 && b.T > 1) e = refit_pyramid(b, s);
+    if (b.pyramid && refitMode != 0 && b.T > 1) e = refit_pyramid(b, false, s);
     else e = refit_stage(b, refitMode, s, treeHeight);
     if (e != hipSuccess) return e;
     (void)hipEventRecord(ev[1], s);

@@ -173,8 +173,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 0 = binary nodes only and no four-box scene section
  *   rows   0|1    parity rule: one tree walk per grid row (default 1)
  *   rowblock 0|1|2|4  ... per row (1), per 2 x 2 or 4 x 4 rows; 0 (default) decides by triangle size
- *   refit  0|1|2  build: box merge by level sweeps (1, 2) or one atomic pass (0); dxv_refit: min/max
- *                 pyramid over the leaf order (1, default), sweeps (2), atomic pass (0)
+ *   refit  0|1|2  box merge of dxv_build and dxv_refit: min/max pyramid over the leaf order (1,
+ *                 default), level sweeps (2), one atomic pass (0)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);

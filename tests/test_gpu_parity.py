@@ -77,18 +77,35 @@ def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
     assert np.array_equal(tn[i].reshape(3, 4)[:, :3], vb[ib[3 * int(k[i]):3 * int(k[i]) + 3], 3:])
 
 
-def test_refit_variants_identical(dxv, dragon):
-    vb, ib, _ = dragon
-    a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
-    a.set_option("refit", 0)
-    b.set_option("refit", 1)
-    a.InitFromArrays(vb, ib)
-    b.InitFromArrays(vb, ib)
-    assert np.array_equal(a.debug(DBG_NODES), b.debug(DBG_NODES))
-    for _ in range(3):                       # rebuilds are deterministic
-        a.InitFromArrays(vb, ib)
-        assert np.array_equal(a.debug(DBG_NODES), b.debug(DBG_NODES))
-    a.close(), b.close()
+@pytest.mark.parametrize("mesh", ["dragon", "turingbowl", "tiny"])
+def test_refit_variants_identical(dxv, request, mesh):
+    """The three box merges of the build -- one atomic pass (0), min/max pyramid with the heights from
+    one climb per leaf (1, default), level sweeps (2) -- write the same node words, heights included."""
+    if mesh == "tiny":                       # 2, 3 and 5 triangles: the smallest hierarchies
+        rng = np.random.default_rng(5)
+        cases = []
+        for T in (2, 3, 5):
+            pos = rng.uniform(-1, 1, (3 * T, 3)).astype(np.float32)
+            nrm = np.tile(np.array([[0, 0, 1]], np.float32), (3 * T, 1))
+            cases.append((np.hstack([pos, nrm]), np.arange(3 * T, dtype=np.uint32)))
+    else:
+        vb, ib, _ = request.getfixturevalue(mesh)
+        cases = [(vb, ib)]
+    vs = [dxv.Voxelizer(0) for _ in range(3)]
+    for refit, v in enumerate(vs):
+        v.set_option("refit", refit)
+    for vb, ib in cases:
+        for v in vs:
+            v.InitFromArrays(vb, ib)
+        want = vs[0].debug(DBG_NODES)
+        for v in vs[1:]:
+            assert np.array_equal(v.debug(DBG_NODES), want)
+            assert v.stats()["tree_height"] == vs[0].stats()["tree_height"]
+        for _ in range(3):                   # rebuilds are deterministic
+            vs[1].InitFromArrays(vb, ib)
+            assert np.array_equal(vs[1].debug(DBG_NODES), want)
+    for v in vs:
+        v.close()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LBVH build and refit timings (HIP events) for both refit variants.
+"""LBVH build and refit timings (HIP events) for the three box-merge variants.
     python tools/build_bench.py [mesh ...]"""
 import json
 import os
@@ -14,7 +14,7 @@ from bench import make_mesh  # noqa: E402
 
 for mesh in (sys.argv[1:] or ["bunny", "torus1m"]):
     vb, ib, label = make_mesh(mesh)
-    for refit in (0, 1):
+    for refit in (0, 2, 1):
         v = dxv.Voxelizer(0)
         v.set_option("refit", refit)
         rows = []
@@ -28,7 +28,7 @@ for mesh in (sys.argv[1:] or ["bunny", "torus1m"]):
             v.UpdateVertices(vb)
             upd.append(v.stats()["refit_ms"])
         T = len(ib) // 3
-        print(json.dumps({"mesh": mesh, "tris": T, "refit_variant": "atomic" if refit == 0 else "sweep",
+        print(json.dumps({"mesh": mesh, "tris": T, "refit_variant": ("atomic", "pyramid", "sweep")[refit],
                           "prep_ms": med[0], "sort_ms": med[1], "hierarchy_ms": med[2], "refit_ms": med[3],
                           "build_ms": med[4], "build_Mtris_s": T / med[4] / 1e3,
                           "update_refit_ms": float(np.median(upd[1:])), "tree_height": v.stats()["tree_height"]}), flush=True)
