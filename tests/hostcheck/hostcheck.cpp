@@ -309,6 +309,85 @@ __attribute__((visibility("default"))) void hc_simt_stats(void* p, uint32_t N, u
     out[8] = uni; out[9] = dis;
 }
 
+// Packet replay: one walk per 4x4x4-voxel wave, a node is visited when ANY live lane's ray meets its
+// box within that lane's closest hit so far; every lane tests both child boxes of every visited node.
+// Near child first by the vote of the lanes that hit both.  out[0] waves, out[1] node visits,
+// out[2] leaf visits (a triangle tested by the lanes whose ray meets its box), out[3] lanes in them,
+// out[4] heaviest wave (visits + leaves), out[5] deepest stack, out[6] grids differ (must be 0)
+__attribute__((visibility("default"))) void hc_packet_stats(void* p, uint32_t N, uint32_t bstep, uint64_t* out)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}};
+    {
+        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
+        for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
+    }
+    const uint32_t nb = N / 4;
+    uint64_t waves = 0, visits = 0, leaves = 0, leafLanes = 0, heaviest = 0, deepest = 0, differ = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : waves, visits, leaves, leafLanes, differ) reduction(max : heaviest, deepest)
+    for (int64_t bzi = 0; bzi < (int64_t)nb; bzi += bstep) {
+        for (uint32_t byi = 0; byi < nb; ++byi) for (uint32_t bxi = 0; bxi < nb; ++bxi) {
+            struct Lane { Ray r; Hit best; bool live; };
+            Lane L[64];
+            int nlive = 0;
+            for (int t = 0; t < 64; ++t) {
+                Lane& l = L[t];
+                const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
+                ray_origin(N, ix, iy, iz, l.r.ox, l.r.oy, l.r.oz);
+                l.live = !origin_leaves_root(l.r.ox, l.r.oy, l.r.oz, sc.rootLo, sc.rootHi);
+                if (!l.live) continue;
+                finish_ray_reference(l.r);
+                l.best.t = kTMax; l.best.k = 0xffffffffu; l.best.leaf = -1; l.best.b1 = l.best.b2 = 0;
+                nlive++;
+            }
+            waves++;
+            if (!nlive) continue;
+            int32_t stack[256]; int sp = 0; int32_t node = 0;
+            uint64_t mine = 0;
+            for (;;) {
+                F4 q0, q1, q2; int32_t c0, c1;
+                load_node(sc.nodes, node, q0, q1, q2, c0, c1);
+                visits++; mine++;
+                bool h0[64], h1[64]; bool any0 = false, any1 = false; int vote = 0;
+                for (int t = 0; t < 64; ++t) {
+                    h0[t] = h1[t] = false;
+                    if (!L[t].live) continue;
+                    float tn0, tn1;
+                    h0[t] = slab(L[t].r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tn0) && tn0 <= L[t].best.t;
+                    h1[t] = slab(L[t].r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tn1) && tn1 <= L[t].best.t;
+                    any0 |= h0[t]; any1 |= h1[t];
+                    if (h0[t] && h1[t]) vote += tn1 < tn0 ? 1 : -1;
+                }
+                for (int side = 0; side < 2; ++side) {
+                    const int32_t c = side ? c1 : c0;
+                    if (!(side ? any1 : any0) || c >= 0) continue;
+                    leaves++; mine++;
+                    for (int t = 0; t < 64; ++t)
+                        if ((side ? h1[t] : h0[t])) { leafLanes++; leaf_reference(L[t].r, sc.triPos, ~c, L[t].best); }
+                }
+                const bool i0 = any0 && c0 >= 0, i1 = any1 && c1 >= 0;
+                if (i0 && i1) {
+                    const bool swap = vote > 0;
+                    stack[sp++] = swap ? c0 : c1;
+                    if ((uint64_t)sp > deepest) deepest = sp;
+                    node = swap ? c1 : c0;
+                } else if (i0 || i1) node = i0 ? c0 : c1;
+                else { if (!sp) break; node = stack[--sp]; }
+            }
+            if (mine > heaviest) heaviest = mine;
+            // same voxels as the per-lane walk
+            for (int t = 0; t < 64; ++t) {
+                if (!L[t].live) continue;
+                Ray r = L[t].r; Hit best;
+                int32_t col[64];
+                trace_reference(r, sc.nodes, sc.triPos, StridedStack{col, 1}, 64, best);
+                if (best.k != L[t].best.k || best.t != L[t].best.t) differ++;
+            }
+        }
+    }
+    out[0] = waves; out[1] = visits; out[2] = leaves; out[3] = leafLanes; out[4] = heaviest; out[5] = deepest; out[6] = differ;
+}
+
 // Lockstep replay of the while-while variant: phase 1 = every lane walks internal nodes until it
 // has a pending leaf (or is finished), phase 2 = all lanes with a pending leaf test it together.
 // out[0] waves, out[1] phase-1 iterations, out[2] live lanes in them, out[3] phase-2 executions,

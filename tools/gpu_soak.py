@@ -13,7 +13,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dxrvoxelizer_amd as dxv  # noqa: E402
-from dxrvoxelizer_amd import meshes  # noqa: E402
+from dxrvoxelizer_amd import camera, meshes  # noqa: E402
 from oracle import orc  # noqa: E402
 from test_fuzz import lattice_mesh  # noqa: E402
 
@@ -54,7 +54,10 @@ def main():
         except Exception:
             continue
         v.set_option("wide", int(rng.integers(0, 3)))
+        v.set_option("refit", int(rng.choice([1, 1, 2, 0])) if T < 30000 else int(rng.choice([1, 2])))   # box merge of the build
         v.InitFromArrays(vb, ib)
+        if rng.integers(0, 3) == 0:                       # same vertices again: the refit must reproduce the build's boxes
+            v.UpdateVertices(np.ascontiguousarray(vb, np.float32))
         cases += 1
         for _ in range(4):
             big = T > 5000
@@ -93,6 +96,14 @@ def main():
                                   "differ": int((got != ref).sum())}))
                 sys.exit(1)
             assert np.array_equal(v.GridBits(), np.packbits(got.reshape(-1), bitorder="little"))
+            if part == 0 and rng.integers(0, 4) == 0:      # display pass: the empty-brick skip changes no pixel
+                eye, vp = camera.default_view_proj(96, 64, eye=tuple(float(x) for x in rng.uniform(-12, 12, 3) + np.array([0, 0, 14.0])))
+                v.set_option("skipempty", 1)
+                a = v.Render(eye, vp, 96, 64)
+                v.set_option("skipempty", 0)
+                b = v.Render(eye, vp, 96, 64)
+                v.set_option("skipempty", 1)
+                assert np.array_equal(a, b), (label, N)
     print(json.dumps({"soak": "ok", "seconds": round(time.time() - t0, 1), "meshes": cases, "grids": grids, "seed": seed}))
 
 
