@@ -77,7 +77,7 @@ struct dxv_ctx {
     // options
     int optBrick = 4;        // 4x4x4 voxels = one wavefront per workgroup (fastest in the r01 sweeps)
     int optStack = 0;        // 0 = adaptive (start small, grow on overflow), else forced depth
-    int optRefit = 1;        // 1 = level-synchronous sweeps (default: 17-30x faster than the fence-bound one-pass climb), 0 = atomic one-pass
+    int optRefit = 1;        // box merge of build and refit: 1 = min/max pyramid (default), 2 = level sweeps, 0 = atomic one-pass climb (17-30x slower, cross-check)
     int optMorton = 1;       // Morton brick order
     int optQueue = 1;        // postponed-leaf traversal
     int optSubbox = 1;       // launch only the bricks around the scene's root box, memset the rest
@@ -582,6 +582,7 @@ int dxv_grid_download(dxv_ctx* c, uint8_t* host, size_t bytes)
 {
     if (!c) return 1;
     if (!host || bytes != c->gridBytes || !c->gridBytes) return fail(c, "dxv_grid_download: expected %zu bytes, got %zu", c->gridBytes, bytes);
+    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
     DXV_HIP(c, hipMemcpyAsync(host, c->dGrid, bytes, hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
@@ -595,6 +596,7 @@ int dxv_grid_download_packed(dxv_ctx* c, uint8_t* host, size_t bytes)
     if (!c) return 1;
     const size_t want = (c->gridBytes + 7) / 8;
     if (!host || !want || bytes != want) return fail(c, "dxv_grid_download_packed: expected %zu bytes, got %zu", want, bytes);
+    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
     if (want > c->packedCap) {
         DXV_HIP(c, hipStreamSynchronize(c->stream));
@@ -612,6 +614,7 @@ int dxv_grid_count(dxv_ctx* c, uint64_t* solid)
 {
     if (!c) return 1;
     if (!solid || !c->gridBytes) return fail(c, "dxv_grid_count: no grid");
+    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
     DXV_HIP(c, launch_count(c->dGrid, c->gridBytes, c->dCount, c->stream));
     unsigned long long v = 0;
@@ -633,6 +636,7 @@ int dxv_texels_download(dxv_ctx* c, uint32_t* host, size_t bytes)
     if (!c) return 1;
     if (!c->texels || !c->dTexels) return fail(c, "dxv_texels_download: texel output not enabled");
     if (!host || bytes != c->gridBytes * 4) return fail(c, "dxv_texels_download: expected %zu bytes, got %zu", c->gridBytes * 4, bytes);
+    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
     DXV_HIP(c, hipMemcpyAsync(host, c->dTexels, bytes, hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));

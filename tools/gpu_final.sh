@@ -18,7 +18,7 @@ import dxrvoxelizer_amd as dxv
 from dxrvoxelizer_amd import camera
 from bench import make_mesh
 v = dxv.Voxelizer(0)
-for mesh, N in (("bunny", 64), ("dragon", 512)):
+for mesh, N in (("bunny", 64), ("dragon", 512), ("torus1m", 512)):
     vb, ib, _ = make_mesh(mesh)
     v.InitFromArrays(vb, ib); v.Voxelize(N)
     eye, vp = camera.default_view_proj(1280, 720)
@@ -30,8 +30,8 @@ for mesh, N in (("bunny", 64), ("dragon", 512)):
     print(json.dumps({"mesh": mesh, "N": N, "render_ms_1280x720": float(np.median(ts[1:])), "opaque_px": int((img[..., 3] == 255).sum())}))
 PY
 python tools/pcie_bench.py 512 > $OUT/pcie.jsonl 2>&1
-python tools/ab_option.py wide 0,1 --meshes torus1m,bunny,dragon,dragon9,bunny16 --grid 512 > $OUT/ab_wide.jsonl 2>&1
-python tools/ab_option.py wide 0,1 --meshes torus1m,bunny,dragon --grid 256 >> $OUT/ab_wide.jsonl 2>&1
+python tools/ab_option.py wide 0,2 --meshes torus1m,bunny,dragon,dragon9,bunny16 --grid 512 > $OUT/ab_wide.jsonl 2>&1
+python tools/ab_option.py wide 0,2 --meshes torus1m,bunny,dragon --grid 256 >> $OUT/ab_wide.jsonl 2>&1
 python tools/ab_option.py stack0 12,16,20,24 --rounds 2 > $OUT/ab_stack0.jsonl 2>&1
 python tools/rowblock_table.py > $OUT/rowblock.jsonl 2>&1
 python tools/small_grid_latency.py > $OUT/small_grid_latency.jsonl 2>&1
