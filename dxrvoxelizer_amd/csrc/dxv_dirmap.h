@@ -1,0 +1,207 @@
+// dxv_dirmap.h -- direction-space candidate lists for the reference rule (shared by the kernels,
+// the device builder and tests/hostcheck).
+//
+// Every ray of the reference rule is radial: origin p = voxel centre, direction p / |p|
+// (Content/Shaders/DXRVoxelizer.hlsl:44-53), so the points of a ray are (rho + t) * dir with
+// rho = |p|: in direction space a ray is one POINT plus a start radius.  A cube map around the grid
+// centre (6 faces of R x R texels, face coordinates u = p_b / |p_a|, v = p_c / |p_a| on the face of
+// the dominant axis a) lists, per texel, the triangles whose projection can reach it.  A ray reads
+// the list of its texel and hands the few entries whose footprint box contains (u, v) and whose
+// radial range lies beyond rho to the same canonical triangle step as the tree walks
+// (leaf_reference: padded-box slab test, watertight test, closest = min (t, k)).  No stack, no tree.
+//
+// Identical results need only one property: every triangle that leaf_reference would accept for a
+// ray is listed in that ray's texel with a footprint containing the ray and a radial range that
+// passes.  A triangle accepted by the watertight test is within a few ulps (positions lie in
+// [-1, 1]: ~1e-7) of the geometric ray, so footprints are those of the triangle dilated by
+// kDmDelta = 2^-16 (200 x that), clipped against face frusta widened by 2^-10, and then rounded
+// outward to halfs; triangles closer than 64 kDmDelta to the centre along the face axis take the
+// whole face.  tests/ (fuzz against the oracle, lattice-snapped adversarial meshes) and the GPU
+// soak check the claim the same way they check the padded leaf boxes.
+#pragma once
+#include "dxv_trace.h"
+
+namespace dxv {
+
+struct alignas(16) DirEntry {
+    uint16_t u0, u1, v0, v1;   // footprint box in face coordinates (halfs, rounded outward); u0 > u1: no footprint
+    uint16_t r0, r1;           // radial range of the triangle part inside the face frustum (halfs, rounded outward)
+    uint32_t tri;              // position in the scene's triangle order (TriPos index)
+};
+static_assert(sizeof(DirEntry) == 16, "one 16-byte load per entry");
+
+struct DirCell { uint32_t begin, end; };            // entries [begin, end) of a texel
+
+struct DirMapView {
+    const DirCell* cells;      // 6 * R * R, cell = (face * R + j) * R + i; NULL: no map
+    const DirEntry* entries;
+    uint32_t R;                // texels per face side, a power of two
+};
+
+constexpr float kDmDelta = 1.52587890625e-5f;       // 2^-16: dilation of the triangles
+constexpr double kDmFrustum = 1.0 + 1.0 / 1024.0;   // face frusta are widened by this factor
+
+// texel index of face coordinate u (monotone in u: add, multiply by a power of two, floor)
+DXV_HD uint32_t dm_texel(float u, uint32_t R)
+{
+    const float x = (u + 1.0f) * (0.5f * (float)R);
+    if (!(x > 0.0f)) return 0u;
+    const uint32_t i = (uint32_t)x;
+    return i < R ? i : R - 1u;
+}
+
+// face = 2 * axis + (negative side); in-face axes (b, c) = ((axis + 1) % 3, (axis + 2) % 3)
+DXV_HD void dm_ray_point(float ox, float oy, float oz, uint32_t& face, float& u, float& v, float& rho)
+{
+    const float ax = __builtin_fabsf(ox), ay = __builtin_fabsf(oy), az = __builtin_fabsf(oz);
+    if (ax >= ay && ax >= az) { face = ox < 0.0f ? 1u : 0u; u = oy / ax; v = oz / ax; }
+    else if (ay >= az) { face = oy < 0.0f ? 3u : 2u; u = oz / ay; v = ox / ay; }
+    else { face = oz < 0.0f ? 5u : 4u; u = ox / az; v = oy / az; }
+    rho = __builtin_sqrtf((ox * ox + oy * oy) + oz * oz);
+}
+
+// Footprint of triangle tp on one face, or false when it cannot be seen through that face.
+// Builder side only (one call per triangle and face): double precision, nothing canonical here --
+// the result only has to be a superset.
+struct DirFootprint { float u0, u1, v0, v1, r0, r1; };
+
+DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
+{
+    const uint32_t a = face >> 1, b = (a + 1u) % 3u, c = (a + 2u) % 3u;
+    const double s = (face & 1u) ? -1.0 : 1.0;
+    const float vx[3][3] = {{tp.v0.x, tp.v0.y, tp.v0.z}, {tp.v1.x, tp.v1.y, tp.v1.z}, {tp.v2.x, tp.v2.y, tp.v2.z}};
+    double poly[2][10][3];
+    int n = 3, cur = 0;
+    for (int i = 0; i < 3; ++i) { poly[0][i][0] = vx[i][b]; poly[0][i][1] = vx[i][c]; poly[0][i][2] = s * (double)vx[i][a]; }
+    const double delta = (double)kDmDelta;
+    // the four side planes of the widened frustum, pushed out by the dilation: kF * d +- b + 2 delta >= 0
+    const double planes[4][2] = {{1.0, 0.0}, {-1.0, 0.0}, {0.0, 1.0}, {0.0, -1.0}};
+    for (int pl = 0; pl < 4 && n > 0; ++pl) {
+        const double nb = planes[pl][0], nc = planes[pl][1];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const double* A = poly[cur][i];
+            const double* B = poly[cur][(i + 1) % n];
+            const double fa = kDmFrustum * A[2] + nb * A[0] + nc * A[1] + 2.0 * delta;
+            const double fb = kDmFrustum * B[2] + nb * B[0] + nc * B[1] + 2.0 * delta;
+            if (fa >= 0.0) { for (int k = 0; k < 3; ++k) poly[cur ^ 1][m][k] = A[k]; ++m; }
+            if ((fa >= 0.0) != (fb >= 0.0)) {
+                const double w = fa / (fa - fb);
+                for (int k = 0; k < 3; ++k) poly[cur ^ 1][m][k] = A[k] + (B[k] - A[k]) * w;
+                ++m;
+            }
+        }
+        cur ^= 1;
+        n = m;
+    }
+    if (n == 0) return false;
+    double dmin = poly[cur][0][2], rmax = 0.0, rminv = 1e300;
+    for (int i = 0; i < n; ++i) {
+        const double* q = poly[cur][i];
+        if (q[2] < dmin) dmin = q[2];
+        const double r = __builtin_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        if (r > rmax) rmax = r;
+        if (r < rminv) rminv = r;
+    }
+    const double full = kDmFrustum + 1.0 / 256.0;
+    double u0 = -full, u1 = full, v0 = -full, v1 = full;
+    if (dmin >= 64.0 * delta) {
+        u0 = v0 = 1e300; u1 = v1 = -1e300;
+        for (int i = 0; i < n; ++i) {
+            const double* q = poly[cur][i];
+            const double u = q[0] / q[2], v = q[1] / q[2];
+            if (u < u0) u0 = u;
+            if (u > u1) u1 = u;
+            if (v < v0) v0 = v;
+            if (v > v1) v1 = v;
+        }
+        // a point moved by delta sideways and in depth at depth >= dmin: du <= (1 + |u|) delta / (dmin - delta)
+        const double pad = 4.0 * delta / dmin + 1e-6;
+        u0 -= pad; u1 += pad; v0 -= pad; v1 += pad;
+        if (u0 < -full) u0 = -full;
+        if (v0 < -full) v0 = -full;
+        if (u1 > full) u1 = full;
+        if (v1 > full) v1 = full;
+    }
+    // radial range: the farthest point of a convex polygon is a vertex; a lower bound of the nearest
+    // is the distance of the origin to the triangle's plane, or the nearest vertex minus the diameter
+    const double e1[3] = {(double)vx[1][0] - vx[0][0], (double)vx[1][1] - vx[0][1], (double)vx[1][2] - vx[0][2]};
+    const double e2[3] = {(double)vx[2][0] - vx[0][0], (double)vx[2][1] - vx[0][1], (double)vx[2][2] - vx[0][2]};
+    const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const double nl = __builtin_sqrt(nx * nx + ny * ny + nz * nz);
+    double rmin = 0.0;
+    if (nl > 1e-30) {
+        const double dist = __builtin_fabs(nx * vx[0][0] + ny * vx[0][1] + nz * vx[0][2]) / nl;
+        rmin = dist * (1.0 - 1e-6);
+    }
+    double diam = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const double* p = poly[cur][i];
+            const double* q = poly[cur][j];
+            const double d = __builtin_sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]));
+            if (d > diam) diam = d;
+        }
+    if (rminv - diam > rmin) rmin = rminv - diam;
+    rmin -= 4.0 * delta;
+    if (rmin < 0.0) rmin = 0.0;
+    rmax += 4.0 * delta;
+    out.u0 = (float)u0; out.u1 = (float)u1; out.v0 = (float)v0; out.v1 = (float)v1;
+    out.r0 = (float)rmin; out.r1 = (float)rmax;
+    // float conversion rounds to nearest: one more ulp outward
+    out.u0 = __builtin_nextafterf(out.u0, -__builtin_inff()); out.v0 = __builtin_nextafterf(out.v0, -__builtin_inff());
+    out.u1 = __builtin_nextafterf(out.u1, __builtin_inff()); out.v1 = __builtin_nextafterf(out.v1, __builtin_inff());
+    out.r0 = out.r0 > 0.0f ? __builtin_nextafterf(out.r0, 0.0f) : 0.0f;
+    out.r1 = __builtin_nextafterf(out.r1, __builtin_inff());
+    return true;
+}
+
+// the record of (triangle, face) as it is stored in the lists; u0 > u1 when there is no footprint
+DXV_HD DirEntry dm_entry(const TriPos& tp, uint32_t face, uint32_t tri)
+{
+    DirEntry e;
+    DirFootprint f;
+    e.tri = tri;
+    if (!dm_footprint(tp, face, f)) { e.u0 = 0x3c00u; e.u1 = 0u; e.v0 = 0x3c00u; e.v1 = 0u; e.r0 = 0u; e.r1 = 0u; return e; }   // 1 > 0
+    e.u0 = half_down(f.u0); e.u1 = half_up(f.u1); e.v0 = half_down(f.v0); e.v1 = half_up(f.v1);
+    e.r0 = half_down(f.r0); e.r1 = half_up(f.r1);
+    return e;
+}
+
+// texel rectangle [i0, i1] x [j0, j1] of an entry (false: none)
+DXV_HD bool dm_rect(const DirEntry& e, uint32_t R, uint32_t& i0, uint32_t& i1, uint32_t& j0, uint32_t& j1)
+{
+    const float u0 = half_bits_to_float(e.u0), u1 = half_bits_to_float(e.u1);
+    const float v0 = half_bits_to_float(e.v0), v1 = half_bits_to_float(e.v1);
+    if (u0 > u1) return false;
+    if (u1 < -1.0f || u0 > 1.0f || v1 < -1.0f || v0 > 1.0f) return false;      // rays only have |u|, |v| <= 1
+    i0 = dm_texel(u0, R); i1 = dm_texel(u1, R); j0 = dm_texel(v0, R); j1 = dm_texel(v1, R);
+    return true;
+}
+
+// closest hit of the reference rule through the lists
+DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, Hit& best)
+{
+    best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
+    uint32_t face;
+    float u, v, rho;
+    dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
+    const DirCell cell = dm.cells[(face * dm.R + dm_texel(v, dm.R)) * dm.R + dm_texel(u, dm.R)];
+    const float near = rho * 0.999f;
+    for (uint32_t i = cell.begin; i < cell.end; ++i) {
+        const DirEntry e = dm.entries[i];
+        if (u < half_bits_to_float(e.u0) || u > half_bits_to_float(e.u1)) continue;
+        if (v < half_bits_to_float(e.v0) || v > half_bits_to_float(e.v1)) continue;
+        if (half_bits_to_float(e.r1) < near) continue;                                   // wholly nearer the centre than the ray's start: t < 0
+        if (half_bits_to_float(e.r0) > (rho + best.t) * 1.001f + 1e-4f) continue;        // wholly beyond the closest hit so far
+        leaf_reference(r, tris, (int32_t)e.tri, best);
+    }
+}
+
+DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, Hit& best)
+{
+    const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
+    trace_reference_dm(r, dm, sc.triPos, best);
+}
+
+} // namespace dxv

@@ -570,12 +570,17 @@ struct SceneView {
     const TriNrm* triNrm;
     float rootLo[3], rootHi[3];
     const Node64* wide;     // wide copy of `nodes` (reference rule, WALK 2)
+    const void* dmCells;    // direction-space lists (dxv_dirmap.h, WALK 4): DirCell[6 R R], DirEntry[], R
+    const void* dmEntries;
+    uint32_t dmR;
 };
+
+DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, Hit& best);      // dxv_dirmap.h
 
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
 // WALK: 0 = leaves tested as they are met, 1 = postponed-leaf walk, 2 = postponed-leaf walk over the
-// wide nodes, 3 = wide nodes on wave-uniform visits only.  All return the same voxel.
+// wide nodes, 3 = wide nodes on wave-uniform visits only, 4 = direction-space lists.  All return the same voxel.
 template <int WALK, class Stack>
 DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
                                const Stack& stk, int cap, uint32_t* texel, bool& overflow)
@@ -586,7 +591,9 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
     finish_ray_reference(r);
     Hit best;
-    const bool ok = WALK == 3 ? trace_reference_h(r, sc.nodes, sc.wide, sc.triPos, stk, cap, best)
+    if (WALK == 4) trace_reference_lists(r, sc, best);                           // no tree, no stack: cannot overflow
+    const bool ok = WALK == 4 ? true
+                  : WALK == 3 ? trace_reference_h(r, sc.nodes, sc.wide, sc.triPos, stk, cap, best)
                   : WALK == 2 ? trace_reference_w(r, sc.wide, sc.triPos, stk, cap, best)
                   : WALK == 1 ? trace_reference_q(r, sc.nodes, sc.triPos, stk, cap, best)
                               : trace_reference(r, sc.nodes, sc.triPos, stk, cap, best);

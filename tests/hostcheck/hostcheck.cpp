@@ -3,6 +3,7 @@
 // hierarchy rule and the traversal can be checked against the oracle without a GPU.
 // Never linked into libdxv.so; the shipped library has no CPU path.
 #include "../../dxrvoxelizer_amd/csrc/dxv_trace.h"
+#include "../../dxrvoxelizer_amd/csrc/dxv_dirmap.h"
 #include "../../dxrvoxelizer_amd/csrc/dxv_raycast.h"
 
 #include <algorithm>
@@ -29,6 +30,9 @@ struct HcScene {
     std::vector<TriPos> triPos;
     std::vector<TriNrm> triNrm;
     uint32_t height = 0;
+    std::vector<DirCell> dmCells;          // direction-space lists (hc_dirmap_build)
+    std::vector<DirEntry> dmEntries;
+    uint32_t dmR = 0;
 };
 
 static void set_child(Node& n, int side, const float lo[3], const float hi[3], uint32_t h)
@@ -112,6 +116,40 @@ __attribute__((visibility("default"))) void* hc_scene_create(const float* vb, ui
     return s;
 }
 
+// Direction-space lists built on the host with the product's own footprint code (dxv_dirmap.h); the
+// device builder (dirmap.hip) must produce the same lists.  Returns the number of entries.
+__attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_t R)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    std::vector<uint64_t> keys;
+    std::vector<DirEntry> rec((size_t)s->T * 6);
+    for (uint32_t t = 0; t < s->T; ++t)
+        for (uint32_t f = 0; f < 6; ++f) {
+            const DirEntry e = rec[(size_t)t * 6 + f] = dm_entry(s->triPos[t], f, t);
+            uint32_t i0, i1, j0, j1;
+            if (!dm_rect(e, R, i0, i1, j0, j1)) continue;
+            for (uint32_t j = j0; j <= j1; ++j)
+                for (uint32_t i = i0; i <= i1; ++i) keys.push_back(((uint64_t)((f * R + j) * R + i) << 32) | t);
+        }
+    std::sort(keys.begin(), keys.end());
+    s->dmR = R;
+    s->dmCells.assign((size_t)6 * R * R, DirCell{0, 0});
+    s->dmEntries.resize(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) {
+        const uint32_t cell = (uint32_t)(keys[i] >> 32), t = (uint32_t)keys[i];
+        s->dmEntries[i] = rec[(size_t)t * 6 + cell / (R * R)];
+        if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != cell) s->dmCells[cell].begin = (uint32_t)i;
+        s->dmCells[cell].end = (uint32_t)i + 1;
+    }
+    return keys.size();
+}
+__attribute__((visibility("default"))) void hc_dirmap_get(void* p, void* cells, void* entries)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    memcpy(cells, s->dmCells.data(), s->dmCells.size() * sizeof(DirCell));
+    memcpy(entries, s->dmEntries.data(), s->dmEntries.size() * sizeof(DirEntry));
+}
+
 __attribute__((visibility("default"))) void hc_scene_nodes32(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes32.data(), s->nodes32.size() * sizeof(Node32)); }
 __attribute__((visibility("default"))) uint32_t hc_half_down(float x) { return half_down(x); }
 __attribute__((visibility("default"))) uint32_t hc_half_up(float x) { return half_up(x); }
@@ -169,7 +207,9 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
         return 0;
     }
     int overflow = 0;
-    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}, s->nodes64.data()};
+    SceneView sc{s->nodes32.data(), s->triPos.data(), s->triNrm.data(), {0, 0, 0}, {0, 0, 0}, s->nodes64.data(),
+                 s->dmCells.data(), s->dmEntries.data(), s->dmR};
+    if (mode == 12 && !s->dmR) return -1;
     {   // root box = union of the root node's two child boxes (as k_root_info computes it)
         const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
         for (int a = 0; a < 3; ++a) { sc.rootLo[a] = min_(w[a], w[6 + a]); sc.rootHi[a] = max_(w[3 + a], w[9 + a]); }
@@ -186,6 +226,7 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
             out[id] = mode == 0 ? voxel_reference<0>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
                       : mode == 2 ? voxel_reference<1>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
                       : mode == 6 ? voxel_reference<2>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
+                      : mode == 12 ? voxel_reference<4>(sc, N, ix, iy, iz, stk, stackCap, texels ? &texel : nullptr, ovf)
                       : mode == 3 ? voxel_parity<true>(sc, N, ix, iy, iz, stk, stackCap, ovf)
                                   : voxel_parity<false>(sc, N, ix, iy, iz, stk, stackCap, ovf);
             if (texels) texels[id] = texel;
