@@ -24,7 +24,8 @@ class Stats(C.Structure):
                 ("refit_ms", C.c_float), ("build_ms", C.c_float), ("voxelize_ms", C.c_float),
                 ("grid_dim", C.c_uint32), ("z0", C.c_uint32), ("nz", C.c_uint32),
                 ("stack_entries", C.c_uint32), ("render_ms", C.c_float), ("redo_rays", C.c_uint32),
-                ("row_block", C.c_uint32), ("tri_extent", C.c_float), ("reserved", C.c_uint32 * 3)]
+                ("row_block", C.c_uint32), ("tri_extent", C.c_float), ("list_entries", C.c_uint32), ("list_res", C.c_uint32),
+                ("list_ms", C.c_float)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("bound", "reserved")}

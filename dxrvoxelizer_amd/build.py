@@ -16,8 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libdxv.so")
 
-SOURCES = ["dxv_api.hip", "lbvh.hip", "radix_sort.hip", "traverse.hip", "raycast.hip", "obj_ingest.cpp"]
-HEADERS = ["dxv_device.h", "dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_raycast.h", os.path.join("..", "..", "include", "dxv.h")]
+SOURCES = ["dxv_api.hip", "lbvh.hip", "radix_sort.hip", "traverse.hip", "raycast.hip", "dirmap.hip", "obj_ingest.cpp"]
+HEADERS = ["dxv_device.h", "dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_raycast.h", "dxv_dirmap.h", os.path.join("..", "..", "include", "dxv.h")]
 
 # -ffp-contract=off: the arithmetic of the path has a fixed operation order; the only fused
 # operations are the explicit fmaf calls in dxv_math.h (hipcc contracts by default).

@@ -1,0 +1,175 @@
+// dirmap.hip -- device build of the direction-space lists (dxv_dirmap.h) from a scene's triangle
+// records.  One-off per scene (and per refit), HBM-bound passes:
+//   k_dm_records  one thread per (triangle, face): footprint record + number of texels it covers
+//   k_dm_emit     one thread per (triangle, face): (texel | far radius | triangle) keys for its texels
+//   radix sort    by texel, then far radius (stable: then triangle)
+//   k_dm_cells    first / last entry of every texel
+//   k_dm_entries  16-byte entries in list order (copied from the records)
+// The keys of one (triangle, face) are written by one thread: footprints are a few texels unless a
+// triangle passes close to the grid centre, and the total is capped (the caller then keeps the tree).
+#include "dxv_device.h"
+#include "dxv_dirmap.h"
+
+namespace dxv {
+
+namespace {
+constexpr uint32_t kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R,
+                                                         DirEntry* __restrict__ rec, uint32_t* __restrict__ counts,
+                                                         unsigned long long* __restrict__ total)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    unsigned long long n = 0;
+    if (i < 6u * T) {
+        const uint32_t tri = i / 6u, face = i % 6u;
+        const DirEntry e = dm_entry(triPos[tri], face, tri);
+        rec[i] = e;
+        uint32_t i0, i1, j0, j1;
+        if (dm_rect(e, R, i0, i1, j0, j1)) n = (unsigned long long)(i1 - i0 + 1u) * (j1 - j0 + 1u);
+        counts[i] = (uint32_t)n;
+    }
+    for (int off = 32; off; off >>= 1) n += __shfl_down(n, off);
+    __shared__ unsigned long long part[kThreads / 64];
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (uint32_t w = 0; w < kThreads / 64; ++w) s += part[w];
+        if (s) atomicAdd(total, s);
+    }
+}
+
+// exclusive scan of counts[0 .. n) in three launches: per-block sums, scan of the sums by one block, add
+constexpr uint32_t kScanBlock = 1024;
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ sums)
+{
+    const uint32_t base = blockIdx.x * kScanBlock;
+    uint32_t s = 0;
+    for (uint32_t k = threadIdx.x; k < kScanBlock; k += 256u)
+        if (base + k < n) s += counts[base + k];
+    for (int off = 32; off; off >>= 1) s += __shfl_down(s, off);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t* sums, uint32_t nb)
+{
+    // one workgroup, sequential chunks of 1024 with a running carry
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024u) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t v = idx < nb ? sums[idx] : 0u;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024u; off <<= 1) {
+            const uint32_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (idx < nb) sums[idx] = carry + buf[threadIdx.x] - v;      // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry += buf[1023];
+        __syncthreads();
+    }
+}
+
+// offsets[i] = sums[block] + exclusive scan inside the block (serial per thread chunk of 4, then across the block)
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ counts, uint32_t n, const uint32_t* __restrict__ sums,
+                                                    uint32_t* __restrict__ offsets)
+{
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+    uint32_t c[4], s = 0;
+    for (int k = 0; k < 4; ++k) { c[k] = base + k < n ? counts[base + k] : 0u; s += c[k]; }
+    __shared__ uint32_t buf[256];
+    buf[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256u; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
+        __syncthreads();
+        buf[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = sums[blockIdx.x] + buf[threadIdx.x] - s;
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) offsets[base + k] = run;
+        run += c[k];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_dm_emit(const DirEntry* __restrict__ rec, const uint32_t* __restrict__ offsets, uint32_t T,
+                                                      uint32_t R, uint64_t* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= 6u * T) return;
+    const uint32_t tri = i / 6u, face = i % 6u;
+    uint32_t i0, i1, j0, j1;
+    if (!dm_rect(rec[i], R, i0, i1, j0, j1)) return;
+    uint64_t* out = keys + offsets[i];
+    const DirKeyLayout lay = dm_key_layout(R);
+    const uint16_t r1 = rec[i].r1;
+    for (uint32_t j = j0; j <= j1; ++j)
+        for (uint32_t x = i0; x <= i1; ++x) *out++ = dm_key(lay, (face * R + j) * R + x, r1, tri);
+}
+
+__global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restrict__ keys, uint32_t n, const DirEntry* __restrict__ rec,
+                                                       uint32_t R, DirCell* __restrict__ cells, DirEntry* __restrict__ entries)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const DirKeyLayout lay = dm_key_layout(R);
+    const uint64_t key = keys[i];
+    const uint32_t cell = dm_key_cell(lay, key), tri = dm_key_tri(lay, key);
+    if (i == 0u || dm_key_cell(lay, keys[i - 1u]) != cell) cells[cell].begin = i;
+    if (i + 1u == n || dm_key_cell(lay, keys[i + 1u]) != cell) cells[cell].end = i + 1u;
+    entries[i] = rec[(size_t)tri * 6u + cell / (R * R)];
+}
+} // namespace
+
+// scratch bytes of a build that emits `entries` keys for T triangles (records, counts/offsets, block sums, keys x 2, histogram)
+size_t dirmap_scratch_bytes(uint32_t T, uint64_t entries)
+{
+    const size_t n6 = 6 * (size_t)T, nb = (n6 + kScanBlock - 1) / kScanBlock;
+    return n6 * sizeof(DirEntry) + 2 * n6 * sizeof(uint32_t) + (nb + 1) * sizeof(uint32_t) + 256 +
+           2 * (size_t)entries * sizeof(uint64_t) + sizeof(uint32_t) * (size_t)radix_sort_hist_words((uint32_t)entries) + 1024;
+}
+
+// Pass 1: records, per-(triangle, face) counts and the total.  rec: 6T entries, counts: 6T words, total: one 64-bit word.
+hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirEntry* rec, uint32_t* counts, unsigned long long* total,
+                        hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    k_dm_records<<<(6u * T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total);
+    return hipGetLastError();
+}
+
+// Pass 2: lists.  offsets: 6T words, sums: ceil(6T / 1024) words, keys / keysTmp: n each, hist: radix_sort_hist_words(n),
+// cells: 6 R R, entries: n (n = the total of pass 1).
+hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirEntry* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
+                       uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, hipStream_t s)
+{
+    const uint32_t n6 = 6u * T, nb = (n6 + kScanBlock - 1) / kScanBlock;
+    hipError_t e;
+    k_scan_sums<<<nb, 256, 0, s>>>(counts, n6, sums);
+    k_scan_top<<<1, 1024, 0, s>>>(sums, nb);
+    k_scan_apply<<<nb, 256, 0, s>>>(counts, n6, sums, offsets);
+    if ((e = hipMemsetAsync(cells, 0, sizeof(DirCell) * 6 * (size_t)R * R, s)) != hipSuccess) return e;
+    if (n == 0) return hipGetLastError();
+    k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, offsets, T, R, keys);
+    // sort by (texel, far radius): the bits above the triangle field, in whole 8-bit digits
+    const DirKeyLayout lay = dm_key_layout(R);
+    const int passes = (int)((lay.cellBits + 16u + 7u) / 8u), loBit = 64 - 8 * passes;
+    uint64_t* sorted = keys;
+    if (n > 1 && (e = radix_sort_keys_bits(keys, keysTmp, n, hist, loBit, passes, &sorted, s)) != hipSuccess) return e;
+    k_dm_cells<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, rec, R, cells, entries);
+    return hipGetLastError();
+}
+
+} // namespace dxv

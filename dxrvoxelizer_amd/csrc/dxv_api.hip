@@ -4,6 +4,7 @@
 #include "../../include/dxv.h"
 #include "dxv_device.h"
 #include "dxv_raycast.h"
+#include "dxv_dirmap.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -66,6 +67,15 @@ struct dxv_ctx {
     size_t packedCap = 0;
     uint32_t* dImage = nullptr;
     size_t imageCap = 0;
+    // direction-space lists of the reference rule (dxv_dirmap.h), built lazily from the scene's triangle records
+    DirCell* dListCells = nullptr;
+    DirEntry* dListEntries = nullptr;
+    size_t listCellCap = 0, listEntryCap = 0;
+    uint32_t listEntries = 0, listRes = 0;
+    int listState = 0;               // 0: not built for this scene, 1: built, -1: over the cap for this scene (tree walk)
+    int optLists = 1;                // reference rule through the lists (-20...-48 % against the tree walk, profiles/r01/final/ab_lists.jsonl)
+    int optListRes = 0;              // texels per face side; 0 = by triangle count (list_resolution)
+    float listMs = 0.0f;
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
     size_t emptyCap = 0;
     int optSkipEmpty = 1;    // display pass: skip the samples of empty 8^3 bricks (same image)
@@ -196,6 +206,78 @@ int safe_stack(const dxv_ctx* c)
     return stack_round_up((int)c->hdr.treeHeight + 3);
 }
 
+// Build the direction-space lists of the current scene (one-off per scene; synchronous).  Scenes whose
+// lists would exceed 256 entries per triangle + 64 M (triangles through the grid centre cover whole
+// faces) keep the tree walk: listState = -1.
+// Texels per face side.  Measured optimum (tools/ab_lists.py): 5-10 entries per texel -- coarser maps
+// have long lists, finer ones stop fitting the caches: 128 below 20 k triangles, 256 up to 3 M, 512 beyond.
+uint32_t list_resolution(const dxv_ctx* c)
+{
+    if (c->optListRes) return (uint32_t)c->optListRes;
+    return c->hdr.numTris < 20000u ? 128u : c->hdr.numTris < 3000000u ? 256u : 512u;
+}
+
+int build_lists(dxv_ctx* c)
+{
+    const uint32_t T = c->hdr.numTris, R = list_resolution(c);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, c->stream);
+    const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
+    DirEntry* rec = nullptr;
+    uint32_t *counts = nullptr, *offsets = nullptr, *sums = nullptr, *hist = nullptr;
+    uint64_t *keys = nullptr, *keysTmp = nullptr;
+    unsigned long long* dTotal = nullptr;
+    auto release = [&]() {
+        (void)hipFree(rec); (void)hipFree(counts); (void)hipFree(offsets); (void)hipFree(sums); (void)hipFree(hist);
+        (void)hipFree(keys); (void)hipFree(keysTmp); (void)hipFree(dTotal);
+    };
+    auto bail = [&](hipError_t e, const char* what) { release(); return fail(c, "lists: %s failed: %s", what, hipGetErrorString(e)); };
+    hipError_t e;
+    if ((e = hipMalloc(&rec, n6 * sizeof(DirEntry))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&counts, n6 * 4)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&offsets, n6 * 4)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&sums, (nb + 1) * 4)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&dTotal, 256)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, c->stream)) != hipSuccess) return bail(e, "dirmap_count");
+    unsigned long long total = 0;
+    if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    const unsigned long long cap = 256ull * T + (64ull << 20);
+    if (total > cap || total > 0x7fffffffull || (unsigned long long)T > (1ull << dm_key_layout(R).triBits)) {
+        release();
+        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+        c->listState = -1;
+        c->listEntries = 0;
+        return 0;
+    }
+    const uint32_t n = (uint32_t)total;
+    const size_t cells = 6 * (size_t)R * R;
+    if (cells > c->listCellCap) {
+        (void)hipFree(c->dListCells); c->dListCells = nullptr; c->listCellCap = 0;
+        if ((e = hipMalloc(&c->dListCells, cells * sizeof(DirCell))) != hipSuccess) return bail(e, "hipMalloc");
+        c->listCellCap = cells;
+    }
+    if ((size_t)n > c->listEntryCap) {
+        (void)hipFree(c->dListEntries); c->dListEntries = nullptr; c->listEntryCap = 0;
+        if ((e = hipMalloc(&c->dListEntries, ((size_t)n + 1) * sizeof(DirEntry))) != hipSuccess) return bail(e, "hipMalloc");
+        c->listEntryCap = n;
+    }
+    if ((e = hipMalloc(&keys, ((size_t)n + 1) * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&keysTmp, ((size_t)n + 1) * 8)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMalloc(&hist, sizeof(uint32_t) * (size_t)radix_sort_hist_words(n ? n : 1))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, c->stream)) != hipSuccess)
+        return bail(e, "dirmap_fill");
+    if (t1) (void)hipEventRecord(t1, c->stream);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    if (t0 && t1) c->listMs = elapsed(t0, t1);
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    release();
+    c->listEntries = n;
+    c->listRes = R;
+    c->listState = 1;
+    return 0;
+}
+
 int launch_now(dxv_ctx* c)
 {
     VoxelizeParams p{};
@@ -213,7 +295,19 @@ int launch_now(dxv_ctx* c)
     p.queued = (uint32_t)c->optQueue;
     p.subbox = (uint32_t)c->optSubbox;
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
-    const int st = c->optStack ? c->optStack : c->stackNow;
+    int st = c->optStack ? c->optStack : c->stackNow;
+    c->stats.list_entries = 0; c->stats.list_res = 0;
+    if (p.mode == DXV_MODE_REFERENCE && c->optLists) {
+        if (c->listState == 0 || (c->listState == 1 && c->listRes != list_resolution(c))) {
+            if (build_lists(c)) return 1;
+        }
+        if (c->listState == 1) {
+            p.lists = 1u;
+            p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
+            st = 8;                                                 // no stack: the smallest column
+            c->stats.list_entries = c->listEntries; c->stats.list_res = c->listRes; c->stats.list_ms = c->listMs;
+        }
+    }
     c->stats.stack_entries = (uint32_t)st;
     DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {
@@ -285,7 +379,7 @@ void dxv_destroy(dxv_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     free_scratch(c);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene); (void)hipFree(c->dGrid);
-    (void)hipFree(c->dImage); (void)hipFree(c->dEmpty);
+    (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries);
     (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dRedo); (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -334,7 +428,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false;
+    c->haveMesh = false; c->haveScene = false; c->listState = 0;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -415,7 +509,7 @@ int dxv_refit(dxv_ctx* c)
     if (!c->haveMesh || !c->haveScene || c->scratchT != c->T || !c->T)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
-    c->haveScene = false;
+    c->haveScene = false; c->listState = 0;
     if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
     fill_build_buffers(c, b);
@@ -431,7 +525,7 @@ int dxv_build(dxv_ctx* c)
     if (!c) return 1;
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
-    c->haveScene = false;
+    c->haveScene = false; c->listState = 0;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -670,7 +764,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
         h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.hasWide > 1u || h.treeHeight == 0 || h.treeHeight > 64)
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
-    c->haveScene = false;
+    c->haveScene = false; c->listState = 0;
     if (alloc_scene(c, h.numTris, h.numVerts, h.hasWide != 0)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dScene, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
@@ -717,6 +811,12 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
             if (!c->haveMesh) return fail(c, "option wide: this scene was imported without wide nodes; set the option on the exporting context before dxv_build");
             return dxv_build(c);
         }
+    } else if (!strcmp(key, "lists")) {
+        if (value != 0 && value != 1) return fail(c, "option lists: %lld not in {0,1}", (long long)value);
+        c->optLists = (int)value;
+    } else if (!strcmp(key, "listres")) {
+        if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option listres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
+        c->optListRes = (int)value;
     } else if (!strcmp(key, "skipempty")) {
         if (value != 0 && value != 1) return fail(c, "option skipempty: %lld not in {0,1}", (long long)value);
         c->optSkipEmpty = (int)value;
@@ -757,6 +857,8 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     case DXV_DBG_NODES64: if (c->haveScene && c->hdr.hasWide) { src = scene_nodes64(c); want = sizeof(Node64) * (size_t)c->hdr.numNodes; } break;
     case DXV_DBG_TRI_POS: if (c->haveScene) { src = scene_tripos(c); want = sizeof(TriPos) * T; } break;
     case DXV_DBG_TRI_NRM: if (c->haveScene) { src = scene_trinrm(c); want = sizeof(TriNrm) * T; } break;
+    case DXV_DBG_LIST_CELLS: if (c->haveScene && c->listState == 1) { src = c->dListCells; want = sizeof(DirCell) * 6 * (size_t)c->listRes * c->listRes; } break;
+    case DXV_DBG_LIST_ENTRIES: if (c->haveScene && c->listState == 1) { src = c->dListEntries; want = sizeof(DirEntry) * (size_t)c->listEntries; } break;
     default: return fail(c, "dxv_debug_download: unknown selector %d", what);
     }
     if (!src) return fail(c, "dxv_debug_download: selector %d not available", what);

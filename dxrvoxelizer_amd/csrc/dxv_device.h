@@ -9,6 +9,8 @@ namespace dxv {
 
 // radix_sort.hip
 hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, hipStream_t s);
+hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int passes, uint64_t** result,
+                                hipStream_t s);
 uint32_t radix_sort_hist_words(uint32_t n);
 
 // lbvh.hip -- device-side build of the scene blob.
@@ -37,6 +39,13 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
 uint32_t pyramid_slots(uint32_t T);
 hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight, hipStream_t s, hipEvent_t ev[2]);
 
+// dirmap.hip -- direction-space lists of the reference rule (dxv_dirmap.h)
+struct DirEntry;
+struct DirCell;
+hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirEntry* rec, uint32_t* counts, unsigned long long* total, hipStream_t s);
+hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirEntry* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
+                       uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, hipStream_t s);
+
 // traverse.hip
 struct VoxelizeParams {
     SceneView scene;
@@ -60,6 +69,7 @@ struct VoxelizeParams {
     uint32_t queued;        // 1: postponed-leaf traversal (default), 0: leaves tested on the spot
     uint32_t subbox;        // 1: launch only bricks the root early-out cannot clear (default)
     uint32_t wide;          // 1: reference rule walks the wide nodes (default when the stack bound allows)
+    uint32_t lists;         // 1: reference rule reads the direction-space lists of p.scene (no tree walk)
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack

@@ -60,6 +60,15 @@ DXV_HD void dm_ray_point(float ox, float oy, float oz, uint32_t& face, float& u,
     rho = __builtin_sqrtf((ox * ox + oy * oy) + oz * oz);
 }
 
+// next float towards +inf / -inf (finite inputs)
+DXV_HD float dm_up(float x)
+{
+    if (x == 0.0f) return 1.401298464e-45f;
+    const uint32_t b = __builtin_bit_cast(uint32_t, x);
+    return __builtin_bit_cast(float, x > 0.0f ? b + 1u : b - 1u);
+}
+DXV_HD float dm_down(float x) { return -dm_up(-x); }
+
 // Footprint of triangle tp on one face, or false when it cannot be seen through that face.
 // Builder side only (one call per triangle and face): double precision, nothing canonical here --
 // the result only has to be a superset.
@@ -149,10 +158,9 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
     out.u0 = (float)u0; out.u1 = (float)u1; out.v0 = (float)v0; out.v1 = (float)v1;
     out.r0 = (float)rmin; out.r1 = (float)rmax;
     // float conversion rounds to nearest: one more ulp outward
-    out.u0 = __builtin_nextafterf(out.u0, -__builtin_inff()); out.v0 = __builtin_nextafterf(out.v0, -__builtin_inff());
-    out.u1 = __builtin_nextafterf(out.u1, __builtin_inff()); out.v1 = __builtin_nextafterf(out.v1, __builtin_inff());
-    out.r0 = out.r0 > 0.0f ? __builtin_nextafterf(out.r0, 0.0f) : 0.0f;
-    out.r1 = __builtin_nextafterf(out.r1, __builtin_inff());
+    out.u0 = dm_down(out.u0); out.v0 = dm_down(out.v0); out.u1 = dm_up(out.u1); out.v1 = dm_up(out.v1);
+    out.r0 = out.r0 > 0.0f ? dm_down(out.r0) : 0.0f;
+    out.r1 = dm_up(out.r1);
     return true;
 }
 
@@ -179,8 +187,31 @@ DXV_HD bool dm_rect(const DirEntry& e, uint32_t R, uint32_t& i0, uint32_t& i1, u
     return true;
 }
 
+// List order: by texel, inside a texel by far radius r1 ascending (then by triangle).  Sort key:
+//   cell (cellBits = bits of 6 R R - 1) | r1 as half (16 bits; positive halfs order like integers) | triangle (the rest)
+struct DirKeyLayout { uint32_t cellBits, triBits; };
+DXV_HD DirKeyLayout dm_key_layout(uint32_t R)
+{
+    DirKeyLayout k;
+    k.cellBits = 1u;
+    while ((6ull * R * R - 1ull) >> k.cellBits) ++k.cellBits;
+    k.triBits = 64u - 16u - k.cellBits;
+    return k;
+}
+DXV_HD uint64_t dm_key(const DirKeyLayout& k, uint32_t cell, uint16_t r1, uint32_t tri)
+{
+    return ((uint64_t)cell << (64u - k.cellBits)) | ((uint64_t)r1 << k.triBits) | (uint64_t)tri;
+}
+DXV_HD uint32_t dm_key_cell(const DirKeyLayout& k, uint64_t key) { return (uint32_t)(key >> (64u - k.cellBits)); }
+DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32_t)(key & ((1ull << k.triBits) - 1ull)); }
+
 // closest hit of the reference rule through the lists
-DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, Hit& best)
+// Two steps like the postponed-leaf walks: scanning entries is short and cheap, the triangle step is
+// long, so the triangles an entry scan selects are queued in the thread's LDS column (cap entries)
+// and tested when some lane's queue is full or every lane has finished scanning -- all lanes with
+// work test together.
+template <class Stack>
+DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, const Stack& stk, int cap, Hit& best)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
     uint32_t face;
@@ -188,20 +219,43 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
     const DirCell cell = dm.cells[(face * dm.R + dm_texel(v, dm.R)) * dm.R + dm_texel(u, dm.R)];
     const float near = rho * 0.999f;
-    for (uint32_t i = cell.begin; i < cell.end; ++i) {
-        const DirEntry e = dm.entries[i];
-        if (u < half_bits_to_float(e.u0) || u > half_bits_to_float(e.u1)) continue;
-        if (v < half_bits_to_float(e.v0) || v > half_bits_to_float(e.v1)) continue;
-        if (half_bits_to_float(e.r1) < near) continue;                                   // wholly nearer the centre than the ray's start: t < 0
-        if (half_bits_to_float(e.r0) > (rho + best.t) * 1.001f + 1e-4f) continue;        // wholly beyond the closest hit so far
-        leaf_reference(r, tris, (int32_t)e.tri, best);
+    // entries wholly nearer the centre than the ray's start (r1 < near: t < 0) come first: skip them
+    uint32_t i = cell.begin, hi = cell.end;
+    while (hi - i > 8u) {
+        const uint32_t mid = i + ((hi - i) >> 1);
+        if (half_bits_to_float(dm.entries[mid].r1) < near) i = mid + 1u; else hi = mid;
+    }
+    int qn = 0;
+    auto consider = [&](const DirEntry& e) {
+        if (!(half_bits_to_float(e.r1) < near) &&
+            !(u < half_bits_to_float(e.u0) || u > half_bits_to_float(e.u1)) &&
+            !(v < half_bits_to_float(e.v0) || v > half_bits_to_float(e.v1)) &&
+            !(half_bits_to_float(e.r0) > (rho + best.t) * 1.001f + 1e-4f))          // wholly beyond the closest hit so far
+            stk.put(qn++, (int32_t)e.tri);
+    };
+    for (;;) {
+        // two entries per round: both loads are in flight before either is looked at
+        if (i < cell.end) {
+            const bool two = i + 1u < cell.end;
+            const DirEntry e0 = dm.entries[i], e1 = dm.entries[two ? i + 1u : i];
+            consider(e0);
+            if (two) consider(e1);
+            i += 2u;
+        }
+        const bool scanning = wave_any(i < cell.end);
+        if (scanning && !wave_any(qn + 2 > cap)) continue;
+        for (int k = 0; wave_any(k < qn); ++k)
+            if (k < qn) leaf_reference(r, tris, stk.get(k), best);
+        qn = 0;
+        if (!scanning) break;
     }
 }
 
-DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, Hit& best)
+template <class Stack>
+DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best)
 {
     const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
-    trace_reference_dm(r, dm, sc.triPos, best);
+    trace_reference_dm(r, dm, sc.triPos, stk, cap, best);
 }
 
 } // namespace dxv

@@ -575,7 +575,8 @@ struct SceneView {
     uint32_t dmR;
 };
 
-DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, Hit& best);      // dxv_dirmap.h
+template <class Stack>
+DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best);      // dxv_dirmap.h
 
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
@@ -591,7 +592,7 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
     finish_ray_reference(r);
     Hit best;
-    if (WALK == 4) trace_reference_lists(r, sc, best);                           // no tree, no stack: cannot overflow
+    if (WALK == 4) trace_reference_lists(r, sc, stk, cap, best);                           // no tree, no stack: cannot overflow
     const bool ok = WALK == 4 ? true
                   : WALK == 3 ? trace_reference_h(r, sc.nodes, sc.wide, sc.triPos, stk, cap, best)
                   : WALK == 2 ? trace_reference_w(r, sc.wide, sc.triPos, stk, cap, best)

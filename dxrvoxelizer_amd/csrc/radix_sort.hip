@@ -125,13 +125,15 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* _
 
 // keys -> sorted keys; tmp is a same-size ping-pong buffer; hist holds 256 * numTiles words.
 // After the 4 passes the result is back in `keys`.
-hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, hipStream_t s)
+// Stable sort by key bits [loBit, loBit + 8 * passes); *result = keys or tmp, whichever holds the sorted keys.
+hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int passes, uint64_t** result,
+                                hipStream_t s)
 {
     const uint32_t numTiles = (n + kSortTile - 1) / kSortTile;
     uint64_t* src = keys;
     uint64_t* dst = tmp;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 32 + 8 * pass;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = loBit + 8 * pass;
         uint32_t* totals = hist + 256u * (size_t)numTiles;      // 256 row totals + 256 digit bases behind the histogram
         uint32_t* digitBase = totals + 256;
         k_sort_hist<<<numTiles, kSortThreads, 0, s>>>(src, n, shift, hist, numTiles);
@@ -140,7 +142,14 @@ hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* 
         k_sort_scatter<<<numTiles, kSortThreads, 0, s>>>(src, dst, n, shift, hist, digitBase, numTiles);
         uint64_t* t = src; src = dst; dst = t;
     }
+    if (result) *result = src;
     return hipGetLastError();
+}
+
+// the build's sort: the Morton half, bits [32, 64); the result is in `keys`
+hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, hipStream_t s)
+{
+    return radix_sort_keys_bits(keys, tmp, n, hist, 32, 4, nullptr, s);
 }
 
 uint32_t radix_sort_hist_words(uint32_t n) { return 256u * ((n + kSortTile - 1) / kSortTile) + 512u; }

@@ -14,6 +14,7 @@
 // Parity mode normally runs k_parity_rows (one wave-uniform walk per block of grid rows, below).
 #include "dxv_device.h"
 #include "dxv_trace.h"
+#include "dxv_dirmap.h"
 
 namespace dxv {
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ uint32_t compact1by2(uint32_t x)
 
 // WALK: 0 = leaves tested as met, 1 = postponed-leaf walk, 2 = the same over the wide nodes (MODE 0)
 template <class B, int STACK, int MODE, bool TEXELS, int WALK>
-__global__ __launch_bounds__(B::threads, 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs
+__global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs (lists: 6, no LDS to speak of)
 {
     __shared__ int32_t stack[STACK * B::threads];
     const uint32_t N = p.N;
@@ -449,7 +450,13 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
     const uint64_t grid = (nb + span - 1) / span * span;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 g((uint32_t)grid), b(B::threads);
-    if (p.mode == 0) {
+    if (p.mode == 0 && p.lists) {
+        // direction-space lists: no stack (the caller passes the smallest column)
+        if constexpr (STACK == 8) {
+            if (p.texels) k_voxelize<B, 8, 0, true, 4><<<g, b, 0, s>>>(p);
+            else k_voxelize<B, 8, 0, false, 4><<<g, b, 0, s>>>(p);
+        } else return hipErrorInvalidValue;
+    } else if (p.mode == 0) {
         if (p.texels) {
             if (p.wide) k_voxelize<B, STACK, 0, true, 2><<<g, b, 0, s>>>(p);
             else k_voxelize<B, STACK, 0, true, 1><<<g, b, 0, s>>>(p);

@@ -9,7 +9,7 @@ import numpy as np
 from ._lib import DxvError, Stats, load_library
 
 MODE_REFERENCE, MODE_PARITY = 0, 1
-DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64 = range(7)
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64, DBG_LIST_CELLS, DBG_LIST_ENTRIES = range(9)
 
 
 def obj_load(path):
@@ -177,7 +177,8 @@ class Voxelizer:
         shapes = {DBG_SORTED_KEYS: ((T,), np.uint64), DBG_NODES: ((st["num_nodes"], 16), np.uint32),
                   DBG_TRI_POS: ((T, 12), np.float32), DBG_TRI_NRM: ((T, 12), np.float32),
                   DBG_PARENTS: ((2 * T - 1,), np.uint32), DBG_NODES32: ((st["num_nodes"], 8), np.uint32),
-                  DBG_NODES64: ((st["num_nodes"], 16), np.uint32)}
+                  DBG_NODES64: ((st["num_nodes"], 16), np.uint32),
+                  DBG_LIST_CELLS: ((6 * st["list_res"] ** 2, 2), np.uint32), DBG_LIST_ENTRIES: ((st["list_entries"], 4), np.uint32)}
         shape, dt = shapes[what]
         out = np.empty(shape, dt)
         self._check(self._lib.dxv_debug_download(self._ctx, what, out.ctypes.data_as(C.c_void_p), out.nbytes))

@@ -41,7 +41,9 @@ enum {
     DXV_DBG_TRI_NRM = 3,     /* T x 48 B: 3 x {nx,ny,nz,0}                                    */
     DXV_DBG_PARENTS = 4,     /* (T-1) internal + T leaf parent words: (parent << 1) | side    */
     DXV_DBG_NODES32 = 5,     /* max(T-1,1) x 32 B traversal nodes (half-float boxes)          */
-    DXV_DBG_NODES64 = 6      /* max(T-1,1) x 64 B wide traversal nodes (up to 4 boxes each)   */
+    DXV_DBG_NODES64 = 6,     /* max(T-1,1) x 64 B wide traversal nodes (up to 4 boxes each)   */
+    DXV_DBG_LIST_CELLS = 7,  /* 6 R R x 8 B: [begin, end) of every texel's list (option lists)  */
+    DXV_DBG_LIST_ENTRIES = 8 /* stats.list_entries x 16 B entries of the direction-space lists  */
 };
 
 typedef struct dxv_stats {
@@ -56,7 +58,9 @@ typedef struct dxv_stats {
     uint32_t redo_rays;      /* rays of the last launch finished by the deep-stack redo pass       */
     uint32_t row_block;      /* parity rule: rows per side of a wave's block of rows (1, 2 or 4)   */
     float tri_extent;        /* mean triangle box extent along y/z, normalised units               */
-    uint32_t reserved[3];
+    uint32_t list_entries;   /* reference rule: entries of the direction-space lists in use, 0 = tree walk */
+    uint32_t list_res;       /* ... texels per cube-map face side                                   */
+    float list_ms;           /* ... time of their build (first launch after a build / refit / import) */
 } dxv_stats;
 
 /* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that
@@ -175,6 +179,10 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   rowblock 0|1|2|4  ... per row (1), per 2 x 2 or 4 x 4 rows; 0 (default) decides by triangle size
  *   refit  0|1|2  box merge of dxv_build and dxv_refit: min/max pyramid over the leaf order (1,
  *                 default), level sweeps (2), one atomic pass (0)
+ *   lists  0|1    reference rule through direction-space lists (1, default; dxv_dirmap.h) or the tree walk (0);
+ *                 the lists are built on the first launch after a build / refit / import; scenes whose
+ *                 lists would exceed 256 entries per triangle + 64 M keep the tree walk
+ *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);

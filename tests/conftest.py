@@ -96,7 +96,7 @@ def hostcheck():
     """The product's __host__ __device__ code compiled for the CPU (tests/hostcheck)."""
     src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
     so = os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so")
-    deps = [src] + [os.path.join(ROOT, "dxrvoxelizer_amd", "csrc", h) for h in ("dxv_math.h", "dxv_trace.h", "dxv_types.h")]
+    deps = [src] + [os.path.join(ROOT, "dxrvoxelizer_amd", "csrc", h) for h in ("dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_dirmap.h", "dxv_raycast.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                                "-mavx2", "-mfma", "-Wno-unknown-pragmas", "-o", so, src])
@@ -113,6 +113,9 @@ def hostcheck():
     L.hc_scene_keys.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_scene_nodes32.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_scene_nodes64.argtypes = [C.c_void_p, C.c_void_p]
+    L.hc_dirmap_build.argtypes = [C.c_void_p, C.c_uint32]
+    L.hc_dirmap_build.restype = C.c_uint64
+    L.hc_dirmap_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hc_half_down.argtypes = [C.c_float]
     L.hc_half_down.restype = C.c_uint32
     L.hc_half_up.argtypes = [C.c_float]
@@ -141,6 +144,14 @@ def hostcheck():
             out = np.empty((max(self.T - 1, 1), 16), np.uint32)
             L.hc_scene_nodes(self.h, out.ctypes.data_as(C.c_void_p))
             return out
+
+        def lists(self, R):
+            """direction-space lists built on the host with the product's footprint code: (cells, entries)"""
+            n = L.hc_dirmap_build(self.h, R)
+            cells = np.empty((6 * R * R, 2), np.uint32)
+            entries = np.empty((n, 4), np.uint32)
+            L.hc_dirmap_get(self.h, cells.ctypes.data_as(C.c_void_p), entries.ctypes.data_as(C.c_void_p))
+            return cells, entries
 
         def nodes32(self):
             out = np.empty((max(self.T - 1, 1), 8), np.uint32)

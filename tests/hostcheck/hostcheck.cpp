@@ -123,22 +123,23 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
     HcScene* s = static_cast<HcScene*>(p);
     std::vector<uint64_t> keys;
     std::vector<DirEntry> rec((size_t)s->T * 6);
+    const DirKeyLayout lay = dm_key_layout(R);
     for (uint32_t t = 0; t < s->T; ++t)
         for (uint32_t f = 0; f < 6; ++f) {
             const DirEntry e = rec[(size_t)t * 6 + f] = dm_entry(s->triPos[t], f, t);
             uint32_t i0, i1, j0, j1;
             if (!dm_rect(e, R, i0, i1, j0, j1)) continue;
             for (uint32_t j = j0; j <= j1; ++j)
-                for (uint32_t i = i0; i <= i1; ++i) keys.push_back(((uint64_t)((f * R + j) * R + i) << 32) | t);
+                for (uint32_t i = i0; i <= i1; ++i) keys.push_back(dm_key(lay, (f * R + j) * R + i, e.r1, t));
         }
     std::sort(keys.begin(), keys.end());
     s->dmR = R;
     s->dmCells.assign((size_t)6 * R * R, DirCell{0, 0});
     s->dmEntries.resize(keys.size());
     for (size_t i = 0; i < keys.size(); ++i) {
-        const uint32_t cell = (uint32_t)(keys[i] >> 32), t = (uint32_t)keys[i];
+        const uint32_t cell = dm_key_cell(lay, keys[i]), t = dm_key_tri(lay, keys[i]);
         s->dmEntries[i] = rec[(size_t)t * 6 + cell / (R * R)];
-        if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != cell) s->dmCells[cell].begin = (uint32_t)i;
+        if (i == 0 || dm_key_cell(lay, keys[i - 1]) != cell) s->dmCells[cell].begin = (uint32_t)i;
         s->dmCells[cell].end = (uint32_t)i + 1;
     }
     return keys.size();

@@ -15,7 +15,7 @@ from dxrvoxelizer_amd.slabs import gather_slabs, slab_range
 
 pytestmark = pytest.mark.gpu
 
-DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64 = range(7)
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64, DBG_LIST_CELLS, DBG_LIST_ENTRIES = range(9)
 
 
 @pytest.fixture(scope="module")
@@ -614,3 +614,70 @@ def test_pyramid_refit_equals_sweep_refit_word_for_word(dxv, bunny):
             v.close()
         for other in words[1:]:
             assert np.array_equal(words[0][0], other[0]) and np.array_equal(words[0][1], other[1]) and words[0][2] == other[2], len(ib) // 3
+
+
+# ---------------------------------------------------------------------------------------------
+# direction-space lists (option lists): the reference rule without a tree walk
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
+def test_lists_equal_tree_walk_and_host_lists(dxv, orc, hostcheck, request, name):
+    """Every grid through the lists equals the tree walk's (and the oracle's); the device-built lists
+    equal, word for word, the lists the same footprint code builds on the host."""
+    vb, ib, _ = request.getfixturevalue(name)
+    v = dxv.Voxelizer(0)
+    v.InitFromArrays(vb, ib)
+    s = orc.Scene(vb, ib)
+    for N, R in ((64, 256), (50, 64), (128, 1024)):
+        v.set_option("lists", 0)
+        v.Voxelize(N)
+        want = v.Grid().copy()
+        assert v.stats()["list_entries"] == 0
+        v.set_option("listres", R)
+        v.set_option("lists", 1)
+        v.Voxelize(N)
+        st = v.stats()
+        assert st["list_entries"] > 0 and st["list_res"] == R and st["redo_rays"] == 0
+        assert np.array_equal(v.Grid(), want), (name, N, R)
+        if N == 64:
+            assert np.array_equal(want, s.voxelize(64, algo=orc.ALGO_BVH))
+            cells, entries = hostcheck(vb, ib, s.bound).lists(R)
+            assert np.array_equal(v.debug(DBG_LIST_CELLS), cells)
+            assert np.array_equal(v.debug(DBG_LIST_ENTRIES), entries)
+        v.Voxelize(N, 0, N // 4, N // 2)                              # a slab through the lists
+        assert np.array_equal(v.Grid(), want[N // 4:N // 4 + N // 2])
+    v.EnableTexels(True)
+    v.Voxelize(64)
+    tl = v.Texels().copy()
+    v.set_option("lists", 0)
+    v.Voxelize(64)
+    assert np.array_equal(v.Texels(), tl)                             # the normal-carrying texel too
+    v.close()
+
+
+def test_lists_follow_the_scene_and_fall_back_over_the_cap(dxv, orc, bunny):
+    vb, ib, _ = bunny
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 1)
+    v.InitFromArrays(vb, ib)
+    v.Voxelize(64)
+    a = v.Grid().copy()
+    moved = np.array(vb, np.float32, copy=True)
+    moved[:, 0] *= 0.5                                                # squash the mesh: refit -> the lists are rebuilt
+    v.UpdateVertices(moved)
+    v.Voxelize(64)
+    b = v.Grid().copy()
+    assert v.stats()["list_entries"] > 0
+    v.set_option("lists", 0)                                          # the refitted tree gives the same grid
+    v.Voxelize(64)
+    assert np.array_equal(b, v.Grid()) and not np.array_equal(a, b)
+    v.set_option("lists", 1)
+    # triangles through the grid centre cover whole cube faces: over the cap the tree walk is used
+    rng = np.random.default_rng(3)
+    T = 400
+    pos = rng.uniform(-1, 1, (3 * T, 3)).astype(np.float32)
+    big = np.hstack([pos, np.tile(np.array([[0, 0, 1]], np.float32), (3 * T, 1))])
+    v.InitFromArrays(big, np.arange(3 * T, dtype=np.uint32))
+    v.Voxelize(32)
+    assert v.stats()["list_entries"] == 0
+    assert np.array_equal(v.Grid(), orc.Scene(big, np.arange(3 * T, dtype=np.uint32)).voxelize(32, algo=orc.ALGO_BRUTE))
+    v.close()
