@@ -65,6 +65,13 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
             v.InitFromArrays(vb, ib)
             for mode in (0, 1):
                 want = s.voxelize(N, mode=mode, algo=orc.ALGO_BRUTE)
+                if mode == 0:                             # the direction-space lists (default), a coarse and a fine map
+                    for res in (0, 16, 512):
+                        v.set_option("listres", res)
+                        v.Voxelize(N, mode)
+                        assert np.array_equal(v.Grid(), want), (seed, N, "lists", res)
+                    v.set_option("listres", 0)
+                v.set_option("lists", 0)                  # ... and every tree walk
                 for rows, queue, wide in (((1, 1, 1), (1, 1, 2), (1, 1, 0), (1, 0, 0)) if mode == 0 else ((1, 1, 1), (0, 1, 1), (0, 0, 1))):
                     v.set_option("rows", rows)
                     v.set_option("queue", queue)
@@ -74,6 +81,7 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
                         v.Voxelize(N, mode)
                         assert np.array_equal(v.Grid(), want), (seed, N, mode, rows, queue, wide, rowblock)
                     v.set_option("rowblock", 0)
+                v.set_option("lists", 1)
             v.set_option("rows", 1)
             v.set_option("queue", 1)
             v.set_option("wide", 2)

@@ -188,8 +188,10 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
             vox.set_option("region", region)
             vox.set_option("queue", queue)
             vox.set_option("subbox", subbox)
-            vox.Voxelize(64)
-            assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region, queue, subbox)
+            for lists in (0, 1):                                      # the tree walks, and the direction-space lists
+                vox.set_option("lists", lists)
+                vox.Voxelize(64)
+                assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region, queue, subbox, lists)
     vox.set_option("subbox", 1)
     vox.set_option("morton", 1)
     vox.set_option("region", 6)
@@ -369,6 +371,7 @@ def test_errors_are_loud(dxv, bunny):
     tri[:3, 3:] = [0.57735, 0.57735, 0.57735]
     tri[3, :3], tri[4, :3] = [-1, -1, -1], [1, 1, 1]
     deep = np.tile(np.arange(3, dtype=np.uint32), 140000)
+    v.set_option("lists", 0)                              # this test is about the tree walks' columns
     v.InitFromArrays(tri, deep)
     assert v.stats()["tree_height"] >= 17
     v.Voxelize(16)
@@ -528,6 +531,7 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
     and at 64^3 the oracle's grid."""
     vb, ib, _ = request.getfixturevalue(name)
     vox.set_option("wide", 0)
+    vox.set_option("lists", 0)
     vox.InitFromArrays(vb, ib)
     vox.EnableTexels(True)
     vox.Voxelize(n)
@@ -548,6 +552,7 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
     finally:
         vox.set_option("stack", 0)
         vox.set_option("wide", 2)
+        vox.set_option("lists", 1)
         vox.EnableTexels(False)
     assert np.array_equal(g0, g1) and np.array_equal(t0, t1) and np.array_equal(g0, g2)
     assert redo > 0
@@ -676,6 +681,7 @@ def test_lists_follow_the_scene_and_fall_back_over_the_cap(dxv, orc, bunny):
     T = 400
     pos = rng.uniform(-1, 1, (3 * T, 3)).astype(np.float32)
     big = np.hstack([pos, np.tile(np.array([[0, 0, 1]], np.float32), (3 * T, 1))])
+    v.set_option("listres", 4096)
     v.InitFromArrays(big, np.arange(3 * T, dtype=np.uint32))
     v.Voxelize(32)
     assert v.stats()["list_entries"] == 0

@@ -195,3 +195,31 @@ def test_queued_walk_every_capacity_is_exact_or_reports_overflow(orc, hostcheck,
                 bad = g != want[mode % 2]
                 assert bad.mean() < 0.2, (cap, mode)
     assert clean >= 15
+
+
+def test_direction_space_lists_give_the_tree_walk_grid(orc, hostcheck, bunny):
+    """The reference rule through the direction-space lists (dxv_dirmap.h: footprints, list order, the
+    two-step scan with a small queue) equals the tree walk and the oracle's brute force -- on the
+    bunny, on lattice-snapped adversarial triangles (shared edges and vertices, degenerate and
+    coplanar duplicates, triangles through the grid centre) and for coarse and fine maps."""
+    from test_fuzz import lattice_mesh
+    vb, ib, _ = bunny
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    want, _ = h.voxelize(64, mode=0)
+    for R in (32, 256):
+        cells, entries = h.lists(R)
+        assert (cells[:, 1] >= cells[:, 0]).all() and int(cells[:, 1].max()) == len(entries)
+        got, ovf = h.voxelize(64, mode=12, stack=4)                   # a queue of four entries: several flushes per ray
+        assert ovf == 0 and np.array_equal(got, want), R
+    rng = np.random.default_rng(99)
+    for n_tris in (1, 2, 3, 7, 30, 200):
+        for N in (8, 16, 32):
+            vb, ib = lattice_mesh(rng, n_tris, N)
+            s = orc.Scene(vb, ib)
+            h = hostcheck(vb, ib, s.bound)
+            want = s.voxelize(N, algo=orc.ALGO_BRUTE)
+            for R in (16, 128):
+                h.lists(R)
+                got, ovf = h.voxelize(N, mode=12, stack=8)
+                assert ovf == 0 and np.array_equal(got, want), (n_tris, N, R)
