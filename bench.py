@@ -211,6 +211,7 @@ def main():
         kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)   # avg launch duration on the kernel's stream
     else:                                        # overlapping launches: the library's own events around each context's last launch
         kernel_ms = float(np.mean([v.stats()["voxelize_ms"] for v in voxes]))
+    st_run = vox.stats()                         # of the timed rule (the other rule below overwrites the launch fields)
     solid = vox.CountSolid() if nz else 0
     other_ms = None
     if world == 1:                               # the second occupancy rule on the same scene, for the record
@@ -256,7 +257,10 @@ def main():
                                                            if interleave else f"Z-slab partition over {world} GPU(s)"),
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
                        "slab_slices_rank0": nz, "frames_in_flight": frames, "solid_voxels": int(tot.item()),
-                       "tree_height": st["tree_height"], "stack_entries": st["stack_entries"],
+                       "tree_height": st["tree_height"], "stack_entries": st_run["stack_entries"],
+                       "candidates": ({"structure": "direction-space lists", "texels_per_face_side": st_run["list_res"],
+                                       "entries": st_run["list_entries"], "build_ms": st_run["list_ms"]}
+                                      if st_run.get("list_entries") else {"structure": "LBVH walk"}),
                        "build_ms": st0["build_ms"], "build_stages_ms": {k: st0[k] for k in
                                                                        ("prep_ms", "sort_ms", "hierarchy_ms", "refit_ms")},
                        "upload_ms": st0["upload_ms"], "scene_broadcast_ms": bcast_ms,
@@ -268,9 +272,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "compulsory HBM bytes are tiny: the measured limiters are VALU issue and the vector-L1 line "
-                                 "accesses of divergent node fetches, about 60 % busy each (profiles/r01/final/pmc_summary.json, "
-                                 "DESIGN.md section 4)"},
+                         "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); the kernel "
+                                 "is latency- and issue-bound, not bandwidth-bound: compulsory HBM bytes are ~1 % of what 8 TB/s "
+                                 "moves in its run time (profiles/r01/final/pmc_summary.json, DESIGN.md section 4)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode)

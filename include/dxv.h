@@ -181,7 +181,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 default), level sweeps (2), one atomic pass (0)
  *   lists  0|1    reference rule through direction-space lists (1, default; dxv_dirmap.h) or the tree walk (0);
  *                 the lists are built on the first launch after a build / refit / import; scenes whose
- *                 lists would exceed 256 entries per triangle + 64 M keep the tree walk
+ *                 lists would average more than 32 entries per texel, or exceed 256 entries per
+ *                 triangle + 64 M, keep the tree walk (stats.list_entries = 0)
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
