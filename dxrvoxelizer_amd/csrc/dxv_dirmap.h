@@ -234,16 +234,20 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             stk.put(qn++, (int32_t)e.tri);
     };
     for (;;) {
-        // two entries per round: both loads are in flight before either is looked at
+        // four entries per round, all four loads in flight before the first is looked at (two per round:
+        // +13 % on the 1 M-triangle scene, one: +40 %)
         if (i < cell.end) {
-            const bool two = i + 1u < cell.end;
-            const DirEntry e0 = dm.entries[i], e1 = dm.entries[two ? i + 1u : i];
+            const uint32_t last = cell.end - 1u;
+            const DirEntry e0 = dm.entries[i], e1 = dm.entries[i + 1u < last ? i + 1u : last];
+            const DirEntry e2 = dm.entries[i + 2u < last ? i + 2u : last], e3 = dm.entries[i + 3u < last ? i + 3u : last];
             consider(e0);
-            if (two) consider(e1);
-            i += 2u;
+            if (i + 1u <= last) consider(e1);
+            if (i + 2u <= last) consider(e2);
+            if (i + 3u <= last) consider(e3);
+            i += 4u;
         }
         const bool scanning = wave_any(i < cell.end);
-        if (scanning && !wave_any(qn + 2 > cap)) continue;
+        if (scanning && !wave_any(qn + 4 > cap)) continue;
         for (int k = 0; wave_any(k < qn); ++k)
             if (k < qn) leaf_reference(r, tris, stk.get(k), best);
         qn = 0;
