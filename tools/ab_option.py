@@ -1,5 +1,5 @@
 """A/B one option of libdxv.so inside one process: interleaved rounds of both settings.
-usage: ab_option.py OPTION V0,V1 [--meshes torus1m,bunny] [--grid 512] [--mode reference] [--reps 9]"""
+usage: ab_option.py OPTION V0,V1 [--meshes torus1m,bunny] [--grid 512] [--mode reference] [--reps 9] [--set lists=0]"""
 import argparse
 import json
 import os
@@ -21,10 +21,13 @@ def main():
     ap.add_argument("--mode", default="reference")
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--set", default="", help="other options held fixed, e.g. lists=0,brick=4")
     a = ap.parse_args()
     values = [int(v) for v in a.values.split(",")]
     mode = dxv.MODE_REFERENCE if a.mode == "reference" else dxv.MODE_PARITY
     v = dxv.Voxelizer(0)
+    for kv in filter(None, a.set.split(",")):
+        v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for mesh in a.meshes.split(","):
         vb, ib, _ = make_mesh(mesh)
         v.InitFromArrays(vb, ib)

@@ -76,10 +76,10 @@ def main():
             "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/r01/final/pmc_fetch.csv, "
                       "pmc_write.csv), mean per k_voxelize launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
                       "128-B requests as 64 B): calibrated in the same pass on k_count, a 16-B/lane streaming read of exactly "
-                      f"134,217,728 B, which reports {kc.get('FETCH_SIZE', float('nan')):.0f} KB = 1/2. The node gathers of k_voxelize are "
+                      f"134,217,728 B, which reports {kc.get('FETCH_SIZE', float('nan')):.0f} KB = 1/2. The gathers of k_voxelize are "
                       "not a streaming pattern, so the doubled figure is an upper estimate; uncorrected total = "
                       f"{int((fetch_kb + write_kb) * 1024)} B",
-            "kernel": "k_voxelize<Brick<4,4,4>,20,0,false,1>", "round": 1}
+            "kernel": "k_voxelize<Brick<4,4,4>,8,0,false,4> (direction-space lists; the tree walk's figures: profiles/r01/final/tree_walk/)", "round": 1}
         with open(tj, "w") as fh:
             json.dump(traffic, fh, indent=1)
     print(json.dumps({k: {n: round(v, 1) for n, v in c.items()} for k, c in out["kernels"].items()}, indent=1)[:3000])

@@ -30,9 +30,14 @@ for mesh, N in (("bunny", 64), ("dragon", 512), ("torus1m", 512)):
     print(json.dumps({"mesh": mesh, "N": N, "render_ms_1280x720": float(np.median(ts[1:])), "opaque_px": int((img[..., 3] == 255).sum())}))
 PY
 python tools/pcie_bench.py 512 > $OUT/pcie.jsonl 2>&1
-python tools/ab_option.py wide 0,2 --meshes torus1m,bunny,dragon,dragon9,bunny16 --grid 512 > $OUT/ab_wide.jsonl 2>&1
-python tools/ab_option.py wide 0,2 --meshes torus1m,bunny,dragon --grid 256 >> $OUT/ab_wide.jsonl 2>&1
-python tools/ab_option.py stack0 12,16,20,24 --rounds 2 > $OUT/ab_stack0.jsonl 2>&1
+python tools/ab_option.py wide 0,2 --set lists=0 --meshes torus1m,bunny,dragon,dragon9,bunny16 --grid 512 > $OUT/ab_wide.jsonl 2>&1
+python tools/ab_option.py wide 0,2 --set lists=0 --meshes torus1m,bunny,dragon --grid 256 >> $OUT/ab_wide.jsonl 2>&1
+python tools/ab_option.py stack0 12,16,20,24 --set lists=0 --rounds 2 > $OUT/ab_stack0.jsonl 2>&1
+python tools/ab_lists.py > $OUT/ab_lists.jsonl 2>&1
+python tools/ab_lists.py --grid 256 --meshes torus1m,bunny,dragon >> $OUT/ab_lists.jsonl 2>&1
+python tools/ab_lists.py --grid 1024 --meshes dragon9,bunny --reps 3 >> $OUT/ab_lists.jsonl 2>&1
+python tools/ab_lists.py --grid 64 --meshes bunny,dragon >> $OUT/ab_lists.jsonl 2>&1
+python tools/ab_lists.py --meshes soup10m --reps 3 >> $OUT/ab_lists.jsonl 2>&1
 python tools/rowblock_table.py > $OUT/rowblock.jsonl 2>&1
 python tools/small_grid_latency.py > $OUT/small_grid_latency.jsonl 2>&1
 python tools/texel_time.py > $OUT/texel_time.jsonl 2>&1
