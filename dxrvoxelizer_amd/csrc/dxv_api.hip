@@ -333,9 +333,12 @@ int launch_now(dxv_ctx* c)
         c->lastRedoParity = -1;
     } else {
         DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
-        DXV_HIP(c, launch_voxelize_redo(p, c->stream));
-        c->lastRedoParity = (int)c->redoParity;
-        c->redoParity ^= 1u;
+        if (p.lists) c->lastRedoParity = -1;                        // no column to run out of, nothing to redo
+        else {
+            DXV_HIP(c, launch_voxelize_redo(p, c->stream));
+            c->lastRedoParity = (int)c->redoParity;
+            c->redoParity ^= 1u;
+        }
     }
     DXV_HIP(c, hipEventRecord(c->ev[6], c->stream));
     c->pending = true;

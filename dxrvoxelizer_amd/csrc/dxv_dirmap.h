@@ -12,11 +12,14 @@
 //
 // Identical results need only one property: every triangle that leaf_reference would accept for a
 // ray is listed in that ray's texel with a footprint containing the ray and a radial range that
-// passes.  A triangle accepted by the watertight test is within a few ulps (positions lie in
-// [-1, 1]: ~1e-7) of the geometric ray, so footprints are those of the triangle dilated by
-// kDmDelta = 2^-16 (200 x that), clipped against face frusta widened by 2^-10, and then rounded
-// outward to halfs; triangles closer than 64 kDmDelta to the centre along the face axis take the
-// whole face.  tests/ (fuzz against the oracle, lattice-snapped adversarial meshes) and the GPU
+// passes.  leaf_reference accepts a triangle when the ray passes the slab test of its box padded by
+// 2^-16 AND the fp32 watertight test: the edge functions of a triangle that is not degenerate only
+// agree in sign within ~1e-6 of it (inputs are differences of coordinates in [-1, 1], rounding
+// ~1e-7), and for a degenerate sliver, whose edge functions all vanish along its line, the padded
+// box keeps the ray within sqrt(3) 2^-16 = 2.64e-5 of it.  Footprints are those of the triangle
+// dilated by kDmDelta = 2^-15 = 3.05e-5, clipped against face frusta widened by 2^-10, and then
+// rounded outward to halfs; triangles closer than 64 kDmDelta to the centre along the face axis
+// take the whole face.  tests/ (fuzz against the oracle, lattice-snapped adversarial meshes) and the GPU
 // soak check the claim the same way they check the padded leaf boxes.
 #pragma once
 #include "dxv_trace.h"
@@ -38,7 +41,7 @@ struct DirMapView {
     uint32_t R;                // texels per face side, a power of two
 };
 
-constexpr float kDmDelta = 1.52587890625e-5f;       // 2^-16: dilation of the triangles
+constexpr float kDmDelta = 3.0517578125e-5f;        // 2^-15: dilation of the triangles
 constexpr double kDmFrustum = 1.0 + 1.0 / 1024.0;   // face frusta are widened by this factor
 
 // texel index of face coordinate u (monotone in u: add, multiply by a power of two, floor)
@@ -85,6 +88,14 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
     const double delta = (double)kDmDelta;
     // the four side planes of the widened frustum, pushed out by the dilation: kF * d +- b + 2 delta >= 0
     const double planes[4][2] = {{1.0, 0.0}, {-1.0, 0.0}, {0.0, 1.0}, {0.0, -1.0}};
+    // most (triangle, face) pairs end here: all three vertices outside one side plane (what the clip
+    // below would find, without its arrays)
+    for (int pl = 0; pl < 4; ++pl) {
+        bool anyIn = false;
+        for (int i = 0; i < 3; ++i)
+            anyIn = anyIn || kDmFrustum * poly[0][i][2] + planes[pl][0] * poly[0][i][0] + planes[pl][1] * poly[0][i][1] + 2.0 * delta >= 0.0;
+        if (!anyIn) return false;
+    }
     for (int pl = 0; pl < 4 && n > 0; ++pl) {
         const double nb = planes[pl][0], nc = planes[pl][1];
         int m = 0;
@@ -124,8 +135,9 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
             if (v < v0) v0 = v;
             if (v > v1) v1 = v;
         }
-        // a point moved by delta sideways and in depth at depth >= dmin: du <= (1 + |u|) delta / (dmin - delta)
-        const double pad = 4.0 * delta / dmin + 1e-6;
+        // a point moved by delta sideways and in depth at depth >= dmin >= 64 delta, |u| <= 1.006:
+        // du <= (1 + |u|) delta / (dmin - delta) <= 2.04 delta / dmin
+        const double pad = 2.25 * delta / dmin + 1e-6;
         u0 -= pad; u1 += pad; v0 -= pad; v1 += pad;
         if (u0 < -full) u0 = -full;
         if (v0 < -full) v0 = -full;
