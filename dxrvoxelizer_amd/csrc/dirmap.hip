@@ -127,8 +127,9 @@ __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restric
     const uint64_t key = keys[i];
     const uint32_t cell = dm_key_cell(lay, key), tri = dm_key_tri(lay, key);
     if (i == 0u || dm_key_cell(lay, keys[i - 1u]) != cell) cells[cell].begin = i;
-    if (i + 1u == n || dm_key_cell(lay, keys[i + 1u]) != cell) cells[cell].end = i + 1u;
-    entries[i] = rec[(size_t)tri * 6u + cell / (R * R)];
+    const DirEntry e = rec[(size_t)tri * 6u + cell / (R * R)];
+    if (i + 1u == n || dm_key_cell(lay, keys[i + 1u]) != cell) { cells[cell].end = i + 1u; cells[cell].r1max = e.r1; }
+    entries[i] = e;
 }
 } // namespace
 

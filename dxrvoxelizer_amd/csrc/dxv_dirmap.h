@@ -33,7 +33,11 @@ struct alignas(16) DirEntry {
 };
 static_assert(sizeof(DirEntry) == 16, "one 16-byte load per entry");
 
-struct DirCell { uint32_t begin, end; };            // entries [begin, end) of a texel
+struct alignas(16) DirCell {                        // one 16-byte load per ray
+    uint32_t begin, end;                            // entries [begin, end) of a texel
+    uint32_t r1max;                                 // far radius of its last entry (half bits): a ray that starts beyond it has no candidate
+    uint32_t pad;
+};
 
 struct DirMapView {
     const DirCell* cells;      // 6 * R * R, cell = (face * R + j) * R + i; NULL: no map
@@ -231,8 +235,10 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
     const DirCell cell = dm.cells[(face * dm.R + dm_texel(v, dm.R)) * dm.R + dm_texel(u, dm.R)];
     const float near = rho * 0.999f;
-    // entries wholly nearer the centre than the ray's start (r1 < near: t < 0) come first: skip them
+    // entries wholly nearer the centre than the ray's start (r1 < near: t < 0) come first: skip them --
+    // all of them at once for a ray that starts beyond the texel's last triangle
     uint32_t i = cell.begin, hi = cell.end;
+    if (half_bits_to_float(cell.r1max) < near) i = hi;
     while (hi - i > 8u) {
         const uint32_t mid = i + ((hi - i) >> 1);
         if (half_bits_to_float(dm.entries[mid].r1) < near) i = mid + 1u; else hi = mid;

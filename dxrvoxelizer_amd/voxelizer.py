@@ -178,7 +178,7 @@ class Voxelizer:
                   DBG_TRI_POS: ((T, 12), np.float32), DBG_TRI_NRM: ((T, 12), np.float32),
                   DBG_PARENTS: ((2 * T - 1,), np.uint32), DBG_NODES32: ((st["num_nodes"], 8), np.uint32),
                   DBG_NODES64: ((st["num_nodes"], 16), np.uint32),
-                  DBG_LIST_CELLS: ((6 * st["list_res"] ** 2, 2), np.uint32), DBG_LIST_ENTRIES: ((st["list_entries"], 4), np.uint32)}
+                  DBG_LIST_CELLS: ((6 * st["list_res"] ** 2, 4), np.uint32), DBG_LIST_ENTRIES: ((st["list_entries"], 4), np.uint32)}
         shape, dt = shapes[what]
         out = np.empty(shape, dt)
         self._check(self._lib.dxv_debug_download(self._ctx, what, out.ctypes.data_as(C.c_void_p), out.nbytes))

@@ -42,7 +42,7 @@ enum {
     DXV_DBG_PARENTS = 4,     /* (T-1) internal + T leaf parent words: (parent << 1) | side    */
     DXV_DBG_NODES32 = 5,     /* max(T-1,1) x 32 B traversal nodes (half-float boxes)          */
     DXV_DBG_NODES64 = 6,     /* max(T-1,1) x 64 B wide traversal nodes (up to 4 boxes each)   */
-    DXV_DBG_LIST_CELLS = 7,  /* 6 R R x 8 B: [begin, end) of every texel's list (option lists)  */
+    DXV_DBG_LIST_CELLS = 7,  /* 6 R R x 16 B: begin, end, far radius of every texel's list       */
     DXV_DBG_LIST_ENTRIES = 8 /* stats.list_entries x 16 B entries of the direction-space lists  */
 };
 

@@ -148,7 +148,7 @@ def hostcheck():
         def lists(self, R):
             """direction-space lists built on the host with the product's footprint code: (cells, entries)"""
             n = L.hc_dirmap_build(self.h, R)
-            cells = np.empty((6 * R * R, 2), np.uint32)
+            cells = np.empty((6 * R * R, 4), np.uint32)
             entries = np.empty((n, 4), np.uint32)
             L.hc_dirmap_get(self.h, cells.ctypes.data_as(C.c_void_p), entries.ctypes.data_as(C.c_void_p))
             return cells, entries

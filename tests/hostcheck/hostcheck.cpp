@@ -134,13 +134,14 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
         }
     std::sort(keys.begin(), keys.end());
     s->dmR = R;
-    s->dmCells.assign((size_t)6 * R * R, DirCell{0, 0});
+    s->dmCells.assign((size_t)6 * R * R, DirCell{0, 0, 0, 0});
     s->dmEntries.resize(keys.size());
     for (size_t i = 0; i < keys.size(); ++i) {
         const uint32_t cell = dm_key_cell(lay, keys[i]), t = dm_key_tri(lay, keys[i]);
         s->dmEntries[i] = rec[(size_t)t * 6 + cell / (R * R)];
         if (i == 0 || dm_key_cell(lay, keys[i - 1]) != cell) s->dmCells[cell].begin = (uint32_t)i;
         s->dmCells[cell].end = (uint32_t)i + 1;
+        s->dmCells[cell].r1max = s->dmEntries[i].r1;
     }
     return keys.size();
 }

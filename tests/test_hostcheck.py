@@ -210,6 +210,8 @@ def test_direction_space_lists_give_the_tree_walk_grid(orc, hostcheck, bunny):
     for R in (32, 256):
         cells, entries = h.lists(R)
         assert (cells[:, 1] >= cells[:, 0]).all() and int(cells[:, 1].max()) == len(entries)
+        full = cells[:, 1] > cells[:, 0]
+        assert np.array_equal(cells[full, 2], entries[cells[full, 1] - 1, 2] >> 16)      # far radius of the last entry
         got, ovf = h.voxelize(64, mode=12, stack=4)                   # a queue of four entries: several flushes per ray
         assert ovf == 0 and np.array_equal(got, want), R
     rng = np.random.default_rng(99)
