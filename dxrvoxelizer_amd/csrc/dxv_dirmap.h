@@ -256,8 +256,12 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         // +13 % on the 1 M-triangle scene, one: +40 %)
         if (i < cell.end) {
             const uint32_t last = cell.end - 1u;
+            // (the third and fourth load are skipped when no lane of the wave has that many entries left:
+            // -5 % on the 1 M-triangle scene; voting on the second one as well: +7 %)
+            const bool wide = wave_any(i + 2u <= last);
             const DirEntry e0 = dm.entries[i], e1 = dm.entries[i + 1u < last ? i + 1u : last];
-            const DirEntry e2 = dm.entries[i + 2u < last ? i + 2u : last], e3 = dm.entries[i + 3u < last ? i + 3u : last];
+            DirEntry e2 = e0, e3 = e0;
+            if (wide) { e2 = dm.entries[i + 2u < last ? i + 2u : last]; e3 = dm.entries[i + 3u < last ? i + 3u : last]; }
             consider(e0);
             if (i + 1u <= last) consider(e1);
             if (i + 2u <= last) consider(e2);
