@@ -76,6 +76,7 @@ struct dxv_ctx {
     int optLists = 1;                // reference rule through the lists (-20...-48 % against the tree walk, profiles/r01/final/ab_lists.jsonl)
     int optListRes = 0;              // texels per face side; 0 = by triangle count (list_resolution)
     float listMs = 0.0f;
+    int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
     size_t emptyCap = 0;
     int optSkipEmpty = 1;    // display pass: skip the samples of empty 8^3 bricks (same image)
@@ -210,7 +211,8 @@ int safe_stack(const dxv_ctx* c)
 // lists would exceed 256 entries per triangle + 64 M (triangles through the grid centre cover whole
 // faces) keep the tree walk: listState = -1.
 // Texels per face side.  Measured optimum (tools/ab_lists.py): 5-10 entries per texel -- coarser maps
-// have long lists, finer ones stop fitting the caches: 128 below 20 k triangles, 256 up to 3 M, 512 beyond.
+// have long lists, finer ones stop fitting the caches: 128 below 20 k triangles, 256 up to 3 M (512 when the
+// 256 map holds more than 10 entries per texel: build_lists), 512 beyond.
 uint32_t list_resolution(const dxv_ctx* c)
 {
     if (c->optListRes) return (uint32_t)c->optListRes;
@@ -219,7 +221,8 @@ uint32_t list_resolution(const dxv_ctx* c)
 
 int build_lists(dxv_ctx* c)
 {
-    const uint32_t T = c->hdr.numTris, R = list_resolution(c);
+    const uint32_t T = c->hdr.numTris;
+    uint32_t R = list_resolution(c);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, c->stream);
     const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
@@ -242,6 +245,14 @@ int build_lists(dxv_ctx* c)
     unsigned long long total = 0;
     if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    // automatic resolution: more than 10 entries per texel on the 256 map -> the 512 map is faster
+    // (bunny x16 1.94 -> 1.77 ms, dragon x9 1.14 -> 1.11; torus-1M, 9.8 per texel, is the same on both)
+    if (!c->optListRes && R == 256u && total > 10ull * 6ull * R * R && total <= 32ull * 6ull * R * R) {
+        R = 512u;
+        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, c->stream)) != hipSuccess) return bail(e, "dirmap_count");
+        if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    }
     const unsigned long long cap = 256ull * T + (64ull << 20);
     // lists pay while they are short: past ~32 entries per texel on average (deep soups: hundreds of
     // triangles behind one another in every direction) the tree walk wins (soup-10M: 120 vs 65 ms).  An
@@ -252,6 +263,7 @@ int build_lists(dxv_ctx* c)
         (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
         c->listState = -1;
         c->listEntries = 0;
+        c->listOpt = c->optListRes;
         return 0;
     }
     const uint32_t n = (uint32_t)total;
@@ -279,6 +291,7 @@ int build_lists(dxv_ctx* c)
     c->listEntries = n;
     c->listRes = R;
     c->listState = 1;
+    c->listOpt = c->optListRes;
     return 0;
 }
 
@@ -302,7 +315,7 @@ int launch_now(dxv_ctx* c)
     int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.list_entries = 0; c->stats.list_res = 0;
     if (p.mode == DXV_MODE_REFERENCE && c->optLists) {
-        if (c->listState == 0 || (c->listState == 1 && c->listRes != list_resolution(c))) {
+        if (c->listState == 0 || (c->listState != 0 && c->listOpt != c->optListRes)) {
             if (build_lists(c)) return 1;
         }
         if (c->listState == 1) {
