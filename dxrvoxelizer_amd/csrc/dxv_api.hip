@@ -73,9 +73,11 @@ struct dxv_ctx {
     size_t listCellCap = 0, listEntryCap = 0;
     uint32_t listEntries = 0, listRes = 0;
     int listState = 0;               // 0: not built for this scene, 1: built, -1: over the cap for this scene (tree walk)
-    int optLists = 1;                // reference rule through the lists (-20...-48 % against the tree walk, profiles/r01/final/ab_lists.jsonl)
+    int optLists = 1;                // reference rule through the lists (-40...-60 % against the tree walk, profiles/r01/final/ab_lists.jsonl):
+                                     // 1 = from a scene's second launch on, 2 = from the first, 0 = tree walk
     int optListRes = 0;              // texels per face side; 0 = by triangle count (list_resolution)
     float listMs = 0.0f;
+    uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
     int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
     size_t emptyCap = 0;
@@ -314,7 +316,12 @@ int launch_now(dxv_ctx* c)
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.list_entries = 0; c->stats.list_res = 0;
-    if (p.mode == DXV_MODE_REFERENCE && c->optLists) {
+    // The lists cost 0.4-3.5 ms to build: a scene pays for them on its second launch (lists=1), so a
+    // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
+    // builds them at the first launch.
+    const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists && (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0);
+    if (p.mode == DXV_MODE_REFERENCE) ++c->launchesOfScene;
+    if (wantLists) {
         if (c->listState == 0 || (c->listState != 0 && c->listOpt != c->optListRes)) {
             if (build_lists(c)) return 1;
         }
@@ -449,7 +456,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->listState = 0;
+    c->haveMesh = false; c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -530,7 +537,7 @@ int dxv_refit(dxv_ctx* c)
     if (!c->haveMesh || !c->haveScene || c->scratchT != c->T || !c->T)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
-    c->haveScene = false; c->listState = 0;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
     if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
     fill_build_buffers(c, b);
@@ -546,7 +553,7 @@ int dxv_build(dxv_ctx* c)
     if (!c) return 1;
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
-    c->haveScene = false; c->listState = 0;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -785,7 +792,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
         h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.hasWide > 1u || h.treeHeight == 0 || h.treeHeight > 64)
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
-    c->haveScene = false; c->listState = 0;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
     if (alloc_scene(c, h.numTris, h.numVerts, h.hasWide != 0)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dScene, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
@@ -833,7 +840,7 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
             return dxv_build(c);
         }
     } else if (!strcmp(key, "lists")) {
-        if (value != 0 && value != 1) return fail(c, "option lists: %lld not in {0,1}", (long long)value);
+        if (value < 0 || value > 2) return fail(c, "option lists: %lld not in {0,1,2}", (long long)value);
         c->optLists = (int)value;
     } else if (!strcmp(key, "listres")) {
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option listres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);

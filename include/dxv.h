@@ -179,8 +179,10 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   rowblock 0|1|2|4  ... per row (1), per 2 x 2 or 4 x 4 rows; 0 (default) decides by triangle size
  *   refit  0|1|2  box merge of dxv_build and dxv_refit: min/max pyramid over the leaf order (1,
  *                 default), level sweeps (2), one atomic pass (0)
- *   lists  0|1    reference rule through direction-space lists (1, default; dxv_dirmap.h) or the tree walk (0);
- *                 the lists are built on the first launch after a build / refit / import; scenes whose
+ *   lists  0|1|2  reference rule through direction-space lists (dxv_dirmap.h) or the tree walk (0).  The
+ *                 lists are built from the scene's triangle records, 0.4-3.5 ms: at the second launch after
+ *                 a build / refit / import (1, default: a mesh refitted every frame stays on the tree walk)
+ *                 or at the first (2); scenes whose
  *                 lists would average more than 32 entries per texel, or exceed 256 entries per
  *                 triangle + 64 M, keep the tree walk (stats.list_entries = 0)
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)

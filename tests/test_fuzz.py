@@ -66,6 +66,7 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
             for mode in (0, 1):
                 want = s.voxelize(N, mode=mode, algo=orc.ALGO_BRUTE)
                 if mode == 0:                             # the direction-space lists (default), a coarse and a fine map
+                    v.set_option("lists", 2)              # (2: from the first launch of a scene on)
                     for res in (0, 16, 512):
                         v.set_option("listres", res)
                         v.Voxelize(N, mode)

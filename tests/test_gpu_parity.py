@@ -188,7 +188,7 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
             vox.set_option("region", region)
             vox.set_option("queue", queue)
             vox.set_option("subbox", subbox)
-            for lists in (0, 1):                                      # the tree walks, and the direction-space lists
+            for lists in (0, 2):                                      # the tree walks, and the direction-space lists
                 vox.set_option("lists", lists)
                 vox.Voxelize(64)
                 assert np.array_equal(vox.Grid(), want), (brick, stack, morton, region, queue, subbox, lists)
@@ -638,7 +638,7 @@ def test_lists_equal_tree_walk_and_host_lists(dxv, orc, hostcheck, request, name
         want = v.Grid().copy()
         assert v.stats()["list_entries"] == 0
         v.set_option("listres", R)
-        v.set_option("lists", 1)
+        v.set_option("lists", 2)
         v.Voxelize(N)
         st = v.stats()
         assert st["list_entries"] > 0 and st["list_res"] == R and st["redo_rays"] == 0
@@ -662,10 +662,13 @@ def test_lists_equal_tree_walk_and_host_lists(dxv, orc, hostcheck, request, name
 def test_lists_follow_the_scene_and_fall_back_over_the_cap(dxv, orc, bunny):
     vb, ib, _ = bunny
     v = dxv.Voxelizer(0)
-    v.set_option("lists", 1)
     v.InitFromArrays(vb, ib)
-    v.Voxelize(64)
+    v.Voxelize(64)                                                    # default: the first launch of a scene walks the tree,
+    assert v.stats()["list_entries"] == 0
     a = v.Grid().copy()
+    v.Voxelize(64)                                                    # the second one builds and uses the lists
+    assert v.stats()["list_entries"] > 0 and np.array_equal(v.Grid(), a)
+    v.set_option("lists", 2)                                          # 2: from the first launch on
     moved = np.array(vb, np.float32, copy=True)
     moved[:, 0] *= 0.5                                                # squash the mesh: refit -> the lists are rebuilt
     v.UpdateVertices(moved)
@@ -675,7 +678,7 @@ def test_lists_follow_the_scene_and_fall_back_over_the_cap(dxv, orc, bunny):
     v.set_option("lists", 0)                                          # the refitted tree gives the same grid
     v.Voxelize(64)
     assert np.array_equal(b, v.Grid()) and not np.array_equal(a, b)
-    v.set_option("lists", 1)
+    v.set_option("lists", 2)
     # triangles through the grid centre cover whole cube faces: over the cap the tree walk is used
     rng = np.random.default_rng(3)
     T = 400

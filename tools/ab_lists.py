@@ -24,7 +24,7 @@ for mesh in a.meshes.split(","):
     row = {"mesh": mesh, "N": a.grid}
     solid = set()
     for res in ["tree"] + a.res.split(","):
-        v.set_option("lists", 0 if res == "tree" else 1)
+        v.set_option("lists", 0 if res == "tree" else 2)
         if res != "tree":
             v.set_option("listres", 0 if res == "auto" else int(res))
         v.Voxelize(a.grid)
