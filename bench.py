@@ -124,6 +124,7 @@ def main():
     stream = torch.cuda.Stream()                 # a real (non-null) stream: kernels, torch events and
     torch.cuda.set_stream(stream)                # RCCL all share it
     vox.set_stream(stream.cuda_stream)
+    vox.set_option("lists", 2)       # candidate lists from a scene's first launch on: their build stays in the warm-up (config.candidates.build_ms)
     if args.brick >= 0:
         vox.set_option("brick", args.brick)
     if args.stack >= 0:
@@ -158,6 +159,7 @@ def main():
             s2 = torch.cuda.Stream()
             v2 = dxv.Voxelizer(local_rank)
             v2.set_stream(s2.cuda_stream)
+            v2.set_option("lists", 2)
             if args.brick >= 0:
                 v2.set_option("brick", args.brick)
             if args.stack >= 0:
