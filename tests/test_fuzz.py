@@ -99,3 +99,16 @@ def test_randomised_soak_short(dxvlib, orc):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_soak.py"), "12", "777"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and '"soak": "ok"' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_lists_edge_cases(dxvlib, orc):
+    """tools/edge_cases.py: the direction-space lists on a single triangle at grids 2..16, triangles through
+    and clustered at the grid centre (whole-face footprints, the fall-back to the tree), near-collinear
+    slivers of three lengths -- coarsest, automatic and finest maps, each grid against brute force."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "edge_cases.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("BAD 0"), r.stdout[-2000:] + r.stderr[-2000:]
