@@ -275,8 +275,8 @@ def main():
                          "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); the kernel "
-                                 "is latency- and issue-bound, not bandwidth-bound: compulsory HBM bytes are ~1 % of what 8 TB/s "
-                                 "moves in its run time (profiles/r01/final/pmc_summary.json, DESIGN.md section 4)"},
+                                 "is bound by vector-L1 line accesses (~80 % of its cycles), not by bandwidth: compulsory HBM bytes are "
+                                 "~2 % of what 8 TB/s moves in its run time (profiles/r01/final/pmc_summary.json, DESIGN.md section 4)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode)
