@@ -19,10 +19,13 @@ __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restric
                                                          DirEntry* __restrict__ rec, uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ total)
 {
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    // thread -> (face, triangle) face-major: the 64 triangles of a wave are neighbours in Morton order and
+    // mostly see the same faces, so the expensive clip runs with full waves or not at all (records and
+    // counts keep their triangle-major slots: the emit order, hence the list order, does not change)
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
     unsigned long long n = 0;
-    if (i < 6u * T) {
-        const uint32_t tri = i / 6u, face = i % 6u;
+    if (t < 6u * T) {
+        const uint32_t face = t / T, tri = t % T, i = tri * 6u + face;
         const DirEntry e = dm_entry(triPos[tri], face, tri);
         rec[i] = e;
         uint32_t i0, i1, j0, j1;
