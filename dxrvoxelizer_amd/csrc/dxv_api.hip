@@ -228,21 +228,20 @@ int build_lists(dxv_ctx* c)
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, c->stream);
     const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
-    DirEntry* rec = nullptr;
-    uint32_t *counts = nullptr, *offsets = nullptr, *sums = nullptr, *hist = nullptr;
-    uint64_t *keys = nullptr, *keysTmp = nullptr;
-    unsigned long long* dTotal = nullptr;
-    auto release = [&]() {
-        (void)hipFree(rec); (void)hipFree(counts); (void)hipFree(offsets); (void)hipFree(sums); (void)hipFree(hist);
-        (void)hipFree(keys); (void)hipFree(keysTmp); (void)hipFree(dTotal);
-    };
+    // scratch in two allocations (an allocation costs ~0.1 ms, as much as a pass): per-(triangle, face)
+    // arrays now, the key buffers once the number of entries is known
+    uint8_t *scratchA = nullptr, *scratchB = nullptr;
+    auto release = [&]() { (void)hipFree(scratchA); (void)hipFree(scratchB); };
     auto bail = [&](hipError_t e, const char* what) { release(); return fail(c, "lists: %s failed: %s", what, hipGetErrorString(e)); };
     hipError_t e;
-    if ((e = hipMalloc(&rec, n6 * sizeof(DirEntry))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&counts, n6 * 4)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&offsets, n6 * 4)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&sums, (nb + 1) * 4)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&dTotal, 256)) != hipSuccess) return bail(e, "hipMalloc");
+    const size_t offCounts = align256(n6 * sizeof(DirEntry)), offOffsets = offCounts + align256(n6 * 4),
+                 offSums = offOffsets + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
+    if ((e = hipMalloc(&scratchA, offTotal + 256)) != hipSuccess) return bail(e, "hipMalloc");
+    DirEntry* rec = reinterpret_cast<DirEntry*>(scratchA);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(scratchA + offCounts);
+    uint32_t* offsets = reinterpret_cast<uint32_t*>(scratchA + offOffsets);
+    uint32_t* sums = reinterpret_cast<uint32_t*>(scratchA + offSums);
+    unsigned long long* dTotal = reinterpret_cast<unsigned long long*>(scratchA + offTotal);
     if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, c->stream)) != hipSuccess) return bail(e, "dirmap_count");
     unsigned long long total = 0;
     if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
@@ -280,9 +279,11 @@ int build_lists(dxv_ctx* c)
         if ((e = hipMalloc(&c->dListEntries, ((size_t)n + 1) * sizeof(DirEntry))) != hipSuccess) return bail(e, "hipMalloc");
         c->listEntryCap = n;
     }
-    if ((e = hipMalloc(&keys, ((size_t)n + 1) * 8)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&keysTmp, ((size_t)n + 1) * 8)) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMalloc(&hist, sizeof(uint32_t) * (size_t)radix_sort_hist_words(n ? n : 1))) != hipSuccess) return bail(e, "hipMalloc");
+    const size_t keyBytes = align256(((size_t)n + 1) * 8);
+    if ((e = hipMalloc(&scratchB, 2 * keyBytes + sizeof(uint32_t) * (size_t)radix_sort_hist_words(n ? n : 1))) != hipSuccess) return bail(e, "hipMalloc");
+    uint64_t* keys = reinterpret_cast<uint64_t*>(scratchB);
+    uint64_t* keysTmp = reinterpret_cast<uint64_t*>(scratchB + keyBytes);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(scratchB + 2 * keyBytes);
     if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, c->stream)) != hipSuccess)
         return bail(e, "dirmap_fill");
     if (t1) (void)hipEventRecord(t1, c->stream);

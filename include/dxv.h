@@ -180,7 +180,7 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   refit  0|1|2  box merge of dxv_build and dxv_refit: min/max pyramid over the leaf order (1,
  *                 default), level sweeps (2), one atomic pass (0)
  *   lists  0|1|2  reference rule through direction-space lists (dxv_dirmap.h) or the tree walk (0).  The
- *                 lists are built from the scene's triangle records, 0.4-3.5 ms: at the second launch after
+ *                 lists are built from the scene's triangle records, 0.3-2.7 ms: at the second launch after
  *                 a build / refit / import (1, default: a mesh refitted every frame stays on the tree walk)
  *                 or at the first (2); scenes whose
  *                 lists would average more than 32 entries per texel, or exceed 256 entries per
