@@ -317,7 +317,7 @@ int launch_now(dxv_ctx* c)
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     int st = c->optStack ? c->optStack : c->stackNow;
     c->stats.list_entries = 0; c->stats.list_res = 0;
-    // The lists cost 0.4-3.5 ms to build: a scene pays for them on its second launch (lists=1), so a
+    // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
     // builds them at the first launch.
     const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists && (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0);
