@@ -231,7 +231,12 @@ int build_lists(dxv_ctx* c)
     // scratch in two allocations (an allocation costs ~0.1 ms, as much as a pass): per-(triangle, face)
     // arrays now, the key buffers once the number of entries is known
     uint8_t *scratchA = nullptr, *scratchB = nullptr;
-    auto release = [&]() { (void)hipFree(scratchA); (void)hipFree(scratchB); };
+    auto release = [&]() {
+        (void)hipFree(scratchA); (void)hipFree(scratchB);
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        t0 = t1 = nullptr;
+    };
     auto bail = [&](hipError_t e, const char* what) { release(); return fail(c, "lists: %s failed: %s", what, hipGetErrorString(e)); };
     hipError_t e;
     const size_t offCounts = align256(n6 * sizeof(DirEntry)), offOffsets = offCounts + align256(n6 * 4),
@@ -261,7 +266,6 @@ int build_lists(dxv_ctx* c)
     const bool tooLong = !c->optListRes && total > 32ull * 6ull * R * R;
     if (tooLong || total > cap || total > 0x7fffffffull || (unsigned long long)T > (1ull << dm_key_layout(R).triBits)) {
         release();
-        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
         c->listState = -1;
         c->listEntries = 0;
         c->listOpt = c->optListRes;
@@ -289,7 +293,6 @@ int build_lists(dxv_ctx* c)
     if (t1) (void)hipEventRecord(t1, c->stream);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     if (t0 && t1) c->listMs = elapsed(t0, t1);
-    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
     release();
     c->listEntries = n;
     c->listRes = R;
