@@ -67,7 +67,8 @@ def build(force=False, save_temps=False, verbose=False):
         if verbose and err.strip():
             print(err, file=sys.stderr)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in results]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    # cwd = the ignored build directory: the offload bundler drops its temp files where it runs
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJDIR)
     if r.returncode:
         raise RuntimeError("link failed: %s\n%s%s" % (" ".join(cmd), r.stdout, r.stderr))
     return LIB
