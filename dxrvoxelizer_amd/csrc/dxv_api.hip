@@ -98,6 +98,7 @@ struct dxv_ctx {
                              // 1 = on every visit (-8 % on low-poly meshes, +10 % on 1 M triangles at 256^3), 0 = binary only
     int optRows = 1;         // parity mode: one tree walk per grid row (k_parity_rows) instead of per voxel
     int optRowBlock = 0;     // rows per side of a wave's block of rows: 0 = by triangle size, 1, 2
+    int optAblate = 0;       // timing-only variants of the lists kernel (results are wrong by design; tools/ablate.py)
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
     int optStack0 = 20;      // adaptive mode starts with this many entries (stack + leaf queue share them)
     int stackNow = 20;       // adaptive: LDS stack entries per thread currently in use for this scene
@@ -331,6 +332,7 @@ int launch_now(dxv_ctx* c)
         }
         if (c->listState == 1) {
             p.lists = 1u;
+            p.ablate = (uint32_t)c->optAblate;
             p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
             st = 8;                                                 // no stack: the smallest column (the queue of selected triangles)
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
@@ -849,6 +851,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "listres")) {
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option listres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
         c->optListRes = (int)value;
+    } else if (!strcmp(key, "ablate")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8}", (long long)value);
+        c->optAblate = (int)value;
     } else if (!strcmp(key, "skipempty")) {
         if (value != 0 && value != 1) return fail(c, "option skipempty: %lld not in {0,1}", (long long)value);
         c->optSkipEmpty = (int)value;

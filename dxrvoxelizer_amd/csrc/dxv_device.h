@@ -70,6 +70,7 @@ struct VoxelizeParams {
     uint32_t subbox;        // 1: launch only bricks the root early-out cannot clear (default)
     uint32_t wide;          // 1: reference rule walks the wide nodes (default when the stack bound allows)
     uint32_t lists;         // 1: reference rule reads the direction-space lists of p.scene (no tree walk)
+    uint32_t ablate;        // timing-only builds of the lists kernel (wrong grids; tools/ablate.py), 0 = the real kernel
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack

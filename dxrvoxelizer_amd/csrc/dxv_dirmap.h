@@ -226,10 +226,13 @@ DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32
 // long, so the triangles an entry scan selects are queued in the thread's LDS column (cap entries)
 // and tested when some lane's queue is full or every lane has finished scanning -- all lanes with
 // work test together.
-template <class Stack>
+// ABL (timing-only builds, tools/ablate.py; 0 in every shipped path): 8 = stop before the texel lookup, 1 = stop after it,
+// 2 = scan the entries but test no triangle
+template <class Stack, int ABL = 0>
 DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, const Stack& stk, int cap, Hit& best)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
+    if (ABL & 8) return;
     uint32_t face;
     float u, v, rho;
     dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
@@ -239,6 +242,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     // all of them at once for a ray that starts beyond the texel's last triangle
     uint32_t i = cell.begin, hi = cell.end;
     if (half_bits_to_float(cell.r1max) < near) i = hi;
+    if (ABL & 1) { if (i == 0xffffffffu) best.k = 0u; return; }
     while (hi - i > 8u) {
         const uint32_t mid = i + ((hi - i) >> 1);
         if (half_bits_to_float(dm.entries[mid].r1) < near) i = mid + 1u; else hi = mid;
@@ -270,6 +274,8 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         }
         const bool scanning = wave_any(i < cell.end);
         if (scanning && !wave_any(qn + 4 > cap)) continue;
+        if (ABL & 2) { if (qn > 100) best.k = 0u; }
+        else
         for (int k = 0; wave_any(k < qn); ++k)
             if (k < qn) leaf_reference(r, tris, stk.get(k), best);
         qn = 0;
@@ -277,11 +283,11 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     }
 }
 
-template <class Stack>
+template <class Stack, int ABL>
 DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best)
 {
     const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
-    trace_reference_dm(r, dm, sc.triPos, stk, cap, best);
+    trace_reference_dm<Stack, ABL>(r, dm, sc.triPos, stk, cap, best);
 }
 
 } // namespace dxv

@@ -575,14 +575,14 @@ struct SceneView {
     uint32_t dmR;
 };
 
-template <class Stack>
+template <class Stack, int ABL = 0>
 DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best);      // dxv_dirmap.h
 
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
 // WALK: 0 = leaves tested as they are met, 1 = postponed-leaf walk, 2 = postponed-leaf walk over the
 // wide nodes, 3 = wide nodes on wave-uniform visits only, 4 = direction-space lists.  All return the same voxel.
-template <int WALK, class Stack>
+template <int WALK, class Stack, int ABL = 0>
 DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz,
                                const Stack& stk, int cap, uint32_t* texel, bool& overflow)
 {
@@ -592,7 +592,7 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
     finish_ray_reference(r);
     Hit best;
-    if (WALK == 4) trace_reference_lists(r, sc, stk, cap, best);                           // no tree, no stack: cannot overflow
+    if (WALK == 4) trace_reference_lists<Stack, ABL>(r, sc, stk, cap, best);                           // no tree, no stack: cannot overflow
     const bool ok = WALK == 4 ? true
                   : WALK == 3 ? trace_reference_h(r, sc.nodes, sc.wide, sc.triPos, stk, cap, best)
                   : WALK == 2 ? trace_reference_w(r, sc.wide, sc.triPos, stk, cap, best)
@@ -600,6 +600,7 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
                               : trace_reference(r, sc.nodes, sc.triPos, stk, cap, best);
     if (!ok) { overflow = true; return 0; }
     if (best.k == 0xffffffffu) return 0;                                         // missMain
+    if (ABL & 4) return 1;
     const TriNrm tn = sc.triNrm[best.leaf];
     float nx, ny, nz;
     const bool in = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz);

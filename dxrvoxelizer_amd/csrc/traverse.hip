@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t compact1by2(uint32_t x)
 }
 
 // WALK: 0 = leaves tested as met, 1 = postponed-leaf walk, 2 = the same over the wide nodes (MODE 0)
-template <class B, int STACK, int MODE, bool TEXELS, int WALK>
+template <class B, int STACK, int MODE, bool TEXELS, int WALK, int ABL = 0>
 __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs (lists: 6, no LDS to speak of)
 {
     __shared__ int32_t stack[STACK * B::threads];
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
     uint8_t occ;
     if (MODE == 0) {
         uint32_t texel = 0;
-        occ = voxel_reference<WALK>(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
+        occ = voxel_reference<WALK, StridedStack, ABL>(p.scene, N, ix, iy, iz, stk, STACK, TEXELS ? &texel : nullptr, overflow);
         if (TEXELS) p.texels[id] = texel;
     } else {
         occ = voxel_parity<WALK != 0>(p.scene, N, ix, iy, iz, stk, STACK, overflow);
@@ -453,6 +453,17 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
     if (p.mode == 0 && p.lists) {
         // direction-space lists: no stack (the caller passes the smallest column)
         if constexpr (STACK == 8) {
+            if constexpr (B::threads == 64 && B::x == 4) {     // timing-only ablations of the default shape (tools/ablate.py)
+                switch (p.ablate) {
+                case 0: break;
+                case 1: k_voxelize<B, 8, 0, false, 4, 1><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 2: k_voxelize<B, 8, 0, false, 4, 2><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 4: k_voxelize<B, 8, 0, false, 4, 4><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 6: k_voxelize<B, 8, 0, false, 4, 6><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 8: k_voxelize<B, 8, 0, false, 4, 8><<<g, b, 0, s>>>(p); return hipGetLastError();
+                default: return hipErrorInvalidValue;
+                }
+            }
             if (p.texels) k_voxelize<B, 8, 0, true, 4><<<g, b, 0, s>>>(p);
             else k_voxelize<B, 8, 0, false, 4><<<g, b, 0, s>>>(p);
         } else return hipErrorInvalidValue;
