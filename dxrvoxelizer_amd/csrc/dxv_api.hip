@@ -238,7 +238,17 @@ int build_lists(dxv_ctx* c)
         if (t1) (void)hipEventDestroy(t1);
         t0 = t1 = nullptr;
     };
-    auto bail = [&](hipError_t e, const char* what) { release(); return fail(c, "lists: %s failed: %s", what, hipGetErrorString(e)); };
+    // The lists are an optional accelerator: when their memory cannot be had the scene keeps the tree walk
+    // (listState = -1, like a scene whose lists would be too long); only launch and sync errors are errors.
+    auto bail = [&](hipError_t e, const char* what) {
+        release();
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();                   // clear the sticky allocation error
+            c->listState = -1; c->listEntries = 0; c->listOpt = c->optListRes;
+            return 0;
+        }
+        return fail(c, "lists: %s failed: %s", what, hipGetErrorString(e));
+    };
     hipError_t e;
     const size_t offCounts = align256(n6 * sizeof(DirEntry)), offOffsets = offCounts + align256(n6 * 4),
                  offSums = offOffsets + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
@@ -441,8 +451,10 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     // bound: AABB over every VB position (XUSGObjLoader.cpp:386-416), centre and half max extent
     // (Content/Voxelizer.cpp:52-57)
     float mn[3] = {vb[0], vb[1], vb[2]}, mx[3] = {vb[0], vb[1], vb[2]};
-    for (uint32_t i = 1; i < V; ++i) {
+    for (uint32_t i = 0; i < V; ++i) {
         const float* p = vb + 6 * (size_t)i;
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]))   // (a NaN would slip through both comparisons below)
+            return fail(c, "dxv_set_mesh: vertex %u has a non-finite position (%g, %g, %g)", i, (double)p[0], (double)p[1], (double)p[2]);
         for (int a = 0; a < 3; ++a) {
             if (p[a] < mn[a]) mn[a] = p[a];
             else if (p[a] > mx[a]) mx[a] = p[a];
@@ -799,6 +811,13 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.hasWide > 1u || h.treeHeight == 0 || h.treeHeight > 64)
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
+    // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
+    // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
+    // triangle count over the old, smaller buffers.
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->dVb); (void)hipFree(c->dIb);
+    c->dVb = nullptr; c->dIb = nullptr; c->haveMesh = false;
+    free_scratch(c);
     if (alloc_scene(c, h.numTris, h.numVerts, h.hasWide != 0)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dScene, src, bytes, hipMemcpyDeviceToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <new>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -66,7 +67,9 @@ inline bool parse_int(const char*& p, const char* e, long long& out)
     if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
     if (q >= e || !is_digit(*q)) return false;
     unsigned long long m = 0;
-    while (q < e && is_digit(*q)) { m = m * 10u + (unsigned)(*q - '0'); ++q; }
+    constexpr unsigned long long kSat = 1ull << 40;       // beyond every index or exponent this file accepts: saturate, never wrap
+    while (q < e && is_digit(*q)) { if (m < kSat) m = m * 10u + (unsigned)(*q - '0'); ++q; }
+    if (m > kSat) m = kSat;
     out = neg ? -(long long)m : (long long)m;
     p = q;
     return true;
@@ -229,13 +232,21 @@ int worker_count(size_t bytes)
 template <class F> void parallel_items(int workers, size_t items, F f)
 {
     std::atomic<size_t> next{0};
-    auto run = [&] { for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < items;) f(i); };
+    std::atomic<bool> failed{false};                      // an exception in a worker (bad_alloc) must not reach std::terminate
+    auto run = [&] {
+        try {
+            for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < items;) f(i);
+        } catch (...) { failed.store(true); next.store(items); }
+    };
     std::vector<std::thread> th;
     const size_t extra = items < (size_t)workers ? (items ? items - 1 : 0) : (size_t)workers - 1;
     th.reserve(extra);
-    for (size_t i = 0; i < extra; ++i) th.emplace_back(run);
+    try {
+        for (size_t i = 0; i < extra; ++i) th.emplace_back(run);
+    } catch (...) {}                                      // thread limit reached: the threads that started (and the caller) do the work
     run();
     for (auto& t : th) t.join();
+    if (failed.load()) throw std::bad_alloc();
 }
 
 struct Mapping {
@@ -256,8 +267,25 @@ extern "C" {
 
 void dxv_free(void* p) { free(p); }
 
+static int obj_load_impl(const char* path, float** vbOut, uint32_t* numVerts, uint32_t** ibOut, uint32_t* numIndices, float aabb[6]);
+
+// C entry point: never throws (include/dxv_voxelizer.hpp promises bool returns like the reference's Import);
+// 4 = out of memory or any other C++ exception.
 int dxv_obj_load(const char* path, float** vbOut, uint32_t* numVerts, uint32_t** ibOut, uint32_t* numIndices,
                  float aabb[6])
+{
+    try {
+        return obj_load_impl(path, vbOut, numVerts, ibOut, numIndices, aabb);
+    } catch (...) {
+        if (vbOut) *vbOut = nullptr;
+        if (ibOut) *ibOut = nullptr;
+        if (numVerts) *numVerts = 0;
+        if (numIndices) *numIndices = 0;
+        return 4;
+    }
+}
+
+static int obj_load_impl(const char* path, float** vbOut, uint32_t* numVerts, uint32_t** ibOut, uint32_t* numIndices, float aabb[6])
 {
     if (!path || !vbOut || !numVerts || !ibOut || !numIndices) return 1;
     *vbOut = nullptr; *ibOut = nullptr; *numVerts = 0; *numIndices = 0;

@@ -1,0 +1,148 @@
+"""BASELINE.json configurations 3, 4 and 5 (and the metric's own meshes) at their full sizes, through the
+C-ABI, against the committed whole-grid fixtures of the CPU oracle (tests/golden/configs.json, made by
+oracle/gen_fixtures_configs.py in the build container): SHA-256 over the whole uint8 grid, the solid count
+and every slice's popcount -- for both candidate structures of the reference rule (direction-space lists,
+`lists=2`, and the LBVH walk, `lists=0`).  Grid indexing: Content/Voxelizer.cpp:366-368, hlsl:64-67."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+from dxrvoxelizer_amd import meshes
+from dxrvoxelizer_amd.slabs import slab_range
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def configs():
+    with open(os.path.join(GOLD, "configs.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="module")
+def dxv(dxvlib):
+    import dxrvoxelizer_amd
+    return dxrvoxelizer_amd
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def mesh_sha(vb, ib):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(vb, np.float32).tobytes())
+    h.update(np.ascontiguousarray(ib, np.uint32).tobytes())
+    return h.hexdigest()
+
+
+_cache = {}
+
+
+def make(name):
+    """The synthetic meshes of BASELINE.md section 4, regenerated here exactly as the fixture generator made them."""
+    if name not in _cache:
+        _cache.clear()                                        # one big mesh at a time
+        gold = lambda n: np.load(os.path.join(GOLD, "meshes", n + ".npz"))
+        if name == "dragon9":
+            d = gold("dragon")
+            _cache[name] = meshes.trisect(d["vb"], d["ib"])
+        elif name == "bunny16":
+            b = gold("bunny")
+            _cache[name] = meshes.midpoint_subdivide(b["vb"], b["ib"], 2)
+        elif name == "torus1m":
+            _cache[name] = meshes.torus()
+        elif name == "soup10m":
+            _cache[name] = meshes.soup()
+        elif name == "soup1m":
+            _cache[name] = meshes.soup(1_000_000)
+    return _cache[name]
+
+
+def check_whole(g, want, what):
+    N = g.shape[1]
+    slices = [int(x) for x in g.reshape(g.shape[0], -1).sum(1, dtype=np.uint64)]
+    bad = [z for z in range(len(slices)) if slices[z] != want["slices"][z]]
+    assert not bad, f"{what}: {len(bad)} slices differ in their solid count, first z = {bad[0]} (N = {N})"
+    assert sum(slices) == want["solid"]
+    assert sha(g) == want["sha256"], f"{what}: per-slice counts agree but the grid hash differs"
+
+
+def init(v, cfg, key):
+    name = key.split("/")[0]
+    vb, ib = make(name)
+    assert mesh_sha(vb, ib) == cfg[key]["mesh_sha256"], f"{name}: the mesh generator no longer produces the fixture's mesh"
+    v.InitFromArrays(vb, ib)
+    assert v.stats()["num_tris"] == cfg[key]["tris"]
+
+
+# config 3 (dragon x9, ~900k triangles, 512^3), the metric's meshes (1 M triangles, 256^3 and 512^3) and a 1 M-triangle soup
+@pytest.mark.parametrize("key", ["dragon9/512/reference", "torus1m/512/reference", "torus1m/256/reference",
+                                 "bunny16/512/reference", "soup1m/256/reference", "torus1m/512/parity"])
+def test_config_grid_equals_oracle_fixture(dxv, configs, key):
+    name, N, rule = key.split("/")
+    N, mode = int(N), (0 if rule == "reference" else 1)
+    v = dxv.Voxelizer(0)
+    try:
+        init(v, configs, key)
+        for lists in ((2, 0) if mode == 0 else (1,)):
+            v.set_option("lists", lists)
+            v.Voxelize(N, mode)
+            st = v.stats()
+            if mode == 0 and lists == 2 and name != "soup1m":
+                assert st["list_entries"] > 0, "the lists were expected to serve this scene"
+            if lists == 0:
+                assert st["list_entries"] == 0
+            check_whole(v.Grid(), configs[key], f"{key} lists={lists}")
+            assert v.CountSolid() == configs[key]["solid"]
+    finally:
+        v.close()
+
+
+def test_config4_dragon9_1024_slabs_and_block_cyclic(dxv, configs):
+    """config 4: dragon x9 at 1024^3 -- the whole grid, the 8 contiguous Z slabs of north_star and the block-cyclic
+    partition bench.py uses (Z blocks of 8 slices dealt round-robin over 8 ranks), every part against the fixture;
+    lists and tree walk.  One GPU plays the 8 ranks in turn (the partition arithmetic is the ranks')."""
+    key = "dragon9/1024/reference"
+    want = configs[key]
+    N, W, blk = 1024, 8, 8
+    v = dxv.Voxelizer(0)
+    try:
+        init(v, configs, key)
+        for lists in (2, 0):
+            v.set_option("lists", lists)
+            v.Voxelize(N)
+            check_whole(v.Grid(), want, f"{key} whole grid lists={lists}")
+            for r in range(W):
+                z0, nz = slab_range(N, r, W)
+                v.Voxelize(N, 0, z0, nz)
+                g = v.Grid()
+                assert [int(x) for x in g.reshape(nz, -1).sum(1, dtype=np.uint64)] == want["slices"][z0:z0 + nz], (lists, r)
+                assert sha(g) == want["slabs8_sha256"][r], f"slab {r} lists={lists}"
+            for r in range(W):
+                v.VoxelizeInterleaved(N, r, W, blk)
+                assert sha(v.Grid()) == want["cyclic8x8_sha256"][r], f"block-cyclic rank {r} lists={lists}"
+    finally:
+        v.close()
+
+
+def test_config5_soup10m_512(dxv, configs):
+    """config 5: the 10 M-triangle soup at 512^3 (build + traversal stress), the product's default candidate
+    structure for it and the plain LBVH walk."""
+    key = "soup10m/512/reference"
+    v = dxv.Voxelizer(0)
+    try:
+        init(v, configs, key)
+        st = v.stats()
+        assert st["num_tris"] == 10_000_000 and st["tree_height"] <= 62
+        for lists in (2, 0):
+            v.set_option("lists", lists)
+            v.Voxelize(512)
+            check_whole(v.Grid(), configs[key], f"{key} lists={lists}")
+    finally:
+        v.close()
+        _cache.clear()

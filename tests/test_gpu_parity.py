@@ -131,8 +131,12 @@ def test_grid_256_golden(vox, request, grids_json, name):
     """config 2: bunny at 256^3 on one MI355X, bit-exact (hash + per-slice popcounts)."""
     vb, ib, _ = request.getfixturevalue(name)
     vox.InitFromArrays(vb, ib)
-    for mode, tag in ((0, "reference"), (1, "parity")):
+    # reference rule through the tree walk (lists = 0) and through the direction-space lists from the first
+    # launch on (lists = 2, the shipped path from a scene's second launch), then the parity rule
+    for mode, tag, lists in ((0, "reference", 0), (0, "reference", 2), (1, "parity", 1)):
+        vox.set_option("lists", lists)
         vox.Voxelize(256, mode)
+        assert (vox.stats()["list_entries"] > 0) == (lists == 2)
         g = vox.Grid()
         want = grids_json[f"{name}/256/{tag}"]
         assert [int(x) for x in g.reshape(256, -1).sum(1)] == want["slices"]
@@ -350,6 +354,44 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     b.Voxelize(64)
     assert np.array_equal(b.Grid(), want)
     a.close(), b.close()
+
+
+def test_import_over_a_built_context_drops_its_mesh_state(dxv, orc, bunny, dragon):
+    """A context that built a SMALL mesh and then imports a bigger scene must not run build / refit / vertex
+    updates over the old buffers: they fail cleanly, and the imported scene voxelizes like its source."""
+    import torch
+    small_vb, small_ib = meshes.tetrahedron()
+    vb, ib, _ = dragon
+    a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
+    a.InitFromArrays(vb, ib)
+    b.InitFromArrays(small_vb, small_ib)
+    n = a.scene_bytes()
+    blob = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.scene_export(blob.data_ptr(), n)
+    torch.cuda.synchronize()
+    b.scene_import(blob.data_ptr(), n)
+    for call in (lambda: b._check(b._lib.dxv_build(b._ctx)), lambda: b._check(b._lib.dxv_refit(b._ctx)),
+                 lambda: b.UpdateVertices(vb, refit=False), lambda: b.UpdateVertices(small_vb, refit=False)):
+        with pytest.raises(dxv.DxvError):
+            call()
+    a.Voxelize(64), b.Voxelize(64)
+    assert np.array_equal(a.Grid(), b.Grid())
+    b.InitFromArrays(small_vb, small_ib)                  # and the context is still usable for a mesh of its own
+    b.Voxelize(16)
+    assert np.array_equal(b.Grid(), orc.Scene(small_vb, small_ib).voxelize(16))
+    a.close(), b.close()
+
+
+def test_non_finite_vertices_are_rejected(dxv):
+    vb, ib = meshes.cube()
+    v = dxv.Voxelizer(0)
+    for bad in (np.nan, np.inf, -np.inf):
+        w = vb.copy()
+        w[5, 1] = bad
+        with pytest.raises(dxv.DxvError, match="vertex 5"):
+            v.InitFromArrays(w, ib)
+    v.InitFromArrays(vb, ib)
+    v.close()
 
 
 def test_errors_are_loud(dxv, bunny):
