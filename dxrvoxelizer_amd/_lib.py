@@ -53,6 +53,8 @@ SYMBOLS = {
     "dxv_voxelize_interleaved": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
     "dxv_voxelize_interleaved_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
     "dxv_sync": (C.c_int, [C.c_void_p]),
+    "dxv_set_frame": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "dxv_sync_all": (C.c_int, [C.c_void_p]),
     "dxv_grid_device_ptr": (C.c_void_p, [C.c_void_p]),
     "dxv_grid_bytes": (C.c_size_t, [C.c_void_p]),
     "dxv_grid_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -52,16 +52,30 @@ struct dxv_ctx {
     uint32_t* dRootInfo = nullptr;
     uint32_t scratchT = 0;
 
-    // outputs
-    uint8_t* dGrid = nullptr;
-    size_t gridCap = 0, gridBytes = 0;
-    uint32_t* dTexels = nullptr;
-    size_t texelCap = 0;
+    // outputs: FrameCount sets of grid / texel image / status words / redo list / stream, the way the reference's
+    // Voxelizer owns FrameCount grids (Content/Voxelizer.h:24, :110); one scene and one set of lists serve them all
+    struct Frame {
+        hipStream_t ownStream = nullptr; // frames 1.. launch on a stream of their own; frame 0 on the context's stream
+        uint8_t* dGrid = nullptr;
+        size_t gridCap = 0, gridBytes = 0;
+        uint32_t* dTexels = nullptr;
+        size_t texelCap = 0;
+        uint32_t* dStatus = nullptr;     // [0] status bits, [1], [2] redo-list counters (alternating launches)
+        uint64_t* dRedo = nullptr;       // voxels whose LDS column was too small, finished by the redo pass
+        uint32_t redoParity = 0;
+        int lastRedoParity = -1;         // counter of the last launch (-1: that launch has none)
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the frame's last launch
+        int lastMode = 0;
+        uint32_t lastZBlock = 1, lastZPeriod = 1;
+        bool pending = false;            // a voxelize launch has not been checked by dxv_sync yet
+        bool ready = false;              // status words, redo list, events and stream exist
+        // launch fields of dxv_stats
+        float voxelize_ms = 0.0f;
+        uint32_t grid_dim = 0, z0 = 0, nz = 0, stack_entries = 0, redo_rays = 0, row_block = 0, list_entries = 0, list_res = 0;
+    };
+    Frame frames[DXV_FRAME_COUNT];
+    uint32_t cur = 0;                    // dxv_set_frame
     bool texels = false;
-    uint32_t* dStatus = nullptr;     // [0] status bits, [1], [2] redo-list counters (alternating launches)
-    uint64_t* dRedo = nullptr;       // voxels whose LDS column was too small, finished by the redo pass
-    uint32_t redoParity = 0;
-    int lastRedoParity = -1;         // counter of the last launch (-1: that launch has none)
     unsigned long long* dCount = nullptr;
     uint8_t* dPacked = nullptr;
     size_t packedCap = 0;
@@ -102,9 +116,6 @@ struct dxv_ctx {
     int optRegion = 6;       // log2 bricks per XCD region (64 bricks: balanced and L2 friendly in the r01 sweeps)
     int optStack0 = 20;      // adaptive mode starts with this many entries (stack + leaf queue share them)
     int stackNow = 20;       // adaptive: LDS stack entries per thread currently in use for this scene
-    int lastMode = 0;
-    uint32_t lastZBlock = 1, lastZPeriod = 1;
-    bool pending = false;    // a voxelize launch has not been checked by dxv_sync yet
 };
 
 namespace {
@@ -125,6 +136,37 @@ int fail(dxv_ctx* c, const char* fmt, ...)
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) return fail((c), "%s failed: %s", #call, hipGetErrorString(e_));    \
     } while (0)
+
+using Frame = dxv_ctx::Frame;
+Frame& cur_frame(dxv_ctx* c) { return c->frames[c->cur]; }
+hipStream_t frame_stream(dxv_ctx* c, uint32_t i) { return i == 0 ? c->stream : c->frames[i].ownStream; }
+hipStream_t cur_stream(dxv_ctx* c) { return frame_stream(c, c->cur); }
+
+// status words, redo list, events and (frames 1..) the stream of a frame, on its first use
+int frame_prepare(dxv_ctx* c, uint32_t i)
+{
+    Frame& f = c->frames[i];
+    if (f.ready) return 0;
+    if (i && !f.ownStream) DXV_HIP(c, hipStreamCreateWithFlags(&f.ownStream, hipStreamNonBlocking));
+    if (!f.ev0) DXV_HIP(c, hipEventCreate(&f.ev0));
+    if (!f.ev1) DXV_HIP(c, hipEventCreate(&f.ev1));
+    if (!f.dStatus) DXV_HIP(c, hipMalloc(&f.dStatus, 256));
+    if (!f.dRedo) DXV_HIP(c, hipMalloc(&f.dRedo, sizeof(uint64_t) * kRedoCap));
+    DXV_HIP(c, hipMemset(f.dStatus, 0, 256));
+    f.ready = true;
+    return 0;
+}
+
+int sync_frame(dxv_ctx* c, uint32_t i);
+
+// Everything that changes what the frames read (mesh, scene, lists, options that rebuild) first lets every
+// frame finish -- including the status check and, if a launch asked for it, the relaunch against the OLD scene.
+int sync_frames(dxv_ctx* c)
+{
+    for (uint32_t i = 0; i < DXV_FRAME_COUNT; ++i)
+        if (c->frames[i].ready && sync_frame(c, i)) return 1;
+    return 0;
+}
 
 Node* scene_nodes(dxv_ctx* c) { return reinterpret_cast<Node*>(c->dScene + c->hdr.offNodes); }
 Node32* scene_nodes32(dxv_ctx* c) { return reinterpret_cast<Node32*>(c->dScene + c->hdr.offNodes32); }
@@ -204,9 +246,9 @@ bool use_wide(const dxv_ctx* c, int mode)
     const int need = 3 * (((int)c->hdr.treeHeight + 1) / 2) + 5;
     return mode == DXV_MODE_REFERENCE && c->optWide && c->hdr.hasWide && c->optQueue && need <= 64;
 }
-int safe_stack(const dxv_ctx* c)
+int safe_stack(const dxv_ctx* c, int mode)
 {
-    if (use_wide(c, c->lastMode)) return stack_round_up(3 * (((int)c->hdr.treeHeight + 1) / 2) + 5);
+    if (use_wide(c, mode)) return stack_round_up(3 * (((int)c->hdr.treeHeight + 1) / 2) + 5);
     return stack_round_up((int)c->hdr.treeHeight + 3);
 }
 
@@ -222,12 +264,12 @@ uint32_t list_resolution(const dxv_ctx* c)
     return c->hdr.numTris < 20000u ? 128u : c->hdr.numTris < 3000000u ? 256u : 512u;
 }
 
-int build_lists(dxv_ctx* c)
+int build_lists(dxv_ctx* c, hipStream_t stream)
 {
     const uint32_t T = c->hdr.numTris;
     uint32_t R = list_resolution(c);
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, c->stream);
+    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, stream);
     const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
     // scratch in two allocations (an allocation costs ~0.1 ms, as much as a pass): per-(triangle, face)
     // arrays now, the key buffers once the number of entries is known
@@ -258,17 +300,17 @@ int build_lists(dxv_ctx* c)
     uint32_t* offsets = reinterpret_cast<uint32_t*>(scratchA + offOffsets);
     uint32_t* sums = reinterpret_cast<uint32_t*>(scratchA + offSums);
     unsigned long long* dTotal = reinterpret_cast<unsigned long long*>(scratchA + offTotal);
-    if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, c->stream)) != hipSuccess) return bail(e, "dirmap_count");
+    if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
     unsigned long long total = 0;
-    if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     // automatic resolution: more than 10 entries per texel on the 256 map -> the 512 map is faster
     // (bunny x16 1.94 -> 1.77 ms, dragon x9 1.14 -> 1.11; torus-1M, 9.8 per texel, is the same on both)
     if (!c->optListRes && R == 256u && total > 10ull * 6ull * R * R && total <= 32ull * 6ull * R * R) {
         R = 512u;
-        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, c->stream)) != hipSuccess) return bail(e, "dirmap_count");
-        if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
-        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
+        if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     }
     const unsigned long long cap = 256ull * T + (64ull << 20);
     // lists pay while they are short: past ~32 entries per texel on average (deep soups: hundreds of
@@ -299,10 +341,10 @@ int build_lists(dxv_ctx* c)
     uint64_t* keys = reinterpret_cast<uint64_t*>(scratchB);
     uint64_t* keysTmp = reinterpret_cast<uint64_t*>(scratchB + keyBytes);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratchB + 2 * keyBytes);
-    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, c->stream)) != hipSuccess)
+    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, stream)) != hipSuccess)
         return bail(e, "dirmap_fill");
-    if (t1) (void)hipEventRecord(t1, c->stream);
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    if (t1) (void)hipEventRecord(t1, stream);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     if (t0 && t1) c->listMs = elapsed(t0, t1);
     release();
     c->listEntries = n;
@@ -312,16 +354,18 @@ int build_lists(dxv_ctx* c)
     return 0;
 }
 
-int launch_now(dxv_ctx* c)
+int launch_now(dxv_ctx* c, uint32_t frame)
 {
+    Frame& f = c->frames[frame];
+    const hipStream_t fs = frame_stream(c, frame);
     VoxelizeParams p{};
     p.scene.nodes = scene_nodes32(c); p.scene.wide = c->hdr.hasWide ? scene_nodes64(c) : nullptr; p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
     memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
-    p.grid = c->dGrid; p.texels = c->texels ? c->dTexels : nullptr; p.status = c->dStatus;
-    p.redo = c->dRedo; p.redoCap = kRedoCap; p.redoParity = c->redoParity;
-    p.N = c->stats.grid_dim; p.z0 = c->stats.z0; p.nz = c->stats.nz; p.mode = c->lastMode;
-    p.zBlock = c->lastZBlock; p.zPeriod = c->lastZPeriod;
+    p.grid = f.dGrid; p.texels = c->texels ? f.dTexels : nullptr; p.status = f.dStatus;
+    p.redo = f.dRedo; p.redoCap = kRedoCap; p.redoParity = f.redoParity;
+    p.N = f.grid_dim; p.z0 = f.z0; p.nz = f.nz; p.mode = f.lastMode;
+    p.zBlock = f.lastZBlock; p.zPeriod = f.lastZPeriod;
     p.zShift = 0;
     while ((1u << p.zShift) < p.zBlock) ++p.zShift;
     p.morton = (uint32_t)c->optMorton;
@@ -330,7 +374,7 @@ int launch_now(dxv_ctx* c)
     p.subbox = (uint32_t)c->optSubbox;
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     int st = c->optStack ? c->optStack : c->stackNow;
-    c->stats.list_entries = 0; c->stats.list_res = 0;
+    f.list_entries = 0; f.list_res = 0;
     // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
     // builds them at the first launch.
@@ -338,7 +382,7 @@ int launch_now(dxv_ctx* c)
     if (p.mode == DXV_MODE_REFERENCE) ++c->launchesOfScene;
     if (wantLists) {
         if (c->listState == 0 || (c->listState != 0 && c->listOpt != c->optListRes)) {
-            if (build_lists(c)) return 1;
+            if (build_lists(c, fs)) return 1;
         }
         if (c->listState == 1) {
             p.lists = 1u;
@@ -346,11 +390,11 @@ int launch_now(dxv_ctx* c)
             p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
             st = 8;                                                 // no stack: the smallest column (the queue of selected triangles)
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
-            c->stats.list_entries = c->listEntries; c->stats.list_res = c->listRes; c->stats.list_ms = c->listMs;
+            f.list_entries = c->listEntries; f.list_res = c->listRes;
         }
     }
-    c->stats.stack_entries = (uint32_t)st;
-    DXV_HIP(c, hipEventRecord(c->ev[5], c->stream));
+    f.stack_entries = (uint32_t)st;
+    DXV_HIP(c, hipEventRecord(f.ev0, fs));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {
         // rows whose triangles span several voxels share a walk: 4 x 4 rows per wave above 1.5 voxels of
         // mean triangle extent, 2 x 2 above 1.2 -- as long as the launch still has enough waves to fill
@@ -364,20 +408,20 @@ int launch_now(dxv_ctx* c)
         if (voxels > 1.5f && waves(4) >= 12288u) rowBlock = 4;
         else if (voxels > 1.2f && waves(2) >= 12288u) rowBlock = 2;
         if (c->optRowBlock) rowBlock = c->optRowBlock;
-        c->stats.row_block = (uint32_t)rowBlock;
-        DXV_HIP(c, launch_parity_rows(p, rowBlock, c->stream));
-        c->lastRedoParity = -1;
+        f.row_block = (uint32_t)rowBlock;
+        DXV_HIP(c, launch_parity_rows(p, rowBlock, fs));
+        f.lastRedoParity = -1;
     } else {
-        DXV_HIP(c, launch_voxelize(p, c->optBrick, st, c->stream));
-        if (p.lists) c->lastRedoParity = -1;                        // no column to run out of, nothing to redo
+        DXV_HIP(c, launch_voxelize(p, c->optBrick, st, fs));
+        if (p.lists) f.lastRedoParity = -1;                        // no column to run out of, nothing to redo
         else {
-            DXV_HIP(c, launch_voxelize_redo(p, c->stream));
-            c->lastRedoParity = (int)c->redoParity;
-            c->redoParity ^= 1u;
+            DXV_HIP(c, launch_voxelize_redo(p, fs));
+            f.lastRedoParity = (int)f.redoParity;
+            f.redoParity ^= 1u;
         }
     }
-    DXV_HIP(c, hipEventRecord(c->ev[6], c->stream));
-    c->pending = true;
+    DXV_HIP(c, hipEventRecord(f.ev1, fs));
+    f.pending = true;
     return 0;
 }
 
@@ -405,13 +449,10 @@ int dxv_create(dxv_ctx** out, int device)
     for (auto& ev : c->ev) {
         if (hipEventCreate(&ev) != hipSuccess) { delete c; return fail(nullptr, "dxv_create: hipEventCreate failed"); }
     }
-    if (hipMalloc(&c->dStatus, 256) != hipSuccess || hipMalloc(&c->dCount, 256) != hipSuccess ||
-        hipMalloc(&c->dRedo, sizeof(uint64_t) * kRedoCap) != hipSuccess ||
-        hipMalloc(&c->dRootInfo, 256) != hipSuccess) {
-        delete c;
+    if (hipMalloc(&c->dCount, 256) != hipSuccess || hipMalloc(&c->dRootInfo, 256) != hipSuccess || frame_prepare(c, 0)) {
+        dxv_destroy(c);
         return fail(nullptr, "dxv_create: hipMalloc failed");
     }
-    (void)hipMemset(c->dStatus, 0, 256);
     *out = c;
     return 0;
 }
@@ -420,11 +461,18 @@ void dxv_destroy(dxv_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    for (uint32_t i = 0; i < DXV_FRAME_COUNT; ++i) {
+        Frame& f = c->frames[i];
+        if (frame_stream(c, i)) (void)hipStreamSynchronize(frame_stream(c, i));
+        (void)hipFree(f.dGrid); (void)hipFree(f.dTexels); (void)hipFree(f.dStatus); (void)hipFree(f.dRedo);
+        if (f.ev0) (void)hipEventDestroy(f.ev0);
+        if (f.ev1) (void)hipEventDestroy(f.ev1);
+        if (f.ownStream) (void)hipStreamDestroy(f.ownStream);
+    }
     free_scratch(c);
-    (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene); (void)hipFree(c->dGrid);
+    (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene);
     (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries);
-    (void)hipFree(c->dTexels); (void)hipFree(c->dStatus); (void)hipFree(c->dRedo); (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
+    (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -436,8 +484,19 @@ int dxv_set_stream(dxv_ctx* c, void* s)
 {
     if (!c) return 1;
     DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = s ? static_cast<hipStream_t>(s) : c->ownStream;
+    return 0;
+}
+
+int dxv_set_frame(dxv_ctx* c, uint32_t frame)
+{
+    if (!c) return 1;
+    if (frame >= DXV_FRAME_COUNT) return fail(c, "dxv_set_frame: frame %u out of range [0, %d)", frame, DXV_FRAME_COUNT);
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (frame_prepare(c, frame)) return 1;
+    c->cur = frame;
     return 0;
 }
 
@@ -471,6 +530,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
         return fail(c, "dxv_set_mesh: degenerate or non-finite bound (half extent %g)", (double)c->bound[3]);
 
     DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
@@ -544,6 +604,7 @@ int dxv_update_vertices(dxv_ctx* c, const float* vb, uint32_t V)
     if (!c->haveMesh || !c->dVb) return fail(c, "dxv_update_vertices: no mesh resident on this context");
     if (!vb || V != c->V) return fail(c, "dxv_update_vertices: vertex count must stay %u, got %u", c->V, V);
     DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dVb, vb, sizeof(float) * 6 * (size_t)V, hipMemcpyHostToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -555,6 +616,7 @@ int dxv_refit(dxv_ctx* c)
     if (!c->haveMesh || !c->haveScene || c->scratchT != c->T || !c->T)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
     c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
     if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
@@ -571,6 +633,7 @@ int dxv_build(dxv_ctx* c)
     if (!c) return 1;
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
     c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
@@ -598,23 +661,56 @@ int voxelize_common(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nzLo
     if (mode != DXV_MODE_REFERENCE && mode != DXV_MODE_PARITY) return fail(c, "dxv_voxelize: unknown mode %d", mode);
     if (c->texels && mode != DXV_MODE_REFERENCE) return fail(c, "dxv_voxelize: texel output exists in reference mode only");
     DXV_HIP(c, hipSetDevice(c->device));
+    Frame& f = cur_frame(c);
+    const hipStream_t fs = cur_stream(c);
+    if (f.pending && sync_frame(c, c->cur)) return 1;     // the frame's previous launch is checked before its grid is reused
     const size_t bytes = (size_t)N * N * nzLocal;
-    if (bytes > c->gridCap) {
-        DXV_HIP(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->dGrid); c->dGrid = nullptr; c->gridCap = 0;
-        DXV_HIP(c, hipMalloc(&c->dGrid, align256(bytes)));
-        c->gridCap = bytes;
+    if (bytes > f.gridCap) {
+        DXV_HIP(c, hipStreamSynchronize(fs));
+        (void)hipFree(f.dGrid); f.dGrid = nullptr; f.gridCap = 0;
+        DXV_HIP(c, hipMalloc(&f.dGrid, align256(bytes)));
+        f.gridCap = bytes;
     }
-    if (c->texels && bytes > c->texelCap) {
-        DXV_HIP(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->dTexels); c->dTexels = nullptr; c->texelCap = 0;
-        DXV_HIP(c, hipMalloc(&c->dTexels, align256(bytes * 4)));
-        c->texelCap = bytes;
+    if (c->texels && bytes > f.texelCap) {
+        DXV_HIP(c, hipStreamSynchronize(fs));
+        (void)hipFree(f.dTexels); f.dTexels = nullptr; f.texelCap = 0;
+        DXV_HIP(c, hipMalloc(&f.dTexels, align256(bytes * 4)));
+        f.texelCap = bytes;
     }
-    c->gridBytes = bytes;
-    c->stats.grid_dim = N; c->stats.z0 = z0; c->stats.nz = nzLocal;
-    c->lastMode = mode; c->lastZBlock = zBlock; c->lastZPeriod = zPeriod;
-    return launch_now(c);
+    f.gridBytes = bytes;
+    f.grid_dim = N; f.z0 = z0; f.nz = nzLocal;
+    f.lastMode = mode; f.lastZBlock = zBlock; f.lastZPeriod = zPeriod;
+    return launch_now(c, c->cur);
+}
+
+// dxv_sync of one frame: wait for its stream, read its status words, redo the launch with a deeper column if asked to
+int sync_frame(dxv_ctx* c, uint32_t i)
+{
+    Frame& f = c->frames[i];
+    const hipStream_t fs = frame_stream(c, i);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        uint32_t words[3] = {0, 0, 0};
+        DXV_HIP(c, hipMemcpyAsync(words, f.dStatus, sizeof(words), hipMemcpyDeviceToHost, fs));
+        DXV_HIP(c, hipStreamSynchronize(fs));
+        const uint32_t status = words[0];
+        if (f.pending) {
+            f.voxelize_ms = elapsed(f.ev0, f.ev1);
+            f.redo_rays = f.lastRedoParity < 0 ? 0u : words[1 + f.lastRedoParity];
+        }
+        f.pending = false;
+        if (!status) return 0;
+        DXV_HIP(c, hipMemsetAsync(f.dStatus, 0, sizeof(uint32_t), fs));
+        if (!c->optStack && c->stackNow < safe_stack(c, f.lastMode) && c->haveScene && f.grid_dim) {
+            // grow to the next instantiated depth (at most up to the depth that cannot overflow) and redo
+            const int next = stack_round_up(c->stackNow + 1);
+            c->stackNow = next < safe_stack(c, f.lastMode) ? next : safe_stack(c, f.lastMode);
+            if (launch_now(c, i)) return 1;
+            continue;
+        }
+        return fail(c, "voxelize kernel reported status 0x%x (traversal stack overflow: tree height %u, stack %u)",
+                    status, c->hdr.treeHeight, f.stack_entries);
+    }
+    return 0;
 }
 } // namespace
 
@@ -646,29 +742,14 @@ int dxv_sync(dxv_ctx* c)
 {
     if (!c) return 1;
     DXV_HIP(c, hipSetDevice(c->device));
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        uint32_t words[3] = {0, 0, 0};
-        DXV_HIP(c, hipMemcpyAsync(words, c->dStatus, sizeof(words), hipMemcpyDeviceToHost, c->stream));
-        DXV_HIP(c, hipStreamSynchronize(c->stream));
-        const uint32_t status = words[0];
-        if (c->pending) {
-            c->stats.voxelize_ms = elapsed(c->ev[5], c->ev[6]);
-            c->stats.redo_rays = c->lastRedoParity < 0 ? 0u : words[1 + c->lastRedoParity];
-        }
-        c->pending = false;
-        if (!status) return 0;
-        DXV_HIP(c, hipMemsetAsync(c->dStatus, 0, sizeof(uint32_t), c->stream));
-        if (!c->optStack && c->stackNow < safe_stack(c) && c->haveScene && c->stats.grid_dim) {
-            // grow to the next instantiated depth (at most up to the depth that cannot overflow) and redo
-            const int next = stack_round_up(c->stackNow + 1);
-            c->stackNow = next < safe_stack(c) ? next : safe_stack(c);
-            if (launch_now(c)) return 1;
-            continue;
-        }
-        return fail(c, "voxelize kernel reported status 0x%x (traversal stack overflow: tree height %u, stack %u)",
-                    status, c->hdr.treeHeight, c->stats.stack_entries);
-    }
-    return 0;
+    return sync_frame(c, c->cur);
+}
+
+int dxv_sync_all(dxv_ctx* c)
+{
+    if (!c) return 1;
+    DXV_HIP(c, hipSetDevice(c->device));
+    return sync_frames(c);
 }
 
 int dxv_voxelize(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nz)
@@ -681,10 +762,13 @@ int dxv_render(dxv_ctx* c, const float eye[3], const float viewProj[16], const f
                uint32_t height, uint8_t* rgbaHost)
 {
     if (!c) return 1;
+    Frame& f = cur_frame(c);
+    const hipStream_t fs = cur_stream(c);
+    (void)fs;
     if (!eye || !viewProj || !rgbaHost || !width || !height || width > 16384 || height > 16384)
         return fail(c, "dxv_render: bad arguments");
-    const uint32_t N = c->stats.grid_dim;
-    if (!c->dGrid || !N || c->stats.z0 != 0 || c->stats.nz != N || c->lastZBlock != N)
+    const uint32_t N = f.grid_dim;
+    if (!f.dGrid || !N || f.z0 != 0 || f.nz != N || f.lastZBlock != N)
         return fail(c, "dxv_render: needs the whole grid of the last dxv_voxelize (z0 = 0, nz = grid_dim) on this context");
     const float unit[4] = {0.0f, 0.0f, 0.0f, 1.0f};                 // DXRVoxelizer.cpp:37
     RayCastCB cb;
@@ -693,73 +777,82 @@ int dxv_render(dxv_ctx* c, const float eye[3], const float viewProj[16], const f
     DXV_HIP(c, hipSetDevice(c->device));
     const size_t pixels = (size_t)width * height;
     if (pixels > c->imageCap) {
-        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        DXV_HIP(c, hipStreamSynchronize(fs));
         (void)hipFree(c->dImage); c->dImage = nullptr; c->imageCap = 0;
         DXV_HIP(c, hipMalloc(&c->dImage, pixels * 4));
         c->imageCap = pixels;
     }
     if (c->optSkipEmpty && empty_brick_bytes(N) > c->emptyCap) {
-        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        DXV_HIP(c, hipStreamSynchronize(fs));
         (void)hipFree(c->dEmpty); c->dEmpty = nullptr; c->emptyCap = 0;
         DXV_HIP(c, hipMalloc(&c->dEmpty, align256(empty_brick_bytes(N))));
         c->emptyCap = empty_brick_bytes(N);
     }
     if (dxv_sync(c)) return 1;                                       // the grid must be complete and valid
-    DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
-    DXV_HIP(c, launch_raycast(cb, c->dGrid, N, width, height, c->dImage, c->optSkipEmpty ? c->dEmpty : nullptr, c->stream));
-    DXV_HIP(c, hipEventRecord(c->ev[9], c->stream));
-    DXV_HIP(c, hipMemcpyAsync(rgbaHost, c->dImage, pixels * 4, hipMemcpyDeviceToHost, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    DXV_HIP(c, hipEventRecord(c->ev[8], fs));
+    DXV_HIP(c, launch_raycast(cb, f.dGrid, N, width, height, c->dImage, c->optSkipEmpty ? c->dEmpty : nullptr, fs));
+    DXV_HIP(c, hipEventRecord(c->ev[9], fs));
+    DXV_HIP(c, hipMemcpyAsync(rgbaHost, c->dImage, pixels * 4, hipMemcpyDeviceToHost, fs));
+    DXV_HIP(c, hipStreamSynchronize(fs));
     c->renderMs = elapsed(c->ev[8], c->ev[9]);
     c->stats.render_ms = c->renderMs;
     return 0;
 }
 
-void* dxv_grid_device_ptr(dxv_ctx* c) { return c ? c->dGrid : nullptr; }
-size_t dxv_grid_bytes(const dxv_ctx* c) { return c ? c->gridBytes : 0; }
+void* dxv_grid_device_ptr(dxv_ctx* c) { return c ? cur_frame(c).dGrid : nullptr; }
+size_t dxv_grid_bytes(const dxv_ctx* c) { return c ? c->frames[c->cur].gridBytes : 0; }
 
 int dxv_grid_download(dxv_ctx* c, uint8_t* host, size_t bytes)
 {
     if (!c) return 1;
-    if (!host || bytes != c->gridBytes || !c->gridBytes) return fail(c, "dxv_grid_download: expected %zu bytes, got %zu", c->gridBytes, bytes);
-    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
+    Frame& f = cur_frame(c);
+    const hipStream_t fs = cur_stream(c);
+    (void)fs;
+    if (!host || bytes != f.gridBytes || !f.gridBytes) return fail(c, "dxv_grid_download: expected %zu bytes, got %zu", f.gridBytes, bytes);
+    if (f.pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
-    DXV_HIP(c, hipMemcpyAsync(host, c->dGrid, bytes, hipMemcpyDeviceToHost, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    DXV_HIP(c, hipMemcpyAsync(host, f.dGrid, bytes, hipMemcpyDeviceToHost, fs));
+    DXV_HIP(c, hipStreamSynchronize(fs));
     return 0;
 }
 
-size_t dxv_grid_packed_bytes(const dxv_ctx* c) { return c ? (c->gridBytes + 7) / 8 : 0; }
+size_t dxv_grid_packed_bytes(const dxv_ctx* c) { return c ? (c->frames[c->cur].gridBytes + 7) / 8 : 0; }
 
 int dxv_grid_download_packed(dxv_ctx* c, uint8_t* host, size_t bytes)
 {
     if (!c) return 1;
-    const size_t want = (c->gridBytes + 7) / 8;
+    Frame& f = cur_frame(c);
+    const hipStream_t fs = cur_stream(c);
+    (void)fs;
+    const size_t want = (f.gridBytes + 7) / 8;
     if (!host || !want || bytes != want) return fail(c, "dxv_grid_download_packed: expected %zu bytes, got %zu", want, bytes);
-    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
+    if (f.pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
     if (want > c->packedCap) {
-        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        DXV_HIP(c, hipStreamSynchronize(fs));
         (void)hipFree(c->dPacked); c->dPacked = nullptr; c->packedCap = 0;
         DXV_HIP(c, hipMalloc(&c->dPacked, align256(want)));
         c->packedCap = want;
     }
-    DXV_HIP(c, launch_pack_bits(c->dGrid, c->gridBytes, c->dPacked, c->stream));
-    DXV_HIP(c, hipMemcpyAsync(host, c->dPacked, want, hipMemcpyDeviceToHost, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    DXV_HIP(c, launch_pack_bits(f.dGrid, f.gridBytes, c->dPacked, fs));
+    DXV_HIP(c, hipMemcpyAsync(host, c->dPacked, want, hipMemcpyDeviceToHost, fs));
+    DXV_HIP(c, hipStreamSynchronize(fs));
     return 0;
 }
 
 int dxv_grid_count(dxv_ctx* c, uint64_t* solid)
 {
     if (!c) return 1;
-    if (!solid || !c->gridBytes) return fail(c, "dxv_grid_count: no grid");
-    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
+    Frame& f = cur_frame(c);
+    const hipStream_t fs = cur_stream(c);
+    (void)fs;
+    if (!solid || !f.gridBytes) return fail(c, "dxv_grid_count: no grid");
+    if (f.pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
-    DXV_HIP(c, launch_count(c->dGrid, c->gridBytes, c->dCount, c->stream));
+    DXV_HIP(c, launch_count(f.dGrid, f.gridBytes, c->dCount, fs));
     unsigned long long v = 0;
-    DXV_HIP(c, hipMemcpyAsync(&v, c->dCount, sizeof(v), hipMemcpyDeviceToHost, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    DXV_HIP(c, hipMemcpyAsync(&v, c->dCount, sizeof(v), hipMemcpyDeviceToHost, fs));
+    DXV_HIP(c, hipStreamSynchronize(fs));
     *solid = v;
     return 0;
 }
@@ -774,12 +867,15 @@ int dxv_enable_texels(dxv_ctx* c, int enable)
 int dxv_texels_download(dxv_ctx* c, uint32_t* host, size_t bytes)
 {
     if (!c) return 1;
-    if (!c->texels || !c->dTexels) return fail(c, "dxv_texels_download: texel output not enabled");
-    if (!host || bytes != c->gridBytes * 4) return fail(c, "dxv_texels_download: expected %zu bytes, got %zu", c->gridBytes * 4, bytes);
-    if (c->pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
+    Frame& f = cur_frame(c);
+    const hipStream_t fs = cur_stream(c);
+    (void)fs;
+    if (!c->texels || !f.dTexels) return fail(c, "dxv_texels_download: texel output not enabled");
+    if (!host || bytes != f.gridBytes * 4) return fail(c, "dxv_texels_download: expected %zu bytes, got %zu", f.gridBytes * 4, bytes);
+    if (f.pending && dxv_sync(c)) return 1;          // an unchecked launch: finish it (and its redo, if any) first
     DXV_HIP(c, hipSetDevice(c->device));
-    DXV_HIP(c, hipMemcpyAsync(host, c->dTexels, bytes, hipMemcpyDeviceToHost, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    DXV_HIP(c, hipMemcpyAsync(host, f.dTexels, bytes, hipMemcpyDeviceToHost, fs));
+    DXV_HIP(c, hipStreamSynchronize(fs));
     return 0;
 }
 
@@ -810,6 +906,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
         h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.hasWide > 1u || h.treeHeight == 0 || h.treeHeight > 64)
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
+    if (sync_frames(c)) return 1;
     c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
@@ -837,6 +934,10 @@ int dxv_get_stats(const dxv_ctx* c, dxv_stats* out)
 {
     if (!c || !out) return 1;
     *out = c->stats;
+    const Frame& f = c->frames[c->cur];
+    out->voxelize_ms = f.voxelize_ms; out->grid_dim = f.grid_dim; out->z0 = f.z0; out->nz = f.nz;
+    out->stack_entries = f.stack_entries; out->redo_rays = f.redo_rays; out->row_block = f.row_block;
+    out->list_entries = f.list_entries; out->list_res = f.list_res; out->list_ms = c->listMs;
     return 0;
 }
 
@@ -869,6 +970,7 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
         c->optLists = (int)value;
     } else if (!strcmp(key, "listres")) {
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option listres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
+        if (c->optListRes != (int)value && sync_frames(c)) return 1;     // the next launch rebuilds the lists: nothing may still read them
         c->optListRes = (int)value;
     } else if (!strcmp(key, "ablate")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8}", (long long)value);

@@ -40,7 +40,8 @@ class Voxelizer:
         if self._lib.dxv_create(C.byref(self._ctx), int(device)):
             raise DxvError(self._lib.dxv_last_error(None).decode())
         self.device = int(device)
-        self._last = None
+        self._frame = 0
+        self._lasts = {}
 
     # ---- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -82,23 +83,41 @@ class Voxelizer:
             self._check(self._lib.dxv_refit(self._ctx))
         return True
 
-    def Voxelize(self, gridDim, mode=MODE_REFERENCE, z0=0, nz=None, sync=True):
-        """Voxelizer::voxelize (Content/Voxelizer.cpp:351-369) with gridDim as a parameter."""
+    def SetFrame(self, frameIndex):
+        """The frame (0 .. FrameCount-1) the following Voxelize / Sync / Grid / Texels / Render / stats calls refer
+        to: the reference's frameIndex argument (Content/Voxelizer.h:20-22) and its m_grids[FrameCount] (:110)."""
+        self._check(self._lib.dxv_set_frame(self._ctx, int(frameIndex)))
+        self._frame = int(frameIndex)
+
+    def Voxelize(self, gridDim, mode=MODE_REFERENCE, z0=0, nz=None, sync=True, frameIndex=None):
+        """Voxelizer::voxelize(pCommandList, frameIndex) (Content/Voxelizer.cpp:351-369) with gridDim as a parameter."""
+        if frameIndex is not None:
+            self.SetFrame(frameIndex)
         nz = gridDim - z0 if nz is None else nz
         fn = self._lib.dxv_voxelize if sync else self._lib.dxv_voxelize_async
         self._check(fn(self._ctx, int(gridDim), int(mode), int(z0), int(nz)))
-        self._last = (int(gridDim), int(nz))
+        self._lasts[self._frame] = (int(gridDim), int(nz))
         return True
 
-    def VoxelizeInterleaved(self, gridDim, rank, world, zblock=8, mode=MODE_REFERENCE, sync=True):
+    def VoxelizeInterleaved(self, gridDim, rank, world, zblock=8, mode=MODE_REFERENCE, sync=True, frameIndex=None):
         """This rank's share of a block-cyclic Z partition (dxv_voxelize_interleaved)."""
+        if frameIndex is not None:
+            self.SetFrame(frameIndex)
         fn = self._lib.dxv_voxelize_interleaved if sync else self._lib.dxv_voxelize_interleaved_async
         self._check(fn(self._ctx, int(gridDim), int(mode), int(rank), int(world), int(zblock)))
-        self._last = (int(gridDim), int(gridDim) // int(world))
+        self._lasts[self._frame] = (int(gridDim), int(gridDim) // int(world))
         return True
 
     def Sync(self):
         self._check(self._lib.dxv_sync(self._ctx))
+
+    def SyncAll(self):
+        """Wait for the launches of every frame (dxv_sync_all)."""
+        self._check(self._lib.dxv_sync_all(self._ctx))
+
+    @property
+    def _last(self):
+        return self._lasts.get(self._frame)
 
     # ---- the grid's consumer (Voxelizer::UpdateFrame + Render's ray-cast pass) -----------------
     def Render(self, eyePt, viewProj, width=1280, height=720, posScale=None):

@@ -118,6 +118,19 @@ DXV_API int dxv_voxelize(dxv_ctx* ctx, uint32_t grid_dim, int mode, uint32_t z0,
 DXV_API int dxv_voxelize_async(dxv_ctx* ctx, uint32_t grid_dim, int mode, uint32_t z0, uint32_t nz);
 DXV_API int dxv_sync(dxv_ctx* ctx);
 
+/* Frames in flight: the reference's Voxelizer owns FrameCount = 3 grids and every per-frame call takes a
+ * frameIndex (static const uint8_t FrameCount, Content/Voxelizer.h:24; m_grids[FrameCount], :110;
+ * Render(pCommandList, frameIndex, ...), :21-22; voxelize(pCommandList, frameIndex), Content/Voxelizer.cpp:351-356),
+ * so that the GPU works on one grid while the host still reads another.  dxv_set_frame selects the frame the
+ * following dxv_voxelize* / dxv_sync / dxv_grid_* / dxv_texels_download / dxv_render / dxv_get_stats calls refer to
+ * (default 0).  Each frame owns its grid, texel image, status words and -- frames 1 and 2 -- an internal stream,
+ * so launches of different frames overlap on the GPU; scene, candidate lists and options are shared (an extra frame
+ * costs its grid).  Calls that change what the frames read (dxv_set_mesh, dxv_build, dxv_refit, dxv_update_vertices,
+ * dxv_scene_import, dxv_set_stream) first wait for every frame; dxv_sync_all does only that. */
+#define DXV_FRAME_COUNT 3
+DXV_API int dxv_set_frame(dxv_ctx* ctx, uint32_t frame_index);
+DXV_API int dxv_sync_all(dxv_ctx* ctx);
+
 /* Load-balanced multi-GPU partition: the grid's Z axis is cut into blocks of `zblock` slices dealt
  * round-robin to `world` ranks; this call voxelizes the grid_dim/world slices of `rank` (global
  * slice of local slice lz: (lz / zblock * world + rank) * zblock + lz % zblock, ascending) into a

@@ -59,6 +59,18 @@ public:
 		return dxv_voxelize(m_ctx, gridDim, mode, z0, nz) == 0;
 	}
 
+	// Frames in flight, as the reference's per-frame calls take a frameIndex (Content/Voxelizer.h:20-22) and the
+	// component owns FrameCount grids (:24, :110): VoxelizeAsync(frameIndex, ...) launches into that frame's grid on
+	// that frame's stream and returns; WaitFrame(frameIndex) waits for it and reports a deferred kernel error.
+	// Download / DownloadBits / CountSolid / DeviceGrid / Render then refer to the frame last selected.
+	bool SetFrame(uint8_t frameIndex) { return m_ctx ? dxv_set_frame(m_ctx, frameIndex) == 0 : setError("SetFrame before Init"); }
+	bool VoxelizeAsync(uint8_t frameIndex, uint32_t gridDim, Mode mode = REFERENCE)
+	{
+		return SetFrame(frameIndex) && dxv_voxelize_async(m_ctx, gridDim, mode, 0, gridDim) == 0;
+	}
+	bool WaitFrame(uint8_t frameIndex) { return SetFrame(frameIndex) && dxv_sync(m_ctx) == 0; }
+	bool WaitAll() { return m_ctx && dxv_sync_all(m_ctx) == 0; }
+
 	// Dynamic meshes: new vertex data on the same topology, refit of the existing hierarchy.
 	bool UpdateVertices(const float* vb, uint32_t numVerts)
 	{
@@ -102,7 +114,7 @@ public:
 	const char* LastError() const { return m_ctx && *dxv_last_error(m_ctx) ? dxv_last_error(m_ctx) : m_err.c_str(); }
 	dxv_ctx* Context() { return m_ctx; }
 
-	static const uint8_t FrameCount = 3; // Content/Voxelizer.h:24 (kept for source compatibility)
+	static const uint8_t FrameCount = DXV_FRAME_COUNT; // Content/Voxelizer.h:24: grids (frames) the component owns
 
 protected:
 	bool setError(const char* msg) { m_err = msg ? msg : ""; return false; }

@@ -356,6 +356,54 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     a.close(), b.close()
 
 
+def test_frames_in_flight_share_one_scene(dxv, orc, bunny, dragon):
+    """FrameCount grids per context (Content/Voxelizer.h:24, :110): launches of different frames overlap on their
+    own streams, read ONE scene and ONE set of lists, and every frame's grid is the oracle's."""
+    vb, ib, _ = bunny
+    v = dxv.Voxelizer(0)
+    assert v.FrameCount == 3
+    v.set_option("lists", 2)
+    v.InitFromArrays(vb, ib)
+    s = orc.Scene(vb, ib)
+    jobs = [(64, 0), (96, 1), (128, 0)]
+    for rounds in range(3):                                # back to back, no host sync in between
+        for f, (N, mode) in enumerate(jobs):
+            v.Voxelize(N, mode, sync=False, frameIndex=f)
+    v.SyncAll()
+    for f, (N, mode) in enumerate(jobs):
+        v.SetFrame(f)
+        assert np.array_equal(v.Grid(), s.voxelize(N, mode=mode)), f
+        assert v.CountSolid() == int(s.voxelize(N, mode=mode).sum())
+        st = v.stats()
+        assert (st["grid_dim"], st["voxelize_ms"] > 0) == (N, True)
+    v.SetFrame(0)
+    e0 = v.stats()["list_entries"]
+    v.SetFrame(2)
+    assert v.stats()["list_entries"] == e0 > 0             # one set of lists serves both frames
+    # a scene change with launches still in flight waits for them; afterwards every frame sees the new scene
+    for f in range(3):
+        v.Voxelize(128, 0, sync=False, frameIndex=f)
+    vb2, ib2, _ = dragon
+    v.InitFromArrays(vb2, ib2)
+    want = orc.Scene(vb2, ib2).voxelize(64)
+    for f in (2, 0, 1):
+        v.Voxelize(64, 0, sync=False, frameIndex=f)
+    for f in range(3):
+        v.SetFrame(f)
+        assert np.array_equal(v.Grid(), want), f           # Grid() finishes the frame's pending launch itself
+    # slabs and the block-cyclic partition per frame
+    v.Voxelize(64, 0, 16, 20, sync=False, frameIndex=1)
+    v.VoxelizeInterleaved(64, 1, 2, 8, sync=False, frameIndex=2)
+    v.SetFrame(1)
+    assert np.array_equal(v.Grid(), want[16:36])
+    v.SetFrame(2)
+    from dxrvoxelizer_amd.slabs import interleaved_slices
+    assert np.array_equal(v.Grid(), want[interleaved_slices(64, 1, 2, 8)])
+    with pytest.raises(dxv.DxvError):
+        v.SetFrame(3)
+    v.close()
+
+
 def test_import_over_a_built_context_drops_its_mesh_state(dxv, orc, bunny, dragon):
     """A context that built a SMALL mesh and then imports a bigger scene must not run build / refit / vertex
     updates over the old buffers: they fail cleanly, and the imported scene voxelizes like its source."""
