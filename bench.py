@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 512] [--mesh torus1m]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Called as `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment, this process touches no GPU: it
+starts the N ranks as a child `python -m torch.distributed.run` (127.0.0.1 rendezvous), waits and relays rank 0's line.
+
 A step = one Voxelize pass (the reference's per-frame DispatchRays, Content/Voxelizer.cpp:366)
 over the whole grid with the scene already resident in HBM: the BVH is built once in Init like
 the reference's acceleration structure (Content/Voxelizer.cpp:73) and is reported separately.
@@ -72,6 +75,37 @@ def cpu_baseline(vb, ib, N, mode, budget_s=15.0):
                       f"oracle BVH traversal, OpenMP over rows, {cores} threads (cgroup quota / affinity)"}
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the ranks as a child process BEFORE anything here has
+    touched the GPU (no torch import, no HIP call in this process), wait, relay rank 0's JSON line and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        try:
+            if isinstance(json.loads(ln), dict) and "metric" in ln:
+                line = ln
+                continue
+        except ValueError:
+            pass
+        print(ln, file=sys.stderr)                         # anything else the ranks wrote to stdout
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode == 0 and line is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,25 +117,50 @@ def main():
     ap.add_argument("--brick", type=int, default=-1)
     ap.add_argument("--stack", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (frames in flight, tree walk, second rule, bunny x16)")
     ap.add_argument("--interleave", action="store_true", help="use the block-cyclic partition call even on one GPU")
-    ap.add_argument("--frames", type=int, default=0,
-                    help="voxelizations in flight per GPU, each on its own context and stream (the reference keeps FrameCount = 3 grids in flight); 0 = 2 when N > 1, else 1")
+    ap.add_argument("--frames", type=int, default=1,
+                    help="voxelizations in flight per GPU in the headline region (frames of ONE context, dxv_set_frame; the "
+                         "reference keeps FrameCount = 3 grids in flight).  Default 1 at every N, so that values at different "
+                         "N compare like for like; the two-in-flight figure is reported beside it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing test without a GPU: ranks rendezvous, reduce and print the line, no voxelizer (needs --backend gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
 
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
+    if args.dry_run:
+        if use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if use_dist:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mvoxels/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "config": {"rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": args.backend,
+                                         "rank_sum": float(t.item())}}), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import dxrvoxelizer_amd as dxv
     from dxrvoxelizer_amd.slabs import broadcast_scene, slab_range
@@ -111,7 +170,6 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)   # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -121,7 +179,7 @@ def main():
 
     N, mode = args.grid, (dxv.MODE_REFERENCE if args.mode == "reference" else dxv.MODE_PARITY)
     vox = dxv.Voxelizer(local_rank)
-    stream = torch.cuda.Stream()                 # a real (non-null) stream: kernels, torch events and
+    stream = torch.cuda.Stream()                 # a real (non-null) stream: frame 0's kernels, torch events and
     torch.cuda.set_stream(stream)                # RCCL all share it
     vox.set_stream(stream.cuda_stream)
     vox.set_option("lists", 2)       # candidate lists from a scene's first launch on: their build stays in the warm-up (config.candidates.build_ms)
@@ -144,31 +202,6 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         bcast_ms = (time.perf_counter() - t0) * 1e3
-    # Frames in flight.  A rank's share of the grid is a short launch (0.35 ms at 8 GPUs) whose tail --
-    # the last long rays running alone -- is a third of it; the reference hides the same thing by keeping
-    # FrameCount = 3 grids in flight (Content/Voxelizer.h:24).  Here: `frames` contexts per GPU, each with
-    # its own stream and grid and a copy of the scene, taking the steps in turn.
-    frames = args.frames if args.frames > 0 else (2 if world > 1 else 1)
-    voxes, streams = [vox], [stream]
-    if frames > 1:
-        n = vox.scene_bytes()
-        blob = torch.empty(n, dtype=torch.uint8, device="cuda")
-        vox.scene_export(blob.data_ptr(), n)
-        torch.cuda.synchronize()
-        for _ in range(frames - 1):
-            s2 = torch.cuda.Stream()
-            v2 = dxv.Voxelizer(local_rank)
-            v2.set_stream(s2.cuda_stream)
-            v2.set_option("lists", 2)
-            if args.brick >= 0:
-                v2.set_option("brick", args.brick)
-            if args.stack >= 0:
-                v2.set_option("stack", args.stack)
-            v2.scene_import(blob.data_ptr(), n)
-            voxes.append(v2)
-            streams.append(s2)
-        torch.cuda.synchronize()
-        del blob
     st0 = vox.stats()
     T, V = st0["num_tris"], st0["num_verts"]
 
@@ -180,62 +213,106 @@ def main():
     if interleave:
         nz = N // world
 
-    turn = [0]
+    def timed_region(frames, steps, warmup):
+        """`steps` steps with `frames` voxelizations in flight (frames of the one context, taking the steps in turn),
+        barrier + synchronize on both sides; (wall seconds, mean kernel ms).  A rank's share of the grid is a short
+        launch whose tail -- its last long rays running alone -- does not shrink with it; the reference hides the same
+        thing by keeping FrameCount = 3 grids in flight (Content/Voxelizer.h:24)."""
+        turn = [0]
 
-    def step():
-        v = voxes[turn[0] % frames]
-        turn[0] += 1
-        if interleave:
-            v.VoxelizeInterleaved(N, rank, world, zblock, mode, sync=False)
-        elif nz:
-            v.Voxelize(N, mode, z0, nz, sync=False)
+        def step():
+            f = turn[0] % frames
+            turn[0] += 1
+            if interleave:
+                vox.VoxelizeInterleaved(N, rank, world, zblock, mode, sync=False, frameIndex=f)
+            elif nz:
+                vox.Voxelize(N, mode, z0, nz, sync=False, frameIndex=f)
 
-    for _ in range(max(args.warmup, frames)):        # every context launches at least once before the clock starts
-        step()
-    for v in voxes:
-        v.Sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    for v in voxes:
-        v.Sync()                                 # deferred kernel status (stack overflow) is an error
-    if frames == 1:
-        kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)   # avg launch duration on the kernel's stream
-    else:                                        # overlapping launches: the library's own events around each context's last launch
-        kernel_ms = float(np.mean([v.stats()["voxelize_ms"] for v in voxes]))
-    st_run = vox.stats()                         # of the timed rule (the other rule below overwrites the launch fields)
+        for _ in range(max(warmup, frames)):     # every frame launches at least once before the clock starts
+            step()
+        vox.SyncAll()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(steps):
+            step()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        vox.SyncAll()                            # deferred kernel status (stack overflow) is an error
+        if frames == 1:
+            k_ms = ev0.elapsed_time(ev1) / max(steps, 1)         # avg launch duration on the kernel's stream
+        else:                                    # overlapping launches: the library's own events around each frame's last launch
+            ks = []
+            for f in range(frames):
+                vox.SetFrame(f)
+                ks.append(vox.stats()["voxelize_ms"])
+            k_ms = float(np.mean(ks))
+        vox.SetFrame(0)
+        return dt, k_ms
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    frames = max(1, min(args.frames, vox.FrameCount))
+    dt, kernel_ms = timed_region(frames, args.steps, args.warmup)
+    dt_max = reduce_max(dt)
+    kmax = reduce_max(kernel_ms)
+    st_run = vox.stats()                         # of the timed rule (the extras below overwrite the launch fields)
     solid = vox.CountSolid() if nz else 0
-    other_ms = None
-    if world == 1:                               # the second occupancy rule on the same scene, for the record
-        om = dxv.MODE_PARITY if mode == dxv.MODE_REFERENCE else dxv.MODE_REFERENCE
-        vox.Voxelize(N, om)
-        ts = []
-        for _ in range(5):
-            vox.Voxelize(N, om)
-            ts.append(vox.stats()["voxelize_ms"])
-        other_ms = float(np.median(ts))
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(solid)], dtype=torch.float64, device="cuda")
-    kmax = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
     if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+
+    extras = {}
+    if not args.no_extras:
+        # the same steps with two voxelizations in flight per GPU, at every N (like-for-like ratios across N)
+        other = 2 if frames == 1 else 1
+        dt2, k2 = timed_region(other, args.steps, 2)
+        dt2 = reduce_max(dt2)
+        extras[f"frames_in_flight_{other}"] = {"value": (N ** 3) * args.steps / dt2 / 1e6, "unit": "Mvoxels/s",
+                                               "ms_per_step": dt2 / args.steps * 1e3, "kernel_ms": reduce_max(k2)}
+    if world == 1 and not args.no_extras:
+
+        def median_ms(m, reps=5):
+            vox.Voxelize(N, m)
+            ts = []
+            for _ in range(reps):
+                vox.Voxelize(N, m)
+                ts.append(vox.stats()["voxelize_ms"])
+            return float(np.median(ts))
+
+        om = dxv.MODE_PARITY if mode == dxv.MODE_REFERENCE else dxv.MODE_REFERENCE
+        other_ms = median_ms(om)                 # the second occupancy rule on the same scene, for the record
+        extras["other_rule"] = {"mode": "parity" if args.mode == "reference" else "reference", "ms": other_ms,
+                                "mvoxels_s": N ** 3 / other_ms / 1e3}
+        if mode == dxv.MODE_REFERENCE:
+            # the kernel north_star describes (LBVH walk, LDS stack, ballot vote) on the same scene
+            vox.set_option("lists", 0)
+            tw = median_ms(mode)
+            vox.set_option("lists", 2)
+            extras["tree_walk_ms"] = tw
+            extras["tree_walk_mvoxels_s"] = N ** 3 / tw / 1e3
+            if args.mesh == "torus1m":
+                # the other "1 M-triangle mesh" BASELINE.md names (no part of its grid is cleared by the partial launch)
+                bvb, bib, blabel = make_mesh("bunny16")
+                vox.InitFromArrays(bvb, bib)
+                lm = median_ms(mode)
+                vox.set_option("lists", 0)
+                tm = median_ms(mode)
+                vox.set_option("lists", 2)
+                extras["bunny16"] = {"workload": f"{blabel}, {N}^3, reference predicate", "ms": lm, "mvoxels_s": N ** 3 / lm / 1e3,
+                                     "tree_walk_ms": tm, "tree_walk_mvoxels_s": N ** 3 / tm / 1e3}
 
     if rank == 0:
-        st = vox.stats()
         value = (N ** 3) * args.steps / dt_max / 1e6
         bytes_launch = algorithmic_bytes(N, nz, T, V)
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
@@ -259,24 +336,22 @@ def main():
                                                            if interleave else f"Z-slab partition over {world} GPU(s)"),
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
                        "slab_slices_rank0": nz, "frames_in_flight": frames, "solid_voxels": int(tot.item()),
-                       "tree_height": st["tree_height"], "stack_entries": st_run["stack_entries"],
+                       "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": args.backend if use_dist else None,
+                       "tree_height": st0["tree_height"], "stack_entries": st_run["stack_entries"],
                        "candidates": ({"structure": "direction-space lists", "texels_per_face_side": st_run["list_res"],
                                        "entries": st_run["list_entries"], "build_ms": st_run["list_ms"]}
                                       if st_run.get("list_entries") else {"structure": "LBVH walk"}),
                        "build_ms": st0["build_ms"], "build_stages_ms": {k: st0[k] for k in
                                                                        ("prep_ms", "sort_ms", "hierarchy_ms", "refit_ms")},
                        "upload_ms": st0["upload_ms"], "scene_broadcast_ms": bcast_ms,
-                       "kernel_ms_max_over_ranks": float(kmax.item()),
-                       "other_rule": None if other_ms is None else {
-                           "mode": "parity" if args.mode == "reference" else "reference", "ms": other_ms,
-                           "mvoxels_s": N ** 3 / other_ms / 1e3}},
+                       "kernel_ms_max_over_ranks": kmax, **extras},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); the kernel "
-                                 "is bound by vector-L1 line accesses (~80 % of its cycles), not by bandwidth: compulsory HBM bytes are "
-                                 "~2 % of what 8 TB/s moves in its run time (profiles/r01/final/pmc_summary.json, DESIGN.md section 4)"},
+                                 "is not bound by bandwidth: compulsory HBM bytes are a few per cent of what 8 TB/s moves in its "
+                                 "run time (DESIGN.md section 4 names the measured limiter)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode)

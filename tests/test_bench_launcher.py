@@ -1,0 +1,53 @@
+"""bench.py as the driver invokes it: `python bench.py --gpus N` with no launcher around it must start its ranks itself
+(a child `python -m torch.distributed.run`, 127.0.0.1 rendezvous) from a process that has not touched the GPU, and relay
+rank 0's single JSON line.  Runs here on CPU: gloo backend, --dry-run (rendezvous, barrier, reductions, the line; no
+voxelizer).  The GPU work of the ranks is covered by the -m gpu suite and by bench.py itself on the GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def run_bench(*argv, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None), e.pop("MASTER_PORT", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_self_launch_two_ranks_gloo_dry_run():
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "4", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # ONE line, rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
+    assert out["config"]["rccl_ranks"] == 2                # dist.get_world_size() inside the ranks
+    assert out["config"]["rank_sum"] == 3.0                # the all-reduce saw both ranks
+
+
+def test_single_rank_needs_no_launcher():
+    r = run_bench("--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 1 and out["config"]["rccl_ranks"] == 1
+
+
+def test_failed_ranks_fail_the_launcher():
+    # without --dry-run the ranks need a GPU: here they fail, and so must the parent (non-zero, no result line)
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0")
+    import torch
+    if torch.cuda.is_available():
+        return
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_parent_does_not_touch_torch_before_launching():
+    # the launcher path runs before `import torch`: importing bench must not pull it in
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; "
+                        "assert 'torch' not in sys.modules and 'dxrvoxelizer_amd' not in sys.modules" % ROOT],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
