@@ -41,7 +41,7 @@
 #define ORC_PAD 1.52587890625e-05f /* 2^-16: outward pad of every per-triangle box (canonical) */
 
 enum { ORC_MODE_REFERENCE = 0, ORC_MODE_PARITY = 1 };
-enum { ORC_ALGO_BRUTE = 0, ORC_ALGO_BVH = 1 };
+enum { ORC_ALGO_BRUTE = 0, ORC_ALGO_BVH = 1, ORC_ALGO_PLAIN = 2 };
 
 typedef struct { float x, y, z; } f3;
 
@@ -617,6 +617,18 @@ static void trace_ref_brute(const orc_scene* s, const orc_ray* r, orc_hit* best)
     for (uint32_t k = 0; k < s->T; ++k) consider_ref(s, r, k, best);
 }
 
+/* ORC_ALGO_PLAIN: what a tracer WITHOUT the two rules this restatement adds would compute -- every triangle takes the
+ * fp32 watertight test, no padded-box candidacy, no tn <= t; closest = min (t, k).  Not a product path and not the
+ * canonical rule: tests/test_oracle_anchor.py uses it to COUNT the voxels those two rules change (none on the assets). */
+static void trace_ref_plain(const orc_scene* s, const orc_ray* r, orc_hit* best)
+{
+    for (uint32_t k = 0; k < s->T; ++k) {
+        float t, b1, b2;
+        if (!tri_test(r, &s->v0[k], &s->v1[k], &s->v2[k], 0, &t, &b1, &b2)) continue;
+        if (t < best->t || (t == best->t && k < best->k)) { best->t = t; best->k = k; best->b1 = b1; best->b2 = b2; }
+    }
+}
+
 static void trace_ref_bvh(const orc_scene* s, const orc_ray* r, orc_hit* best)
 {
     uint32_t stack[128];
@@ -718,7 +730,9 @@ ORC_API int orc_voxel_reference(const orc_scene* s, uint32_t N, uint32_t ix, uin
     orc_ray r;
     ray_make_reference(&r, N, ix, iy, iz);
     orc_hit best = {ORC_TMAX, 0.0f, 0.0f, UINT32_MAX};
-    if (algo == ORC_ALGO_BRUTE) trace_ref_brute(s, &r, &best); else trace_ref_bvh(s, &r, &best);
+    if (algo == ORC_ALGO_BRUTE) trace_ref_brute(s, &r, &best);
+    else if (algo == ORC_ALGO_PLAIN) trace_ref_plain(s, &r, &best);
+    else trace_ref_bvh(s, &r, &best);
     if (t_out) *t_out = best.t;
     if (k_out) *k_out = best.k;
     if (b_out) { b_out[0] = best.b1; b_out[1] = best.b2; }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MODE_REFERENCE, MODE_PARITY = 0, 1
-ALGO_BRUTE, ALGO_BVH = 0, 1
+ALGO_BRUTE, ALGO_BVH, ALGO_PLAIN = 0, 1, 2
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
