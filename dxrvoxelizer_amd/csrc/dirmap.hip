@@ -132,6 +132,8 @@ __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restric
     if (i == 0u || dm_key_cell(lay, keys[i - 1u]) != cell) cells[cell].begin = i;
     const DirEntry e = rec[(size_t)tri * 6u + cell / (R * R)];
     if (i + 1u == n || dm_key_cell(lay, keys[i + 1u]) != cell) { cells[cell].end = i + 1u; cells[cell].r1max = e.r1; }
+    // radial extent of the thickest entry of the texel (halfs convert and subtract exactly; positive halfs order like integers)
+    atomicMax(&cells[cell].thick, (uint32_t)half_up(half_bits_to_float(e.r1) - half_bits_to_float(e.r0)));
     entries[i] = e;
 }
 } // namespace

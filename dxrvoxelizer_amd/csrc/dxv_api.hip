@@ -304,20 +304,30 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
     unsigned long long total = 0;
     if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
-    // automatic resolution: more than 10 entries per texel on the 256 map -> the 512 map is faster
-    // (bunny x16 1.94 -> 1.77 ms, dragon x9 1.14 -> 1.11; torus-1M, 9.8 per texel, is the same on both)
-    if (!c->optListRes && R == 256u && total > 10ull * 6ull * R * R && total <= 32ull * 6ull * R * R) {
-        R = 512u;
+    auto recount = [&](uint32_t res) -> int {
+        R = res;
         if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
         if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+        return 0;
+    };
+    // automatic resolution, from the mean list length A = entries per texel (it hardly depends on the map: it is the
+    // number of triangles a direction meets, at any depth):
+    //  * 10 < A <= 32 on the 256 map: the 512 map is faster (bunny x16 1.94 -> 1.77 ms, dragon x9 1.14 -> 1.11; torus-1M,
+    //    9.8 per texel, is the same on both);
+    //  * A > 32: the scene is deep in every direction (soups: hundreds of triangles behind one another).  A ray still
+    //    reads only the part of its list between its start and its first hit (the lists are sorted by far radius and the
+    //    scan stops behind the hit, dxv_dirmap.h), so what matters is the size of the structure, which grows with the
+    //    square of the map: the 256 map while it stays below 320 M entries, else the 128 map.
+    auto perTexel = [&]() { return (double)total / (6.0 * R * R); };
+    if (!c->optListRes && R == 256u && perTexel() > 10.0 && perTexel() <= 32.0) {
+        if (recount(512u)) return 1;
+    } else if (!c->optListRes && perTexel() > 32.0) {
+        if (R != 256u && recount(256u)) return 1;
+        if (total > (320ull << 20) && recount(128u)) return 1;
     }
     const unsigned long long cap = 256ull * T + (64ull << 20);
-    // lists pay while they are short: past ~32 entries per texel on average (deep soups: hundreds of
-    // triangles behind one another in every direction) the tree walk wins (soup-10M: 120 vs 65 ms).  An
-    // explicit listres takes the map as asked.
-    const bool tooLong = !c->optListRes && total > 32ull * 6ull * R * R;
-    if (tooLong || total > cap || total > 0x7fffffffull || (unsigned long long)T > (1ull << dm_key_layout(R).triBits)) {
+    if (total > cap || total > 0x7fffffffull || (unsigned long long)T > (1ull << dm_key_layout(R).triBits)) {
         release();
         c->listState = -1;
         c->listEntries = 0;

@@ -36,7 +36,7 @@ static_assert(sizeof(DirEntry) == 16, "one 16-byte load per entry");
 struct alignas(16) DirCell {                        // one 16-byte load per ray
     uint32_t begin, end;                            // entries [begin, end) of a texel
     uint32_t r1max;                                 // far radius of its last entry (half bits): a ray that starts beyond it has no candidate
-    uint32_t pad;
+    uint32_t thick;                                 // largest radial extent r1 - r0 of its entries (half bits, rounded up): where a scan may stop
 };
 
 struct DirMapView {
@@ -119,13 +119,12 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
         n = m;
     }
     if (n == 0) return false;
-    double dmin = poly[cur][0][2], rmax = 0.0, rminv = 1e300;
+    double dmin = poly[cur][0][2], rmax = 0.0;
     for (int i = 0; i < n; ++i) {
         const double* q = poly[cur][i];
         if (q[2] < dmin) dmin = q[2];
         const double r = __builtin_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
         if (r > rmax) rmax = r;
-        if (r < rminv) rminv = r;
     }
     const double full = kDmFrustum + 1.0 / 256.0;
     double u0 = -full, u1 = full, v0 = -full, v1 = full;
@@ -148,26 +147,49 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
         if (u1 > full) u1 = full;
         if (v1 > full) v1 = full;
     }
-    // radial range: the farthest point of a convex polygon is a vertex; a lower bound of the nearest
-    // is the distance of the origin to the triangle's plane, or the nearest vertex minus the diameter
-    const double e1[3] = {(double)vx[1][0] - vx[0][0], (double)vx[1][1] - vx[0][1], (double)vx[1][2] - vx[0][2]};
-    const double e2[3] = {(double)vx[2][0] - vx[0][0], (double)vx[2][1] - vx[0][1], (double)vx[2][2] - vx[0][2]};
-    const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-    const double nl = __builtin_sqrt(nx * nx + ny * ny + nz * nz);
-    double rmin = 0.0;
-    if (nl > 1e-30) {
-        const double dist = __builtin_fabs(nx * vx[0][0] + ny * vx[0][1] + nz * vx[0][2]) / nl;
-        rmin = dist * (1.0 - 1e-6);
+    // radial range: the farthest point of a convex polygon is a vertex; the nearest is the foot of the perpendicular from
+    // the centre onto its plane when that lies inside the polygon, else the nearest point of its boundary.  (A tight near
+    // radius matters twice: it is what culls entries behind a hit, and the thickest entry of a texel decides how far
+    // behind a hit the scan of that texel goes on.)
+    double rmin = 1e300;
+    for (int i = 0; i < n; ++i) {                                      // nearest point of every edge (covers degenerate polygons)
+        const double* A = poly[cur][i];
+        const double* B = poly[cur][(i + 1) % n];
+        const double d[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+        const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        double w = dd > 0.0 ? -(A[0] * d[0] + A[1] * d[1] + A[2] * d[2]) / dd : 0.0;
+        w = w < 0.0 ? 0.0 : w > 1.0 ? 1.0 : w;
+        const double x = A[0] + w * d[0], y = A[1] + w * d[1], z = A[2] + w * d[2];
+        const double dist = __builtin_sqrt(x * x + y * y + z * z);
+        if (dist < rmin) rmin = dist;
     }
-    double diam = 0.0;
-    for (int i = 0; i < n; ++i)
-        for (int j = i + 1; j < n; ++j) {
-            const double* p = poly[cur][i];
-            const double* q = poly[cur][j];
-            const double d = __builtin_sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]));
-            if (d > diam) diam = d;
+    if (n >= 3) {
+        // plane through the polygon (its vertices are coplanar: clipped from one triangle), in the polygon's own coordinates
+        const double* A = poly[cur][0];
+        double nx = 0.0, ny = 0.0, nz = 0.0;
+        for (int i = 1; i + 1 < n; ++i) {                              // summed fan normals: robust for thin clips
+            const double* B = poly[cur][i];
+            const double* C = poly[cur][i + 1];
+            const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+            nx += e1[1] * e2[2] - e1[2] * e2[1]; ny += e1[2] * e2[0] - e1[0] * e2[2]; nz += e1[0] * e2[1] - e1[1] * e2[0];
         }
-    if (rminv - diam > rmin) rmin = rminv - diam;
+        const double nn = nx * nx + ny * ny + nz * nz;
+        if (nn > 1e-60) {
+            const double k = (nx * A[0] + ny * A[1] + nz * A[2]) / nn;
+            const double P[3] = {k * nx, k * ny, k * nz};               // foot of the perpendicular from the centre
+            bool inside = true;
+            for (int i = 0; i < n && inside; ++i) {
+                const double* E = poly[cur][i];
+                const double* F = poly[cur][(i + 1) % n];
+                const double d[3] = {F[0] - E[0], F[1] - E[1], F[2] - E[2]}, q[3] = {P[0] - E[0], P[1] - E[1], P[2] - E[2]};
+                const double cx = d[1] * q[2] - d[2] * q[1], cy = d[2] * q[0] - d[0] * q[2], cz = d[0] * q[1] - d[1] * q[0];
+                inside = cx * nx + cy * ny + cz * nz >= 0.0;            // same turn as the polygon's own orientation (the fan normal)
+            }
+            const double dist = __builtin_fabs(k) * __builtin_sqrt(nn);
+            if (inside && dist < rmin) rmin = dist;
+        }
+    }
+    rmin *= 1.0 - 1e-6;
     rmin -= 4.0 * delta;
     if (rmin < 0.0) rmin = 0.0;
     rmax += 4.0 * delta;
@@ -248,6 +270,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         if (half_bits_to_float(dm.entries[mid].r1) < near) i = mid + 1u; else hi = mid;
     }
     int qn = 0;
+    const float thick = half_bits_to_float(cell.thick);
     auto consider = [&](const DirEntry& e) {
         if (!(half_bits_to_float(e.r1) < near) &&
             !(u < half_bits_to_float(e.u0) || u > half_bits_to_float(e.u1)) &&
@@ -266,11 +289,17 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             const DirEntry e0 = dm.entries[i], e1 = dm.entries[i + 1u < last ? i + 1u : last];
             DirEntry e2 = e0, e3 = e0;
             if (wide) { e2 = dm.entries[i + 2u < last ? i + 2u : last]; e3 = dm.entries[i + 3u < last ? i + 3u : last]; }
-            consider(e0);
-            if (i + 1u <= last) consider(e1);
-            if (i + 2u <= last) consider(e2);
-            if (i + 3u <= last) consider(e3);
-            i += 4u;
+            // The list is sorted by far radius and no entry of the texel is thicker than `thick`: once an entry ends more
+            // than that beyond the closest hit so far, it and everything behind it START beyond the hit.  (Surface meshes
+            // have short lists and gain little; in a deep soup a ray stops after the first few of hundreds of entries.)
+            if (half_bits_to_float(e0.r1) - thick > (rho + best.t) * 1.001f + 1e-4f) i = cell.end;
+            else {
+                consider(e0);
+                if (i + 1u <= last) consider(e1);
+                if (i + 2u <= last) consider(e2);
+                if (i + 3u <= last) consider(e3);
+                i += 4u;
+            }
         }
         const bool scanning = wave_any(i < cell.end);
         if (scanning && !wave_any(qn + 4 > cap)) continue;

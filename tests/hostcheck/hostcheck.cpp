@@ -142,6 +142,8 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
         if (i == 0 || dm_key_cell(lay, keys[i - 1]) != cell) s->dmCells[cell].begin = (uint32_t)i;
         s->dmCells[cell].end = (uint32_t)i + 1;
         s->dmCells[cell].r1max = s->dmEntries[i].r1;
+        const uint32_t th = half_up(half_bits_to_float(s->dmEntries[i].r1) - half_bits_to_float(s->dmEntries[i].r0));
+        if (th > s->dmCells[cell].thick) s->dmCells[cell].thick = th;
     }
     return keys.size();
 }

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Median kernel times of the reference rule for a few meshes: lists (as the library chooses them) and tree walk.
+usage: quick_times.py [--meshes torus1m,bunny16,dragon9,bunny,dragon,soup10m] [--grid 512] [--set key=value,...]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import dxrvoxelizer_amd as dxv  # noqa: E402
+from bench import make_mesh  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--meshes", default="torus1m,bunny16,dragon9,bunny,dragon")
+    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--set", default="")
+    ap.add_argument("--tree", action="store_true")
+    a = ap.parse_args()
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 2)
+    for kv in filter(None, a.set.split(",")):
+        v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    for mesh in a.meshes.split(","):
+        vb, ib, _ = make_mesh(mesh)
+        v.InitFromArrays(vb, ib)
+        out = {"mesh": mesh, "N": a.grid, "build_ms": round(v.stats()["build_ms"], 3)}
+        for lists in ((2, 0) if a.tree else (2,)):
+            v.set_option("lists", lists)
+            v.Voxelize(a.grid, 0)
+            ts = []
+            for _ in range(a.reps):
+                v.Voxelize(a.grid, 0)
+                ts.append(v.stats()["voxelize_ms"])
+            st = v.stats()
+            tag = "lists" if lists else "tree"
+            out[f"{tag}_ms"] = round(float(np.median(ts)), 4)
+            if lists:
+                out.update({"entries": st["list_entries"], "res": st["list_res"], "list_ms": round(st["list_ms"], 3)})
+            out[f"{tag}_solid"] = v.CountSolid()
+        v.set_option("lists", 2)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
