@@ -292,7 +292,7 @@ __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, u
             bool live[64], scanning[64];
             int nlive = 0;
             std::vector<uint32_t> tris, slots;
-            uint64_t maxScan = 0, maxQ = 0, maxScan2 = 0, maxT2 = 0, tsum = 0;
+            uint64_t maxScan = 0, maxQ = 0, maxScan2 = 0, maxT2 = 0, tsum = 0, maxSel1 = 0;
             for (int t = 0; t < 64; ++t) {
                 const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
                 Ray r;
@@ -313,11 +313,46 @@ __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, u
                 startOf[t] = i;
                 scanning[t] = true;
                 Hit best; best.t = kTMax; best.k = 0xffffffffu; best.leaf = -1; best.b1 = best.b2 = 0;
-                uint64_t q = 0;
+                uint64_t q = 0, sel1 = 0;
                 for (uint32_t e = i; e < cell.end; ++e) {
                     const DirEntry& en = s->dmEntries[e];
                     if (!(u < half_bits_to_float(en.u0) || u > half_bits_to_float(en.u1)) && !(v < half_bits_to_float(en.v0) || v > half_bits_to_float(en.v1))) {
                         q++; tris.push_back(en.tri); slots.push_back(e);
+                        {   // what a tighter footprint would select: the projected triangle (3 edges), or the box + its best single edge
+                            const TriPos tq = s->triPos[en.tri];
+                            const uint32_t a = face >> 1, b = (a + 1u) % 3u, c = (a + 2u) % 3u;
+                            const double sg = (face & 1u) ? -1.0 : 1.0;
+                            const float vx[3][3] = {{tq.v0.x, tq.v0.y, tq.v0.z}, {tq.v1.x, tq.v1.y, tq.v1.z}, {tq.v2.x, tq.v2.y, tq.v2.z}};
+                            double P[3][2]; bool front = true; double dmin = 1e9;
+                            for (int k = 0; k < 3; ++k) { const double d = sg * vx[k][a]; if (d < 1e-3) front = false; else { P[k][0] = vx[k][b] / d; P[k][1] = vx[k][c] / d; } if (d < dmin) dmin = d; }
+                            bool in3 = true, in1 = true;
+                            if (front) {
+                                const double pad = 2.25 * 3.0517578125e-5 / dmin + 1e-6;
+                                double area2 = (P[1][0] - P[0][0]) * (P[2][1] - P[0][1]) - (P[1][1] - P[0][1]) * (P[2][0] - P[0][0]);
+                                const double sgn = area2 >= 0 ? 1.0 : -1.0;
+                                double bestCut = -1; int bestEdge = -1;
+                                const double bu0 = half_bits_to_float(en.u0), bu1 = half_bits_to_float(en.u1), bv0 = half_bits_to_float(en.v0), bv1 = half_bits_to_float(en.v1);
+                                // texel rectangle
+                                const double tu0 = (double)dm_texel(u, R) / (0.5 * R) - 1.0, tu1 = tu0 + 2.0 / R, tv0 = (double)dm_texel(v, R) / (0.5 * R) - 1.0, tv1 = tv0 + 2.0 / R;
+                                const double cu0 = bu0 > tu0 ? bu0 : tu0, cu1 = bu1 < tu1 ? bu1 : tu1, cv0 = bv0 > tv0 ? bv0 : tv0, cv1 = bv1 < tv1 ? bv1 : tv1;
+                                bool edgeOk[3];
+                                for (int k = 0; k < 3; ++k) {
+                                    const double ex = P[(k + 1) % 3][0] - P[k][0], ey = P[(k + 1) % 3][1] - P[k][1];
+                                    const double len = __builtin_sqrt(ex * ex + ey * ey) + 1e-30;
+                                    const double nxk = -ey / len * sgn, nyk = ex / len * sgn;     // inward normal
+                                    auto f = [&](double uu, double vv) { return (uu - P[k][0]) * nxk + (vv - P[k][1]) * nyk + pad; };
+                                    edgeOk[k] = f(u, v) >= 0.0;
+                                    if (!edgeOk[k]) in3 = false;
+                                    int cut = 0;                                                 // sample the clipped box: how much does this edge remove
+                                    for (int a2 = 0; a2 < 4; ++a2) for (int b2 = 0; b2 < 4; ++b2)
+                                        if (f(cu0 + (cu1 - cu0) * (a2 + 0.5) / 4, cv0 + (cv1 - cv0) * (b2 + 0.5) / 4) < 0.0) cut++;
+                                    if (cut > bestCut) { bestCut = cut; bestEdge = k; }
+                                }
+                                in1 = edgeOk[bestEdge];
+                            }
+                            if (in3) o[16]++;
+                            if (in1) { o[17]++; sel1++; }
+                        }
                         const TriPos tp = s->triPos[en.tri];
                         float lo[3], hb[3], tn;
                         tri_box(tp.v0, tp.v1, tp.v2, lo, hb);
@@ -349,10 +384,11 @@ __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, u
                 o[6] += cell.end - i; o[8] += q;
                 if (cell.end - i > maxScan) maxScan = cell.end - i;
                 if (q > maxQ) maxQ = q;
+                if (sel1 > maxSel1) maxSel1 = sel1;
                 if (best.k != 0xffffffffu) o[11]++;
             }
             if (!nlive) continue;
-            o[0]++; o[1] += nlive; o[7] += maxScan; o[9] += maxQ; o[16] += tsum; o[17] += maxScan2; o[18] += maxT2; if (!scells_any(scanning)) o[19]++;
+            o[0]++; o[1] += nlive; o[7] += maxScan; o[9] += maxQ; o[18] += maxSel1; if (!scells_any(scanning)) o[19]++;
             std::vector<uint32_t> cells, scells;
             for (int t = 0; t < 64; ++t) if (live[t]) cells.push_back(cellOf[t]);
             for (int t = 0; t < 64; ++t) if (scanning[t]) scells.push_back(cellOf[t]);
