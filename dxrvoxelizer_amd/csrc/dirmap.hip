@@ -4,7 +4,7 @@
 //   k_dm_emit     one thread per (triangle, face): (texel | far radius | triangle) keys for its texels
 //   radix sort    by texel, then far radius (stable: then triangle)
 //   k_dm_cells    first / last entry of every texel
-//   k_dm_entries  16-byte entries in list order (copied from the records)
+//   (k_dm_cells also writes the 16-byte entries in list order: each record cut to its texel, dm_local_entry)
 // The keys of one (triangle, face) are written by one thread: footprints are a few texels unless a
 // triangle passes close to the grid centre, and the total is capped (the caller then keeps the tree).
 #include "dxv_device.h"
@@ -16,7 +16,7 @@ namespace {
 constexpr uint32_t kThreads = 256;
 
 __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R,
-                                                         DirEntry* __restrict__ rec, uint32_t* __restrict__ counts,
+                                                         DirRecord* __restrict__ rec, uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ total)
 {
     // thread -> (face, triangle) face-major: the 64 triangles of a wave are neighbours in Morton order and
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restric
     unsigned long long n = 0;
     if (t < 6u * T) {
         const uint32_t face = t / T, tri = t % T, i = tri * 6u + face;
-        const DirEntry e = dm_entry(triPos[tri], face, tri);
+        const DirRecord e = dm_record(triPos[tri], face);
         rec[i] = e;
         uint32_t i0, i1, j0, j1;
         if (dm_rect(e, R, i0, i1, j0, j1)) n = (unsigned long long)(i1 - i0 + 1u) * (j1 - j0 + 1u);
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_dm_emit(const DirEntry* __restrict__ rec, const uint32_t* __restrict__ offsets, uint32_t T,
+__global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ offsets, uint32_t T,
                                                       uint32_t R, uint64_t* __restrict__ keys)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
@@ -116,12 +116,12 @@ __global__ __launch_bounds__(kThreads) void k_dm_emit(const DirEntry* __restrict
     if (!dm_rect(rec[i], R, i0, i1, j0, j1)) return;
     uint64_t* out = keys + offsets[i];
     const DirKeyLayout lay = dm_key_layout(R);
-    const uint16_t r1 = rec[i].r1;
+    const uint16_t r1 = (uint16_t)rec[i].r1;
     for (uint32_t j = j0; j <= j1; ++j)
         for (uint32_t x = i0; x <= i1; ++x) *out++ = dm_key(lay, (face * R + j) * R + x, r1, tri);
 }
 
-__global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restrict__ keys, uint32_t n, const DirEntry* __restrict__ rec,
+__global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restrict__ keys, uint32_t n, const DirRecord* __restrict__ rec,
                                                        uint32_t R, DirCell* __restrict__ cells, DirEntry* __restrict__ entries)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
@@ -130,11 +130,12 @@ __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restric
     const uint64_t key = keys[i];
     const uint32_t cell = dm_key_cell(lay, key), tri = dm_key_tri(lay, key);
     if (i == 0u || dm_key_cell(lay, keys[i - 1u]) != cell) cells[cell].begin = i;
-    const DirEntry e = rec[(size_t)tri * 6u + cell / (R * R)];
-    if (i + 1u == n || dm_key_cell(lay, keys[i + 1u]) != cell) { cells[cell].end = i + 1u; cells[cell].r1max = e.r1; }
+    const DirRecord rc = rec[(size_t)tri * 6u + cell / (R * R)];
+    if (i + 1u == n || dm_key_cell(lay, keys[i + 1u]) != cell) { cells[cell].end = i + 1u; cells[cell].r1max = rc.r1; }
     // radial extent of the thickest entry of the texel (halfs convert and subtract exactly; positive halfs order like integers)
-    atomicMax(&cells[cell].thick, (uint32_t)half_up(half_bits_to_float(e.r1) - half_bits_to_float(e.r0)));
-    entries[i] = e;
+    atomicMax(&cells[cell].thick, (uint32_t)half_up(half_bits_to_float(rc.r1) - half_bits_to_float(rc.r0)));
+    const uint32_t inFace = cell % (R * R);
+    entries[i] = dm_local_entry(rc, R, inFace % R, inFace / R, tri);    // the record cut to this texel
 }
 } // namespace
 
@@ -142,12 +143,12 @@ __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restric
 size_t dirmap_scratch_bytes(uint32_t T, uint64_t entries)
 {
     const size_t n6 = 6 * (size_t)T, nb = (n6 + kScanBlock - 1) / kScanBlock;
-    return n6 * sizeof(DirEntry) + 2 * n6 * sizeof(uint32_t) + (nb + 1) * sizeof(uint32_t) + 256 +
+    return n6 * sizeof(DirRecord) + 2 * n6 * sizeof(uint32_t) + (nb + 1) * sizeof(uint32_t) + 256 +
            2 * (size_t)entries * sizeof(uint64_t) + sizeof(uint32_t) * (size_t)radix_sort_hist_words((uint32_t)entries) + 1024;
 }
 
 // Pass 1: records, per-(triangle, face) counts and the total.  rec: 6T entries, counts: 6T words, total: one 64-bit word.
-hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirEntry* rec, uint32_t* counts, unsigned long long* total,
+hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, unsigned long long* total,
                         hipStream_t s)
 {
     hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), s);
@@ -158,7 +159,7 @@ hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirEntry* 
 
 // Pass 2: lists.  offsets: 6T words, sums: ceil(6T / 1024) words, keys / keysTmp: n each, hist: radix_sort_hist_words(n),
 // cells: 6 R R, entries: n (n = the total of pass 1).
-hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirEntry* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
+hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
                        uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, hipStream_t s)
 {
     const uint32_t n6 = 6u * T, nb = (n6 + kScanBlock - 1) / kScanBlock;

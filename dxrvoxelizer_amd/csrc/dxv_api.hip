@@ -292,10 +292,10 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
         return fail(c, "lists: %s failed: %s", what, hipGetErrorString(e));
     };
     hipError_t e;
-    const size_t offCounts = align256(n6 * sizeof(DirEntry)), offOffsets = offCounts + align256(n6 * 4),
+    const size_t offCounts = align256(n6 * sizeof(DirRecord)), offOffsets = offCounts + align256(n6 * 4),
                  offSums = offOffsets + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
     if ((e = hipMalloc(&scratchA, offTotal + 256)) != hipSuccess) return bail(e, "hipMalloc");
-    DirEntry* rec = reinterpret_cast<DirEntry*>(scratchA);
+    DirRecord* rec = reinterpret_cast<DirRecord*>(scratchA);
     uint32_t* counts = reinterpret_cast<uint32_t*>(scratchA + offCounts);
     uint32_t* offsets = reinterpret_cast<uint32_t*>(scratchA + offOffsets);
     uint32_t* sums = reinterpret_cast<uint32_t*>(scratchA + offSums);

@@ -41,9 +41,10 @@ hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight,
 
 // dirmap.hip -- direction-space lists of the reference rule (dxv_dirmap.h)
 struct DirEntry;
+struct DirRecord;
 struct DirCell;
-hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirEntry* rec, uint32_t* counts, unsigned long long* total, hipStream_t s);
-hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirEntry* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
+hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, unsigned long long* total, hipStream_t s);
+hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
                        uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, hipStream_t s);
 
 // traverse.hip

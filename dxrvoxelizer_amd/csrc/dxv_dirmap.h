@@ -26,12 +26,34 @@
 
 namespace dxv {
 
+// One entry per (triangle, texel), everything in small integers so that a ray decides in a handful of integer
+// instructions whether the triangle is worth the 48-byte fetch and the watertight test:
+//   box   bytes (x0, y0, 127 - x1, 127 - y1): the footprint's box, cut to the texel, in texel-local cells (a texel is
+//         128 x 128 cells).  A ray in cell (x, y) passes iff every byte of (x, y, 127 - x, 127 - y) is >= this word's
+//         byte: one subtraction of packed bytes (dm_local_pass).
+//   edge  signed bytes (a, b, c1, c2): the ONE edge of the projected, dilated triangle that cuts most off that box.
+//         The ray passes iff a x + b y + 127 c1 + c2 >= 0 (one v_dot4c_i32_i8); 0 = no edge (clipped polygons, or no
+//         edge crosses the box).  A triangle fills at most half of its box: this halves the triangle tests.
+//   rr    (0x7fff - r0) | r1 << 16 | 0x80008000, r0 / r1 the outward-rounded radial range as halfs: positive halfs
+//         order like integers, so r1 >= near and r0 <= (start + closest hit) are one packed subtraction as well.
+//   tri   position in the scene's triangle order (TriPos index)
 struct alignas(16) DirEntry {
-    uint16_t u0, u1, v0, v1;   // footprint box in face coordinates (halfs, rounded outward); u0 > u1: no footprint
-    uint16_t r0, r1;           // radial range of the triangle part inside the face frustum (halfs, rounded outward)
-    uint32_t tri;              // position in the scene's triangle order (TriPos index)
+    uint32_t box, edge, rr, tri;
 };
 static_assert(sizeof(DirEntry) == 16, "one 16-byte load per entry");
+constexpr uint32_t kDmCells = 128u;                 // cells per texel side (7 bits)
+
+// Record of a (triangle, face) pair, builder side: the footprint as before plus the projected triangle, from which
+// the per-texel entries are cut.
+struct alignas(16) DirRecord {
+    float u0, u1, v0, v1;      // footprint box in face coordinates, rounded outward; u0 > u1: no footprint
+    uint32_t r0, r1;           // radial range, halfs rounded outward
+    uint32_t hasTri;           // 1: px / py hold the projected triangle (all three vertices in front of the face plane)
+    float pad;                 // dilation of the projected triangle in face coordinates
+    float px[3], py[3];        // projected vertices
+    uint32_t spare[2];
+};
+static_assert(sizeof(DirRecord) == 64, "record layout");
 
 struct alignas(16) DirCell {                        // one 16-byte load per ray
     uint32_t begin, end;                            // entries [begin, end) of a texel
@@ -57,6 +79,54 @@ DXV_HD uint32_t dm_texel(float u, uint32_t R)
     return i < R ? i : R - 1u;
 }
 
+// texel AND texel-local cell (0 .. 127) of face coordinate u: lexicographically monotone in u, evaluated identically by
+// builder and kernel (x - i is exact for x in [i, i + 1), the scaling a power of two)
+DXV_HD void dm_local(float u, uint32_t R, uint32_t& texel, uint32_t& cell)
+{
+    const float x = (u + 1.0f) * (0.5f * (float)R);
+    if (!(x > 0.0f)) { texel = 0u; cell = 0u; return; }
+    const uint32_t i = (uint32_t)x;
+    if (i >= R) { texel = R - 1u; cell = kDmCells - 1u; return; }
+    const uint32_t c = (uint32_t)((x - (float)i) * (float)kDmCells);
+    texel = i;
+    cell = c < kDmCells ? c : kDmCells - 1u;
+}
+
+// a . b over four signed bytes (v_dot4c_i32_i8 on the device)
+DXV_HD int32_t dm_dot4(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sdot4((int)a, (int)b, 0, false);
+#else
+    int32_t s = 0;
+    for (int k = 0; k < 4; ++k) s += (int32_t)(int8_t)(a >> (8 * k)) * (int32_t)(int8_t)(b >> (8 * k));
+    return s;
+#endif
+}
+
+// The ray's side of an entry test: q = bytes (x, y, 127 - x, 127 - y) | 0x80808080, p = bytes (x, y, 127, 1),
+// rc = (0x7fff - half_down(bound)) | half_up(near) << 16 (dm_radial_word)
+struct DirRayLocal { uint32_t q, p; };
+DXV_HD DirRayLocal dm_ray_local(uint32_t x, uint32_t y)
+{
+    DirRayLocal l;
+    l.q = (x | (y << 8) | ((kDmCells - 1u - x) << 16) | ((kDmCells - 1u - y) << 24)) | 0x80808080u;
+    l.p = x | (y << 8) | (127u << 16) | (1u << 24);
+    return l;
+}
+DXV_HD uint32_t dm_radial_word(float near, float bound)
+{
+    const uint32_t b = bound < 65504.0f ? (uint32_t)half_down(bound) : 0x7bffu;
+    return (0x7fffu - b) | ((uint32_t)half_up(near) << 16);
+}
+// box, edge and radial range of an entry against a ray: true = fetch and test the triangle
+DXV_HD bool dm_local_pass(const DirEntry& e, const DirRayLocal& l, uint32_t rc)
+{
+    return ((l.q - e.box) & 0x80808080u) == 0x80808080u && ((e.rr - rc) & 0x80008000u) == 0x80008000u && dm_dot4(e.edge, l.p) >= 0;
+}
+DXV_HD float dm_entry_r1(const DirEntry& e) { return half_bits_to_float((e.rr >> 16) & 0x7fffu); }
+DXV_HD float dm_entry_r0(const DirEntry& e) { return half_bits_to_float(0x7fffu - (e.rr & 0x7fffu)); }
+
 // face = 2 * axis + (negative side); in-face axes (b, c) = ((axis + 1) % 3, (axis + 2) % 3)
 DXV_HD void dm_ray_point(float ox, float oy, float oz, uint32_t& face, float& u, float& v, float& rho)
 {
@@ -79,7 +149,7 @@ DXV_HD float dm_down(float x) { return -dm_up(-x); }
 // Footprint of triangle tp on one face, or false when it cannot be seen through that face.
 // Builder side only (one call per triangle and face): double precision, nothing canonical here --
 // the result only has to be a superset.
-struct DirFootprint { float u0, u1, v0, v1, r0, r1; };
+struct DirFootprint { float u0, u1, v0, v1, r0, r1, pad, px[3], py[3]; bool hasTri; };
 
 DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
 {
@@ -128,6 +198,8 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
     }
     const double full = kDmFrustum + 1.0 / 256.0;
     double u0 = -full, u1 = full, v0 = -full, v1 = full;
+    out.hasTri = false; out.pad = 0.0f;
+    for (int i = 0; i < 3; ++i) out.px[i] = out.py[i] = 0.0f;
     if (dmin >= 64.0 * delta) {
         u0 = v0 = 1e300; u1 = v1 = -1e300;
         for (int i = 0; i < n; ++i) {
@@ -142,6 +214,15 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
         // du <= (1 + |u|) delta / (dmin - delta) <= 2.04 delta / dmin
         const double pad = 2.25 * delta / dmin + 1e-6;
         u0 -= pad; u1 += pad; v0 -= pad; v1 += pad;
+        // the projected triangle itself, when all of it lies in front of the face plane: its edges, pushed out by the same
+        // pad, bound the footprint too (the part cut off by the frustum's side planes only makes the polygon smaller)
+        const double d0 = s * (double)vx[0][a], d1 = s * (double)vx[1][a], d2 = s * (double)vx[2][a];
+        if (d0 >= 64.0 * delta && d1 >= 64.0 * delta && d2 >= 64.0 * delta) {
+            const double dd[3] = {d0, d1, d2};
+            for (int i = 0; i < 3; ++i) { out.px[i] = (float)((double)vx[i][b] / dd[i]); out.py[i] = (float)((double)vx[i][c] / dd[i]); }
+            out.hasTri = true;
+            out.pad = (float)(pad + 1e-6);                      // (+ the rounding of the stored vertices)
+        }
         if (u0 < -full) u0 = -full;
         if (v0 < -full) v0 = -full;
         if (u1 > full) u1 = full;
@@ -202,27 +283,88 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
     return true;
 }
 
-// the record of (triangle, face) as it is stored in the lists; u0 > u1 when there is no footprint
-DXV_HD DirEntry dm_entry(const TriPos& tp, uint32_t face, uint32_t tri)
+// the record of a (triangle, face) pair; u0 > u1 when there is no footprint
+DXV_HD DirRecord dm_record(const TriPos& tp, uint32_t face)
 {
-    DirEntry e;
+    DirRecord r;
     DirFootprint f;
-    e.tri = tri;
-    if (!dm_footprint(tp, face, f)) { e.u0 = 0x3c00u; e.u1 = 0u; e.v0 = 0x3c00u; e.v1 = 0u; e.r0 = 0u; e.r1 = 0u; return e; }   // 1 > 0
-    e.u0 = half_down(f.u0); e.u1 = half_up(f.u1); e.v0 = half_down(f.v0); e.v1 = half_up(f.v1);
-    e.r0 = half_down(f.r0); e.r1 = half_up(f.r1);
-    return e;
+    r.spare[0] = r.spare[1] = 0u;
+    if (!dm_footprint(tp, face, f)) {
+        r.u0 = 1.0f; r.u1 = 0.0f; r.v0 = 1.0f; r.v1 = 0.0f; r.r0 = r.r1 = 0u; r.hasTri = 0u; r.pad = 0.0f;
+        for (int i = 0; i < 3; ++i) r.px[i] = r.py[i] = 0.0f;
+        return r;
+    }
+    r.u0 = f.u0; r.u1 = f.u1; r.v0 = f.v0; r.v1 = f.v1;
+    r.r0 = half_down(f.r0); r.r1 = half_up(f.r1);
+    r.hasTri = f.hasTri ? 1u : 0u; r.pad = f.pad;
+    for (int i = 0; i < 3; ++i) { r.px[i] = f.px[i]; r.py[i] = f.py[i]; }
+    return r;
 }
 
-// texel rectangle [i0, i1] x [j0, j1] of an entry (false: none)
-DXV_HD bool dm_rect(const DirEntry& e, uint32_t R, uint32_t& i0, uint32_t& i1, uint32_t& j0, uint32_t& j1)
+// texel rectangle [i0, i1] x [j0, j1] of a record (false: none)
+DXV_HD bool dm_rect(const DirRecord& e, uint32_t R, uint32_t& i0, uint32_t& i1, uint32_t& j0, uint32_t& j1)
 {
-    const float u0 = half_bits_to_float(e.u0), u1 = half_bits_to_float(e.u1);
-    const float v0 = half_bits_to_float(e.v0), v1 = half_bits_to_float(e.v1);
-    if (u0 > u1) return false;
-    if (u1 < -1.0f || u0 > 1.0f || v1 < -1.0f || v0 > 1.0f) return false;      // rays only have |u|, |v| <= 1
-    i0 = dm_texel(u0, R); i1 = dm_texel(u1, R); j0 = dm_texel(v0, R); j1 = dm_texel(v1, R);
+    if (e.u0 > e.u1) return false;
+    if (e.u1 < -1.0f || e.u0 > 1.0f || e.v1 < -1.0f || e.v0 > 1.0f) return false;      // rays only have |u|, |v| <= 1
+    i0 = dm_texel(e.u0, R); i1 = dm_texel(e.u1, R); j0 = dm_texel(e.v0, R); j1 = dm_texel(e.v1, R);
     return true;
+}
+
+// The entry of a record in texel (i, j) of its rectangle: the box cut to the texel in local cells, the radial word, and
+// the edge of the projected triangle that removes most of that box.
+// Edge arithmetic (builder side, double): inside the dilated triangle means (p - P_k) . n_k + pad >= 0 for the unit inward
+// normal n_k of every edge k.  With texel-local coordinates X, Y (u = 2 i / R - 1 + X / (64 R)) that is A X + B Y + C >= 0;
+// scaled so that the larger of |A|, |B| is 127 and rounded to bytes a, b.  For a ray in integer cell (x, y), i.e. anywhere
+// in [x, x + 1) x [y, y + 1), a x + b y differs from the scaled A X + B Y by at most |A| + |B| (position inside the cell)
+// + 127 (rounding of a and b, x, y <= 127) + a little for the ray's own float arithmetic: c takes all of that, so the
+// byte test passes wherever the real one does (it gives away two to three cells of 128, 2 % of a texel).
+DXV_HD DirEntry dm_local_entry(const DirRecord& rec, uint32_t R, uint32_t i, uint32_t j, uint32_t tri)
+{
+    DirEntry e;
+    e.tri = tri;
+    e.rr = ((0x7fffu - rec.r0) | (rec.r1 << 16)) | 0x80008000u;
+    uint32_t t0, c0, t1, c1, x0, x1, y0, y1;
+    dm_local(rec.u0, R, t0, c0); dm_local(rec.u1, R, t1, c1);
+    x0 = t0 < i ? 0u : c0; x1 = t1 > i ? kDmCells - 1u : c1;
+    dm_local(rec.v0, R, t0, c0); dm_local(rec.v1, R, t1, c1);
+    y0 = t0 < j ? 0u : c0; y1 = t1 > j ? kDmCells - 1u : c1;
+    e.box = x0 | (y0 << 8) | ((kDmCells - 1u - x1) << 16) | ((kDmCells - 1u - y1) << 24);
+    e.edge = 0u;
+    if (!rec.hasTri) return e;
+    const double area2 = ((double)rec.px[1] - rec.px[0]) * ((double)rec.py[2] - rec.py[0]) - ((double)rec.py[1] - rec.py[0]) * ((double)rec.px[2] - rec.px[0]);
+    if (!(__builtin_fabs(area2) > 1e-14)) return e;                     // seen edge-on: the box has to do
+    const double sgn = area2 > 0.0 ? 1.0 : -1.0;
+    const double ou = 2.0 * i / R - 1.0, ov = 2.0 * j / R - 1.0, perCell = 1.0 / (64.0 * R);
+    int bestCut = 0;
+    for (int k = 0; k < 3; ++k) {
+        const double ex = (double)rec.px[(k + 1) % 3] - rec.px[k], ey = (double)rec.py[(k + 1) % 3] - rec.py[k];
+        const double len = __builtin_sqrt(ex * ex + ey * ey);
+        if (!(len > 1e-12)) continue;
+        const double nx = -ey / len * sgn, ny = ex / len * sgn;          // unit inward normal
+        const double A = nx * perCell, B = ny * perCell;
+        const double C = (ou - rec.px[k]) * nx + (ov - rec.py[k]) * ny + rec.pad;
+        const double big = __builtin_fabs(A) > __builtin_fabs(B) ? __builtin_fabs(A) : __builtin_fabs(B);
+        const double sc = 127.0 / big;
+        const double ka = A * sc, kb = B * sc;
+        const int a = (int)__builtin_floor(ka + 0.5), b = (int)__builtin_floor(kb + 0.5);
+        double cd = __builtin_ceil(C * sc + __builtin_fabs(ka) + __builtin_fabs(kb) + 127.0 + 13.0);
+        if (!(cd < 16256.0)) continue;                                   // this edge cuts nothing representable off the texel
+        if (cd < -16256.0) cd = -16256.0;                               // (more permissive: safe)
+        const int c = (int)cd;
+        const int c1b = c / 127, c2b = c - 127 * c1b;                   // truncation: |c2b| < 127
+        // how much of the box does it remove?  (4 x 4 cell samples)
+        int cut = 0;
+        for (int sy = 0; sy < 4; ++sy)
+            for (int sx = 0; sx < 4; ++sx) {
+                const int x = (int)x0 + (int)((x1 - x0) * (2 * sx + 1) / 8), y = (int)y0 + (int)((y1 - y0) * (2 * sy + 1) / 8);
+                if (a * x + b * y + c < 0) ++cut;
+            }
+        if (cut > bestCut) {
+            bestCut = cut;
+            e.edge = (uint32_t)(uint8_t)(int8_t)a | ((uint32_t)(uint8_t)(int8_t)b << 8) | ((uint32_t)(uint8_t)(int8_t)c1b << 16) | ((uint32_t)(uint8_t)(int8_t)c2b << 24);
+        }
+    }
+    return e;
 }
 
 // List order: by texel, inside a texel by far radius r1 ascending (then by triangle).  Sort key:
@@ -258,7 +400,9 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     uint32_t face;
     float u, v, rho;
     dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
-    const DirCell cell = dm.cells[(face * dm.R + dm_texel(v, dm.R)) * dm.R + dm_texel(u, dm.R)];
+    uint32_t ti, tj, cx, cy;
+    dm_local(u, dm.R, ti, cx); dm_local(v, dm.R, tj, cy);
+    const DirCell cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
     const float near = rho * 0.999f;
     // entries wholly nearer the centre than the ray's start (r1 < near: t < 0) come first: skip them --
     // all of them at once for a ray that starts beyond the texel's last triangle
@@ -267,17 +411,12 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     if (ABL & 1) { if (i == 0xffffffffu) best.k = 0u; return; }
     while (hi - i > 8u) {
         const uint32_t mid = i + ((hi - i) >> 1);
-        if (half_bits_to_float(dm.entries[mid].r1) < near) i = mid + 1u; else hi = mid;
+        if (dm_entry_r1(dm.entries[mid]) < near) i = mid + 1u; else hi = mid;
     }
     int qn = 0;
     const float thick = half_bits_to_float(cell.thick);
-    auto consider = [&](const DirEntry& e) {
-        if (!(half_bits_to_float(e.r1) < near) &&
-            !(u < half_bits_to_float(e.u0) || u > half_bits_to_float(e.u1)) &&
-            !(v < half_bits_to_float(e.v0) || v > half_bits_to_float(e.v1)) &&
-            !(half_bits_to_float(e.r0) > (rho + best.t) * 1.001f + 1e-4f))          // wholly beyond the closest hit so far
-            stk.put(qn++, (int32_t)e.tri);
-    };
+    const DirRayLocal loc = dm_ray_local(cx, cy);
+    uint32_t rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);   // radial cut: r1 >= near, r0 not beyond the closest hit so far
     for (;;) {
         // four entries per round, all four loads in flight before the first is looked at (two per round:
         // +13 % on the 1 M-triangle scene, one: +40 %)
@@ -292,21 +431,23 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             // The list is sorted by far radius and no entry of the texel is thicker than `thick`: once an entry ends more
             // than that beyond the closest hit so far, it and everything behind it START beyond the hit.  (Surface meshes
             // have short lists and gain little; in a deep soup a ray stops after the first few of hundreds of entries.)
-            if (half_bits_to_float(e0.r1) - thick > (rho + best.t) * 1.001f + 1e-4f) i = cell.end;
+            if (dm_entry_r1(e0) - thick > (rho + best.t) * 1.001f + 1e-4f) i = cell.end;
             else {
-                consider(e0);
-                if (i + 1u <= last) consider(e1);
-                if (i + 2u <= last) consider(e2);
-                if (i + 3u <= last) consider(e3);
+                if (dm_local_pass(e0, loc, rc)) stk.put(qn++, (int32_t)e0.tri);
+                if (i + 1u <= last && dm_local_pass(e1, loc, rc)) stk.put(qn++, (int32_t)e1.tri);
+                if (i + 2u <= last && dm_local_pass(e2, loc, rc)) stk.put(qn++, (int32_t)e2.tri);
+                if (i + 3u <= last && dm_local_pass(e3, loc, rc)) stk.put(qn++, (int32_t)e3.tri);
                 i += 4u;
             }
         }
         const bool scanning = wave_any(i < cell.end);
         if (scanning && !wave_any(qn + 4 > cap)) continue;
         if (ABL & 2) { if (qn > 100) best.k = 0u; }
-        else
-        for (int k = 0; wave_any(k < qn); ++k)
-            if (k < qn) leaf_reference(r, tris, stk.get(k), best);
+        else {
+            for (int k = 0; wave_any(k < qn); ++k)
+                if (k < qn) leaf_reference(r, tris, stk.get(k), best);
+            rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);
+        }
         qn = 0;
         if (!scanning) break;
     }

@@ -122,15 +122,15 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
 {
     HcScene* s = static_cast<HcScene*>(p);
     std::vector<uint64_t> keys;
-    std::vector<DirEntry> rec((size_t)s->T * 6);
+    std::vector<DirRecord> rec((size_t)s->T * 6);
     const DirKeyLayout lay = dm_key_layout(R);
     for (uint32_t t = 0; t < s->T; ++t)
         for (uint32_t f = 0; f < 6; ++f) {
-            const DirEntry e = rec[(size_t)t * 6 + f] = dm_entry(s->triPos[t], f, t);
+            const DirRecord e = rec[(size_t)t * 6 + f] = dm_record(s->triPos[t], f);
             uint32_t i0, i1, j0, j1;
             if (!dm_rect(e, R, i0, i1, j0, j1)) continue;
             for (uint32_t j = j0; j <= j1; ++j)
-                for (uint32_t i = i0; i <= i1; ++i) keys.push_back(dm_key(lay, (f * R + j) * R + i, e.r1, t));
+                for (uint32_t i = i0; i <= i1; ++i) keys.push_back(dm_key(lay, (f * R + j) * R + i, (uint16_t)e.r1, t));
         }
     std::sort(keys.begin(), keys.end());
     s->dmR = R;
@@ -138,11 +138,13 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
     s->dmEntries.resize(keys.size());
     for (size_t i = 0; i < keys.size(); ++i) {
         const uint32_t cell = dm_key_cell(lay, keys[i]), t = dm_key_tri(lay, keys[i]);
-        s->dmEntries[i] = rec[(size_t)t * 6 + cell / (R * R)];
+        const DirRecord& rc = rec[(size_t)t * 6 + cell / (R * R)];
+        const uint32_t inFace = cell % (R * R);
+        s->dmEntries[i] = dm_local_entry(rc, R, inFace % R, inFace / R, t);
         if (i == 0 || dm_key_cell(lay, keys[i - 1]) != cell) s->dmCells[cell].begin = (uint32_t)i;
         s->dmCells[cell].end = (uint32_t)i + 1;
-        s->dmCells[cell].r1max = s->dmEntries[i].r1;
-        const uint32_t th = half_up(half_bits_to_float(s->dmEntries[i].r1) - half_bits_to_float(s->dmEntries[i].r0));
+        s->dmCells[cell].r1max = rc.r1;
+        const uint32_t th = half_up(half_bits_to_float(rc.r1) - half_bits_to_float(rc.r0));
         if (th > s->dmCells[cell].thick) s->dmCells[cell].thick = th;
     }
     return keys.size();
@@ -268,148 +270,6 @@ __attribute__((visibility("default"))) void hc_trace_stats(void* p, uint32_t N, 
 }
 
 static bool scells_any(const bool* b) { for (int t = 0; t < 64; ++t) if (b[t]) return true; return false; }
-// Lists replay per 4x4x4 brick (design aid for the list kernels): out[0] waves with a live lane, out[1] live lanes,
-// out[2] lanes ended by the texel's far radius, out[3] sum of distinct texels per wave, out[4] sum over waves of the
-// distinct texels' list lengths, out[5] the same counted from each texel's smallest start index among its lanes,
-// out[6] entries scanned by the lanes (from their start to the end of the list), out[7] sum over waves of the longest
-// lane scan, out[8] triangles selected (queued), out[9] sum over waves of the longest lane queue, out[10] selected
-// triangles whose exact box the ray passes, out[11] hits (lanes with a closest hit), out[12] distinct selected
-// triangles per wave (sum), out[13] distinct selected list slots per wave (sum), out[14] distinct texels of scanning lanes
-__attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, uint32_t bstep, uint64_t* out)
-{
-    HcScene* s = static_cast<HcScene*>(p);
-    float rootLo[3], rootHi[3];
-    {
-        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
-        for (int a = 0; a < 3; ++a) { rootLo[a] = min_(w[a], w[6 + a]); rootHi[a] = max_(w[3 + a], w[9 + a]); }
-    }
-    const uint32_t nb = N / 4, R = s->dmR;
-    uint64_t o[20] = {0};
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : o[:20])
-    for (int64_t bzi = 0; bzi < (int64_t)nb; bzi += bstep) {
-        for (uint32_t byi = 0; byi < nb; ++byi) for (uint32_t bxi = 0; bxi < nb; ++bxi) {
-            uint32_t cellOf[64], startOf[64];
-            bool live[64], scanning[64];
-            int nlive = 0;
-            std::vector<uint32_t> tris, slots;
-            uint64_t maxScan = 0, maxQ = 0, maxScan2 = 0, maxT2 = 0, tsum = 0, maxSel1 = 0;
-            for (int t = 0; t < 64; ++t) {
-                const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
-                Ray r;
-                ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
-                live[t] = scanning[t] = false;
-                if (origin_leaves_root(r.ox, r.oy, r.oz, rootLo, rootHi)) continue;
-                finish_ray_reference(r);
-                live[t] = true; nlive++;
-                uint32_t face; float u, v, rho;
-                dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
-                const uint32_t ci = (face * R + dm_texel(v, R)) * R + dm_texel(u, R);
-                cellOf[t] = ci;
-                const DirCell cell = s->dmCells[ci];
-                const float near = rho * 0.999f;
-                uint32_t i = cell.begin, hi = cell.end;
-                if (half_bits_to_float(cell.r1max) < near) { o[2]++; startOf[t] = cell.end; continue; }
-                while (hi > i) { const uint32_t mid = i + ((hi - i) >> 1); if (half_bits_to_float(s->dmEntries[mid].r1) < near) i = mid + 1u; else hi = mid; }
-                startOf[t] = i;
-                scanning[t] = true;
-                Hit best; best.t = kTMax; best.k = 0xffffffffu; best.leaf = -1; best.b1 = best.b2 = 0;
-                uint64_t q = 0, sel1 = 0;
-                for (uint32_t e = i; e < cell.end; ++e) {
-                    const DirEntry& en = s->dmEntries[e];
-                    if (!(u < half_bits_to_float(en.u0) || u > half_bits_to_float(en.u1)) && !(v < half_bits_to_float(en.v0) || v > half_bits_to_float(en.v1))) {
-                        q++; tris.push_back(en.tri); slots.push_back(e);
-                        {   // what a tighter footprint would select: the projected triangle (3 edges), or the box + its best single edge
-                            const TriPos tq = s->triPos[en.tri];
-                            const uint32_t a = face >> 1, b = (a + 1u) % 3u, c = (a + 2u) % 3u;
-                            const double sg = (face & 1u) ? -1.0 : 1.0;
-                            const float vx[3][3] = {{tq.v0.x, tq.v0.y, tq.v0.z}, {tq.v1.x, tq.v1.y, tq.v1.z}, {tq.v2.x, tq.v2.y, tq.v2.z}};
-                            double P[3][2]; bool front = true; double dmin = 1e9;
-                            for (int k = 0; k < 3; ++k) { const double d = sg * vx[k][a]; if (d < 1e-3) front = false; else { P[k][0] = vx[k][b] / d; P[k][1] = vx[k][c] / d; } if (d < dmin) dmin = d; }
-                            bool in3 = true, in1 = true;
-                            if (front) {
-                                const double pad = 2.25 * 3.0517578125e-5 / dmin + 1e-6;
-                                double area2 = (P[1][0] - P[0][0]) * (P[2][1] - P[0][1]) - (P[1][1] - P[0][1]) * (P[2][0] - P[0][0]);
-                                const double sgn = area2 >= 0 ? 1.0 : -1.0;
-                                double bestCut = -1; int bestEdge = -1;
-                                const double bu0 = half_bits_to_float(en.u0), bu1 = half_bits_to_float(en.u1), bv0 = half_bits_to_float(en.v0), bv1 = half_bits_to_float(en.v1);
-                                // texel rectangle
-                                const double tu0 = (double)dm_texel(u, R) / (0.5 * R) - 1.0, tu1 = tu0 + 2.0 / R, tv0 = (double)dm_texel(v, R) / (0.5 * R) - 1.0, tv1 = tv0 + 2.0 / R;
-                                const double cu0 = bu0 > tu0 ? bu0 : tu0, cu1 = bu1 < tu1 ? bu1 : tu1, cv0 = bv0 > tv0 ? bv0 : tv0, cv1 = bv1 < tv1 ? bv1 : tv1;
-                                bool edgeOk[3];
-                                for (int k = 0; k < 3; ++k) {
-                                    const double ex = P[(k + 1) % 3][0] - P[k][0], ey = P[(k + 1) % 3][1] - P[k][1];
-                                    const double len = __builtin_sqrt(ex * ex + ey * ey) + 1e-30;
-                                    const double nxk = -ey / len * sgn, nyk = ex / len * sgn;     // inward normal
-                                    auto f = [&](double uu, double vv) { return (uu - P[k][0]) * nxk + (vv - P[k][1]) * nyk + pad; };
-                                    edgeOk[k] = f(u, v) >= 0.0;
-                                    if (!edgeOk[k]) in3 = false;
-                                    int cut = 0;                                                 // sample the clipped box: how much does this edge remove
-                                    for (int a2 = 0; a2 < 4; ++a2) for (int b2 = 0; b2 < 4; ++b2)
-                                        if (f(cu0 + (cu1 - cu0) * (a2 + 0.5) / 4, cv0 + (cv1 - cv0) * (b2 + 0.5) / 4) < 0.0) cut++;
-                                    if (cut > bestCut) { bestCut = cut; bestEdge = k; }
-                                }
-                                in1 = edgeOk[bestEdge];
-                            }
-                            if (in3) o[16]++;
-                            if (in1) { o[17]++; sel1++; }
-                        }
-                        const TriPos tp = s->triPos[en.tri];
-                        float lo[3], hb[3], tn;
-                        tri_box(tp.v0, tp.v1, tp.v2, lo, hb);
-                        if (slab(r, lo[0], lo[1], lo[2], hb[0], hb[1], hb[2], tn)) o[10]++;
-                        leaf_reference(r, s->triPos.data(), (int32_t)en.tri, best);
-                    }
-                }
-                {   // ideal early termination: test on selection, stop once every later entry starts beyond the hit
-                    float thick = 0.0f;
-                    for (uint32_t e = cell.begin; e < cell.end; ++e) {
-                        const float d = half_bits_to_float(s->dmEntries[e].r1) - half_bits_to_float(s->dmEntries[e].r0);
-                        if (d > thick) thick = d;
-                    }
-                    Hit b2; b2.t = kTMax; b2.k = 0xffffffffu; b2.leaf = -1; b2.b1 = b2.b2 = 0;
-                    Ray r2 = r;
-                    uint64_t sc = 0, ts = 0;
-                    for (uint32_t e = i; e < cell.end; ++e) {
-                        const DirEntry& en = s->dmEntries[e];
-                        const float bound = (rho + b2.t) * 1.001f + 1e-4f;
-                        if (half_bits_to_float(en.r1) - thick > bound) break;
-                        sc++;
-                        if (!(u < half_bits_to_float(en.u0) || u > half_bits_to_float(en.u1)) && !(v < half_bits_to_float(en.v0) || v > half_bits_to_float(en.v1)) &&
-                            !(half_bits_to_float(en.r0) > bound)) { ts++; leaf_reference(r2, s->triPos.data(), (int32_t)en.tri, b2); }
-                    }
-                    o[15] += sc; tsum += ts;
-                    if (sc > maxScan2) maxScan2 = sc;
-                    if (ts > maxT2) maxT2 = ts;
-                }
-                o[6] += cell.end - i; o[8] += q;
-                if (cell.end - i > maxScan) maxScan = cell.end - i;
-                if (q > maxQ) maxQ = q;
-                if (sel1 > maxSel1) maxSel1 = sel1;
-                if (best.k != 0xffffffffu) o[11]++;
-            }
-            if (!nlive) continue;
-            o[0]++; o[1] += nlive; o[7] += maxScan; o[9] += maxQ; o[18] += maxSel1; if (!scells_any(scanning)) o[19]++;
-            std::vector<uint32_t> cells, scells;
-            for (int t = 0; t < 64; ++t) if (live[t]) cells.push_back(cellOf[t]);
-            for (int t = 0; t < 64; ++t) if (scanning[t]) scells.push_back(cellOf[t]);
-            std::sort(cells.begin(), cells.end()); cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
-            std::sort(scells.begin(), scells.end()); scells.erase(std::unique(scells.begin(), scells.end()), scells.end());
-            o[3] += cells.size(); o[14] += scells.size();
-            for (uint32_t ci : scells) {
-                const DirCell cell = s->dmCells[ci];
-                o[4] += cell.end - cell.begin;
-                uint32_t st = cell.end;
-                for (int t = 0; t < 64; ++t) if (scanning[t] && cellOf[t] == ci && startOf[t] < st) st = startOf[t];
-                o[5] += cell.end - st;
-            }
-            std::sort(tris.begin(), tris.end()); tris.erase(std::unique(tris.begin(), tris.end()), tris.end());
-            std::sort(slots.begin(), slots.end()); slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
-            o[12] += tris.size(); o[13] += slots.size();
-        }
-    }
-    for (int i = 0; i < 20; ++i) out[i] = o[i];
-}
-
 static uint64_t g_uniform = 0, g_distinct = 0;
 #pragma omp threadprivate(g_uniform, g_distinct)
 // Lockstep (SIMT) replay of the reference-mode loop for 4x4x4-voxel waves: every iteration each

@@ -211,7 +211,12 @@ def test_direction_space_lists_give_the_tree_walk_grid(orc, hostcheck, bunny):
         cells, entries = h.lists(R)
         assert (cells[:, 1] >= cells[:, 0]).all() and int(cells[:, 1].max()) == len(entries)
         full = cells[:, 1] > cells[:, 0]
-        assert np.array_equal(cells[full, 2], entries[cells[full, 1] - 1, 2] >> 16)      # far radius of the last entry
+        assert np.array_equal(cells[full, 2], (entries[cells[full, 1] - 1, 2] >> 16) & 0x7fff)   # far radius of the last entry
+        assert (entries[:, 2] & 0x80008000 == 0x80008000).all() and (entries[:, 0] & 0x80808080 == 0).all()
+        r1 = ((entries[:, 2] >> 16) & 0x7fff).astype(np.int64)
+        for k in np.flatnonzero(full)[:: max(1, int(full.sum()) // 50)]:                           # lists are sorted by far radius
+            assert (np.diff(r1[cells[k, 0]:cells[k, 1]]) >= 0).all()
+        assert (entries[:, 1] != 0).mean() > 0.2                                                   # a good part of the entries carries an edge
         got, ovf = h.voxelize(64, mode=12, stack=4)                   # a queue of four entries: several flushes per ray
         assert ovf == 0 and np.array_equal(got, want), R
     rng = np.random.default_rng(99)
