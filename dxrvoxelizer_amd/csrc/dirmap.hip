@@ -129,13 +129,43 @@ __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restric
     const DirKeyLayout lay = dm_key_layout(R);
     const uint64_t key = keys[i];
     const uint32_t cell = dm_key_cell(lay, key), tri = dm_key_tri(lay, key);
-    if (i == 0u || dm_key_cell(lay, keys[i - 1u]) != cell) cells[cell].begin = i;
+    uint32_t* words = reinterpret_cast<uint32_t*>(cells + cell);      // [0] begin, [1] count | r1max << 16, [2] thick | q1 << 16, [3] q2 | q3 << 16
+    if (i == 0u || dm_key_cell(lay, keys[i - 1u]) != cell) words[0] = i;
     const DirRecord rc = rec[(size_t)tri * 6u + cell / (R * R)];
-    if (i + 1u == n || dm_key_cell(lay, keys[i + 1u]) != cell) { cells[cell].end = i + 1u; cells[cell].r1max = rc.r1; }
+    // (count and far radius: k_dm_close, once every texel's begin is in place)
     // radial extent of the thickest entry of the texel (halfs convert and subtract exactly; positive halfs order like integers)
-    atomicMax(&cells[cell].thick, (uint32_t)half_up(half_bits_to_float(rc.r1) - half_bits_to_float(rc.r0)));
+    atomicMax(words + 2, (uint32_t)half_up(half_bits_to_float(rc.r1) - half_bits_to_float(rc.r0)));
     const uint32_t inFace = cell % (R * R);
     entries[i] = dm_local_entry(rc, R, inFace % R, inFace / R, tri);    // the record cut to this texel
+}
+// the far radii the start search of a texel looks at first (dm_search_hints): one thread per texel, after k_dm_cells
+__global__ __launch_bounds__(kThreads) void k_dm_hints(DirCell* __restrict__ cells, uint32_t ncells, const DirEntry* __restrict__ entries)
+{
+    const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= ncells) return;
+    const DirCell cell = cells[c];
+    if (cell.count <= 8u) return;
+    const DirSearchHints h = dm_search_hints(cell.count);
+    auto r1 = [&](uint32_t k) { return (uint16_t)((entries[cell.begin + k].rr >> 16) & 0x7fffu); };
+    cells[c].q2 = r1(h.m2);
+    if (h.has1) cells[c].q1 = r1(h.m1);
+    if (h.has3) cells[c].q3 = r1(h.m3);
+}
+
+// count and far radius of every texel: the thread of a texel's LAST key (the lists are sorted by far radius) reads the begin
+// its first key wrote in k_dm_cells; also the longest list of the map (the count field has 16 bits)
+__global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restrict__ keys, uint32_t n, uint32_t R, DirCell* __restrict__ cells,
+                                                       const DirEntry* __restrict__ entries, uint32_t* __restrict__ longest)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const DirKeyLayout lay = dm_key_layout(R);
+    const uint32_t cell = dm_key_cell(lay, keys[i]);
+    if (i + 1u != n && dm_key_cell(lay, keys[i + 1u]) == cell) return;
+    uint32_t* words = reinterpret_cast<uint32_t*>(cells + cell);
+    const uint32_t count = i + 1u - words[0];
+    words[1] = (count < 0xffffu ? count : 0xffffu) | (((entries[i].rr >> 16) & 0x7fffu) << 16);
+    atomicMax(longest, count);
 }
 } // namespace
 
@@ -160,7 +190,8 @@ hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord*
 // Pass 2: lists.  offsets: 6T words, sums: ceil(6T / 1024) words, keys / keysTmp: n each, hist: radix_sort_hist_words(n),
 // cells: 6 R R, entries: n (n = the total of pass 1).
 hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
-                       uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, hipStream_t s)
+                       uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longestOut,
+                       hipStream_t s)
 {
     const uint32_t n6 = 6u * T, nb = (n6 + kScanBlock - 1) / kScanBlock;
     hipError_t e;
@@ -176,6 +207,13 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     uint64_t* sorted = keys;
     if (n > 1 && (e = radix_sort_keys_bits(keys, keysTmp, n, hist, loBit, passes, &sorted, s)) != hipSuccess) return e;
     k_dm_cells<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, rec, R, cells, entries);
+    // the texel words count entries in 16 bits: the caller reads `*longest` (sums[0] is free by now) when it synchronises
+    // and keeps the tree walk for a scene with a longer list
+    if ((e = hipMemsetAsync(sums, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
+    k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums);
+    const uint32_t ncells = 6u * R * R;
+    k_dm_hints<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
+    if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -351,12 +351,18 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
     uint64_t* keys = reinterpret_cast<uint64_t*>(scratchB);
     uint64_t* keysTmp = reinterpret_cast<uint64_t*>(scratchB + keyBytes);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratchB + 2 * keyBytes);
-    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, stream)) != hipSuccess)
+    uint32_t longest = 0;
+    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, &longest, stream)) != hipSuccess)
         return bail(e, "dirmap_fill");
+
     if (t1) (void)hipEventRecord(t1, stream);
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     if (t0 && t1) c->listMs = elapsed(t0, t1);
     release();
+    if (longest > 0xffffu) {                              // a texel with more entries than its 16-bit count holds: tree walk
+        c->listState = -1; c->listEntries = 0; c->listOpt = c->optListRes;
+        return 0;
+    }
     c->listEntries = n;
     c->listRes = R;
     c->listState = 1;

@@ -56,10 +56,31 @@ struct alignas(16) DirRecord {
 static_assert(sizeof(DirRecord) == 64, "record layout");
 
 struct alignas(16) DirCell {                        // one 16-byte load per ray
-    uint32_t begin, end;                            // entries [begin, end) of a texel
-    uint32_t r1max;                                 // far radius of its last entry (half bits): a ray that starts beyond it has no candidate
-    uint32_t thick;                                 // largest radial extent r1 - r0 of its entries (half bits, rounded up): where a scan may stop
+    uint32_t begin;                                 // the texel's entries: [begin, begin + count)
+    uint16_t count;                                 // (a scene with more than 65,535 entries in one texel keeps the tree walk)
+    uint16_t r1max;                                 // far radius of its last entry (half bits): a ray that starts beyond it has no candidate
+    uint16_t thick;                                 // largest radial extent r1 - r0 of its entries (half bits, rounded up): where a scan may stop
+    // The first two steps of the binary search for a ray's start need no load: the far radii (half bits) of the entries
+    // the search would look at -- the middle one, and the middles of both halves (dm_search_hints).  Lists of up to 35
+    // entries (all of a surface mesh's) are then down to the eight entries a scan round starts with anyway.
+    uint16_t q1, q2, q3;
 };
+static_assert(sizeof(DirCell) == 16, "one 16-byte load per texel");
+
+// entries the start search looks at first in a list of n entries (relative indices; n > 8): the middle of [0, n), and the
+// middles of [0, m2) and [m2 + 1, n) where those halves are still longer than 8 -- exactly the sequence of the loop
+// `while (hi - lo > 8) { mid = lo + (hi - lo) / 2; r1[mid] < near ? lo = mid + 1 : hi = mid; }`
+struct DirSearchHints { uint32_t m1, m2, m3; bool has1, has3; };
+DXV_HD DirSearchHints dm_search_hints(uint32_t n)
+{
+    DirSearchHints h;
+    h.m2 = n >> 1;
+    h.has1 = h.m2 > 8u;                       // left half [0, m2)
+    h.m1 = h.m2 >> 1;
+    h.has3 = n - (h.m2 + 1u) > 8u;            // right half [m2 + 1, n)
+    h.m3 = h.m2 + 1u + ((n - (h.m2 + 1u)) >> 1);
+    return h;
+}
 
 struct DirMapView {
     const DirCell* cells;      // 6 * R * R, cell = (face * R + j) * R + i; NULL: no map
@@ -114,10 +135,16 @@ DXV_HD DirRayLocal dm_ray_local(uint32_t x, uint32_t y)
     l.p = x | (y << 8) | (127u << 16) | (1u << 24);
     return l;
 }
+// Directed float -> half for the values a ray brings to the integer radial test: positive, inside the half's normal
+// range [2^-14, 65504) (a ray starts at least half a voxel diagonal, 4e-4 even at 2048^3, from the centre).  There the
+// half's bits are the float's, rebiased and cut: truncation rounds down, adding the dropped bits' mask first rounds up
+// (the carry runs into the exponent as it should).  Equal to half_down / half_up (dxv_math.h) on that range (tests).
+DXV_HD uint32_t dm_half_down_pos(float x) { return (__builtin_bit_cast(uint32_t, x) - 0x38000000u) >> 13; }
+DXV_HD uint32_t dm_half_up_pos(float x) { return (__builtin_bit_cast(uint32_t, x) - 0x38000000u + 0x1fffu) >> 13; }
 DXV_HD uint32_t dm_radial_word(float near, float bound)
 {
-    const uint32_t b = bound < 65504.0f ? (uint32_t)half_down(bound) : 0x7bffu;
-    return (0x7fffu - b) | ((uint32_t)half_up(near) << 16);
+    const uint32_t b = bound < 65504.0f ? dm_half_down_pos(bound) : 0x7bffu;
+    return (0x7fffu - b) | (dm_half_up_pos(near) << 16);
 }
 // box, edge and radial range of an entry against a ray: true = fetch and test the triangle
 DXV_HD bool dm_local_pass(const DirEntry& e, const DirRayLocal& l, uint32_t rc)
@@ -406,22 +433,33 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     const float near = rho * 0.999f;
     // entries wholly nearer the centre than the ray's start (r1 < near: t < 0) come first: skip them --
     // all of them at once for a ray that starts beyond the texel's last triangle
-    uint32_t i = cell.begin, hi = cell.end;
+    uint32_t end = cell.begin + cell.count;
+    uint32_t i = cell.begin, hi = end;
     if (half_bits_to_float(cell.r1max) < near) i = hi;
     if (ABL & 1) { if (i == 0xffffffffu) best.k = 0u; return; }
+    if (hi - i > 8u) {                                                  // the first two steps of the search from the texel's own words
+        const uint32_t mid = i + ((hi - i) >> 1);
+        const bool right = half_bits_to_float(cell.q2) < near;
+        const float q = half_bits_to_float(right ? cell.q3 : cell.q1);
+        if (right) i = mid + 1u; else hi = mid;
+        if (hi - i > 8u) {
+            const uint32_t mid2 = i + ((hi - i) >> 1);
+            if (q < near) i = mid2 + 1u; else hi = mid2;
+        }
+    }
     while (hi - i > 8u) {
         const uint32_t mid = i + ((hi - i) >> 1);
         if (dm_entry_r1(dm.entries[mid]) < near) i = mid + 1u; else hi = mid;
     }
     int qn = 0;
     const float thick = half_bits_to_float(cell.thick);
-    const DirRayLocal loc = dm_ray_local(cx, cy);
+    DirRayLocal loc = dm_ray_local(cx, cy);
     uint32_t rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);   // radial cut: r1 >= near, r0 not beyond the closest hit so far
     for (;;) {
         // four entries per round, all four loads in flight before the first is looked at (two per round:
         // +13 % on the 1 M-triangle scene, one: +40 %)
-        if (i < cell.end) {
-            const uint32_t last = cell.end - 1u;
+        if (i < end) {
+            const uint32_t last = end - 1u;
             // (the third and fourth load are skipped when no lane of the wave has that many entries left:
             // -5 % on the 1 M-triangle scene; voting on the second one as well: +7 %)
             const bool wide = wave_any(i + 2u <= last);
@@ -431,7 +469,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             // The list is sorted by far radius and no entry of the texel is thicker than `thick`: once an entry ends more
             // than that beyond the closest hit so far, it and everything behind it START beyond the hit.  (Surface meshes
             // have short lists and gain little; in a deep soup a ray stops after the first few of hundreds of entries.)
-            if (dm_entry_r1(e0) - thick > (rho + best.t) * 1.001f + 1e-4f) i = cell.end;
+            if (dm_entry_r1(e0) - thick > (rho + best.t) * 1.001f + 1e-4f) i = end;
             else {
                 if (dm_local_pass(e0, loc, rc)) stk.put(qn++, (int32_t)e0.tri);
                 if (i + 1u <= last && dm_local_pass(e1, loc, rc)) stk.put(qn++, (int32_t)e1.tri);
@@ -440,10 +478,13 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
                 i += 4u;
             }
         }
-        const bool scanning = wave_any(i < cell.end);
+        const bool scanning = wave_any(i < end);
         if (scanning && !wave_any(qn + 4 > cap)) continue;
         if (ABL & 2) { if (qn > 100) best.k = 0u; }
         else {
+            // direction, 1 / d, -o / d (hlsl:52 and the slab constants): only now, after the scan of the short lists of a
+            // surface mesh is over -- two waves in five never get here, and the scan runs with a dozen registers less
+            finish_ray_reference(r);
             for (int k = 0; wave_any(k < qn); ++k)
                 if (k < qn) leaf_reference(r, tris, stk.get(k), best);
             rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);

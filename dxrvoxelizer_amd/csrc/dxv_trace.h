@@ -31,6 +31,7 @@ struct StridedStack {
     int stride;
     DXV_HD void put(int e, int32_t v) const { base[e * stride] = v; }
     DXV_HD int32_t get(int e) const { return base[e * stride]; }
+    DXV_HD int32_t getv(int e) const { return *const_cast<volatile int32_t*>(base + e * stride); }   // a load the compiler may not forward from a store
 };
 
 DXV_HD float half_bits_to_float(uint32_t h16)
@@ -590,7 +591,7 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     Ray r;
     ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
-    finish_ray_reference(r);
+    if (WALK != 4) finish_ray_reference(r);                                     // (the lists finish the ray when they first test a triangle)
     Hit best;
     if (WALK == 4) trace_reference_lists<Stack, ABL>(r, sc, stk, cap, best);                           // no tree, no stack: cannot overflow
     const bool ok = WALK == 4 ? true

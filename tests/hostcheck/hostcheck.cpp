@@ -134,7 +134,7 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
         }
     std::sort(keys.begin(), keys.end());
     s->dmR = R;
-    s->dmCells.assign((size_t)6 * R * R, DirCell{0, 0, 0, 0});
+    s->dmCells.assign((size_t)6 * R * R, DirCell{0, 0, 0, 0, 0, 0, 0});
     s->dmEntries.resize(keys.size());
     for (size_t i = 0; i < keys.size(); ++i) {
         const uint32_t cell = dm_key_cell(lay, keys[i]), t = dm_key_tri(lay, keys[i]);
@@ -142,10 +142,19 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
         const uint32_t inFace = cell % (R * R);
         s->dmEntries[i] = dm_local_entry(rc, R, inFace % R, inFace / R, t);
         if (i == 0 || dm_key_cell(lay, keys[i - 1]) != cell) s->dmCells[cell].begin = (uint32_t)i;
-        s->dmCells[cell].end = (uint32_t)i + 1;
-        s->dmCells[cell].r1max = rc.r1;
+        if (s->dmCells[cell].count == 0xffffu) return ~0ull;             // does not fit the 16-bit count
+        s->dmCells[cell].count++;
+        s->dmCells[cell].r1max = (uint16_t)rc.r1;
         const uint32_t th = half_up(half_bits_to_float(rc.r1) - half_bits_to_float(rc.r0));
-        if (th > s->dmCells[cell].thick) s->dmCells[cell].thick = th;
+        if (th > s->dmCells[cell].thick) s->dmCells[cell].thick = (uint16_t)th;
+    }
+    for (DirCell& cell : s->dmCells) {
+        if (cell.count <= 8u) continue;
+        const DirSearchHints h = dm_search_hints(cell.count);
+        auto r1 = [&](uint32_t k) { return (uint16_t)((s->dmEntries[cell.begin + k].rr >> 16) & 0x7fffu); };
+        cell.q2 = r1(h.m2);
+        if (h.has1) cell.q1 = r1(h.m1);
+        if (h.has3) cell.q3 = r1(h.m3);
     }
     return keys.size();
 }

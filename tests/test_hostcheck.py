@@ -209,13 +209,17 @@ def test_direction_space_lists_give_the_tree_walk_grid(orc, hostcheck, bunny):
     want, _ = h.voxelize(64, mode=0)
     for R in (32, 256):
         cells, entries = h.lists(R)
-        assert (cells[:, 1] >= cells[:, 0]).all() and int(cells[:, 1].max()) == len(entries)
-        full = cells[:, 1] > cells[:, 0]
-        assert np.array_equal(cells[full, 2], (entries[cells[full, 1] - 1, 2] >> 16) & 0x7fff)   # far radius of the last entry
+        begin, count, r1max = cells[:, 0].astype(np.int64), (cells[:, 1] & 0xffff).astype(np.int64), cells[:, 1] >> 16
+        full = count > 0
+        assert int((begin + count).max()) == len(entries) and int(count.sum()) == len(entries)
+        assert np.array_equal(r1max[full], (entries[(begin + count)[full] - 1, 2] >> 16) & 0x7fff)   # far radius of the last entry
         assert (entries[:, 2] & 0x80008000 == 0x80008000).all() and (entries[:, 0] & 0x80808080 == 0).all()
         r1 = ((entries[:, 2] >> 16) & 0x7fff).astype(np.int64)
         for k in np.flatnonzero(full)[:: max(1, int(full.sum()) // 50)]:                           # lists are sorted by far radius
-            assert (np.diff(r1[cells[k, 0]:cells[k, 1]]) >= 0).all()
+            assert (np.diff(r1[begin[k]:begin[k] + count[k]]) >= 0).all()
+        k = int(np.argmax(count))                                                                  # the search hints of the longest list
+        if count[k] > 8:
+            assert (cells[k, 3] & 0xffff) == r1[begin[k] + count[k] // 2]
         assert (entries[:, 1] != 0).mean() > 0.2                                                   # a good part of the entries carries an edge
         got, ovf = h.voxelize(64, mode=12, stack=4)                   # a queue of four entries: several flushes per ray
         assert ovf == 0 and np.array_equal(got, want), R

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-launch and per-wave means of the PMC passes of tools/gpu_pmc_quick.sh for the voxelize kernels."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    d = sys.argv[1]
+    per = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(list)
+    for cc in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
+        disp = defaultdict(dict)
+        with open(cc) as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"]
+                if "dxv::k_voxelize" not in name or "redo" in name:
+                    continue
+                disp[row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
+        for _, c in disp.items():
+            for k, v in c.items():
+                per["k_voxelize"][k].append(v)
+    for kt in glob.glob(os.path.join(d, "*", "*", "*_kernel_trace.csv")):
+        with open(kt) as fh:
+            for row in csv.DictReader(fh):
+                if "dxv::k_voxelize" in row["Kernel_Name"] and "redo" not in row["Kernel_Name"]:
+                    dur["k_voxelize"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+    out = {}
+    for k, c in per.items():
+        m = {n: sum(v) / len(v) for n, v in c.items()}
+        w = m.get("SQ_WAVES", 0) or 1
+        m["per_wave"] = {n: round(m[n] / w, 1) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS",
+                                                           "TCP_TOTAL_CACHE_ACCESSES_sum") if n in m}
+        if "SQ_WAVE_CYCLES" in m:
+            m["per_wave"]["wave_quad_cycles"] = round(m["SQ_WAVE_CYCLES"] / w, 1)
+            for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+                if n in m:
+                    m["per_wave"][n + "_frac"] = round(m[n] / m["SQ_WAVE_CYCLES"], 3)
+        if dur.get(k):
+            m["profiled_ms_mean"] = sum(dur[k]) / len(dur[k])
+        out[k] = m
+    with open(os.path.join(d, "summary.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps({k: {"per_wave": v.get("per_wave"), "ms": v.get("profiled_ms_mean"), "TA_BUSY": v.get("TA_TA_BUSY_sum"),
+                          "GRBM": v.get("GRBM_GUI_ACTIVE"), "waves": v.get("SQ_WAVES")} for k, v in out.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
