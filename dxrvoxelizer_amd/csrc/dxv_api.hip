@@ -1017,6 +1017,35 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     return 0;
 }
 
+int dxv_debug_list_check(dxv_ctx* c, uint32_t N, uint64_t out[34])
+{
+    if (!c || !out) return 1;
+    if (!c->haveScene) return fail(c, "dxv_debug_list_check: no scene");
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_debug_list_check: grid_dim must be even and in [2, 2048], got %u", N);
+    if (c->hdr.treeHeight + 1 > 64) return fail(c, "dxv_debug_list_check: tree too deep for the checker's stack");
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
+    if (c->listState == 0 || c->listOpt != c->optListRes) {
+        if (build_lists(c, c->stream)) return 1;
+    }
+    if (c->listState != 1) return fail(c, "dxv_debug_list_check: this scene has no lists (over the caps)");
+    unsigned long long* dOut = nullptr;
+    DXV_HIP(c, hipMalloc(&dOut, 34 * sizeof(unsigned long long)));
+    VoxelizeParams p{};
+    p.scene.nodes = scene_nodes32(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
+    memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
+    memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
+    p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
+    p.N = N;
+    hipError_t e = hipMemsetAsync(dOut, 0, 34 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = launch_list_check(p, dOut, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, 34 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(c, "dxv_debug_list_check failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
 {
     if (!c || !host) return 1;

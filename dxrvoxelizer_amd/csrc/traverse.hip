@@ -90,6 +90,85 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
     p.grid[id] = occ;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Test hook (dxv_debug_list_check): the lists' superset claim, checked exhaustively on the device.  For every voxel the
+// LBVH is walked WITHOUT distance culling; every triangle the canonical step accepts for the ray (own padded box passed,
+// watertight hit at 0 < t < TMax, box entry <= t) must be found in the ray's texel list and pass that entry's integer
+// test (box, edge, radial range) even with the radial cut already drawn at its own t -- then no order of scanning, no
+// cut by an earlier hit and no early stop can keep the closest hit out of the queue (dxv_dirmap.h).
+// out[0] accepted (ray, triangle) pairs, out[1] violations, out[2 + 2 k], out[3 + 2 k]: voxel id and triangle slot of the
+// first 16 violations.  Not a product path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_list_check(VoxelizeParams p, unsigned long long* out)
+{
+    __shared__ int32_t stack[64 * 64];
+    const uint32_t N = p.N, nbx = (N + 3u) / 4u;
+    const uint32_t b = blockIdx.x, bx = b % nbx, by = (b / nbx) % nbx, bz = b / (nbx * nbx);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ix = bx * 4u + (lane & 3u), iy = by * 4u + ((lane >> 2) & 3u), iz = bz * 4u + (lane >> 4);
+    if (ix >= N || iy >= N || iz >= N) return;
+    const SceneView& sc = p.scene;
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return;
+    finish_ray_reference(r);
+    ray_shear(r);
+    const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
+    uint32_t face, ti, tj, cx, cy;
+    float u, v, rho;
+    dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
+    dm_local(u, dm.R, ti, cx); dm_local(v, dm.R, tj, cy);
+    const DirCell cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
+    const DirRayLocal loc = dm_ray_local(cx, cy);
+    const float near = rho * 0.999f;
+    const size_t id = ((size_t)iz * N + iy) * N + ix;
+    auto leaf = [&](int32_t l) {
+        const TriPos tp = load_tri(sc.triPos, l);
+        float lo[3], hi[3], tn, t, b1, b2;
+        tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+        if (!slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn)) return;
+        if (!tri_test<false>(r, tp.v0, tp.v1, tp.v2, t, b1, b2) || tn > t) return;
+        atomicAdd(out, 1ull);
+        const uint32_t rc = dm_radial_word(near, (rho + t) * 1.001f + 1e-4f);
+        bool found = false;
+        if (!(half_bits_to_float(cell.r1max) < near))
+            for (uint32_t k = cell.begin; k < cell.begin + cell.count && !found; ++k) {
+                const DirEntry e = dm.entries[k];
+                found = e.tri == (uint32_t)l && dm_local_pass(e, loc, rc);
+            }
+        if (!found) {
+            const unsigned long long slot = atomicAdd(out + 1, 1ull);
+            if (slot < 16ull) { out[2 + 2 * slot] = (unsigned long long)id; out[3 + 2 * slot] = (unsigned long long)(uint32_t)l; }
+        }
+    };
+    int32_t* stk = stack + lane;
+    int sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        const NodePlanes n = load_node(sc.nodes, node);
+        float tn0, tn1;
+        const bool h0 = slab(r, n.b[0], n.b[1], n.b[2], n.b[3], n.b[4], n.b[5], tn0);
+        const bool h1 = slab(r, n.b[6], n.b[7], n.b[8], n.b[9], n.b[10], n.b[11], tn1);
+        if (h0 && n.c0 < 0) leaf(~n.c0);
+        if (h1 && n.c1 < 0) leaf(~n.c1);
+        const bool i0 = h0 && n.c0 >= 0, i1 = h1 && n.c1 >= 0;
+        if (i0 && i1) { if (sp < 64) stk[64 * sp++] = n.c1; node = n.c0; }
+        else if (i0) node = n.c0;
+        else if (i1) node = n.c1;
+        else {
+            if (sp == 0) break;
+            node = stk[64 * --sp];
+        }
+    }
+}
+
+hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s)
+{
+    const uint32_t nb = (p.N + 3u) / 4u;
+    k_list_check<<<dim3(nb * nb * nb), dim3(64), 0, s>>>(p, out);
+    return hipGetLastError();
+}
+
 // The rays whose LDS column was too small in k_voxelize (a few per million: DESIGN.md), one per
 // lane with a column of kRedoStack entries -- enough for any tree the builder makes (height <= 62).
 // Plain binary walk, leaves tested where they are met; same voxel as every other walk.

@@ -203,6 +203,12 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
 
+/* Test hook: the superset claim of the direction-space lists, checked for every voxel of a grid_dim^3 grid on the device:
+ * every triangle the canonical triangle step accepts for a ray (found by an LBVH walk without distance culling) must be
+ * selectable from that ray's texel list.  out[0] = accepted (ray, triangle) pairs, out[1] = violations (must be 0),
+ * out[2 + 2k], out[3 + 2k] = voxel id and triangle slot of the first 16 violations.  Builds the lists if needed. */
+DXV_API int dxv_debug_list_check(dxv_ctx* ctx, uint32_t grid_dim, uint64_t out[34]);
+
 /* Test hook: copy an internal device array to the host (enum above). */
 DXV_API int dxv_debug_download(dxv_ctx* ctx, int what, void* host, size_t bytes);
 

@@ -29,6 +29,42 @@ def lattice_mesh(rng, n_tris, N):
     return vb, np.arange(3 * n_tris, dtype=np.uint32)
 
 
+def needle_mesh(rng, n_tris, N):
+    """Off-lattice needles and slivers aimed at the rays: short edge 1e-7 .. 1e-4, long edge 0.003 .. 0.5, centred ON the
+    radial ray of a random voxel centre at radius 0.5 .. 1.7, the long edge within 1e-4 .. 0.3 rad of that ray (grazing
+    to face-on), a third of them split into two triangles sharing the long edge.  What the lists' margins must survive:
+    edge functions that all but vanish, footprints a fraction of a texel wide, radial extents of half the scene."""
+    tris = []
+    while len(tris) < n_tris:
+        c = (rng.integers(0, N, 3) + 0.5) / N * 2 - 1
+        c[1] = -c[1]
+        d = c / np.linalg.norm(c)
+        rho = rng.uniform(0.5, 1.7)
+        p = d * rho
+        if np.abs(p).max() > 0.98 or rho <= np.linalg.norm(c):
+            continue                                            # keep the needle inside the cube and in front of the ray
+        a = rng.normal(size=3)
+        a -= a.dot(d) * d
+        a /= np.linalg.norm(a)                                  # unit vector across the ray
+        b = np.cross(d, a)
+        ang = 10.0 ** rng.uniform(-4, -0.5)
+        long_dir = np.cos(ang) * d + np.sin(ang) * (np.cos(1.7) * a + np.sin(1.7) * b)
+        L, w = 10.0 ** rng.uniform(-2.5, -0.3), 10.0 ** rng.uniform(-7, -4)
+        off = rng.uniform(-0.5, 0.5) * w * a                    # the ray passes within the needle's width of its axis
+        v0, v1 = p - 0.5 * L * long_dir + off, p + 0.5 * L * long_dir + off
+        v2 = p + rng.uniform(-0.5, 0.5) * L * long_dir + w * a + off
+        if max(np.abs(v0).max(), np.abs(v1).max(), np.abs(v2).max()) > 0.99:
+            continue
+        tris.append([v0, v1, v2])
+        if rng.random() < 0.33 and len(tris) < n_tris:          # the other half of a thin quad: shared long edge
+            tris.append([v1, v0, p - w * a + off])
+    pos = np.asarray(tris, np.float64).reshape(-1, 3)
+    pos = np.concatenate([pos, [[-1, -1, -1], [1, 1, 1]]]).astype(np.float32)   # pin the bound to the unit cube
+    nrm = rng.normal(size=pos.shape).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    return np.concatenate([pos, nrm], axis=1).astype(np.float32), np.arange(3 * len(tris), dtype=np.uint32)
+
+
 CASES = [(seed, n) for seed, n in zip(range(12), (1, 2, 3, 5, 8, 13, 21, 40, 80, 150, 300, 600))]
 
 
@@ -86,6 +122,57 @@ def test_fuzz_gpu_vs_brute_force(dxvlib, orc):
             v.set_option("rows", 1)
             v.set_option("queue", 1)
             v.set_option("wide", 2)
+    v.close()
+
+
+def test_needles_host_lists_vs_brute_force(orc, hostcheck):
+    """The product's list code (footprints, texel-local boxes and edges, radial words, scan) compiled for the CPU, on
+    needles aimed at the rays, coarse to fine maps, against the oracle's brute force."""
+    rng = np.random.default_rng(4242)
+    for n_tris, N in ((40, 16), (200, 16), (120, 32)):
+        vb, ib = needle_mesh(rng, n_tris, N)
+        s = orc.Scene(vb, ib)
+        assert np.allclose(s.bound, [0, 0, 0, 1])
+        want = s.voxelize(N, algo=orc.ALGO_BRUTE)
+        assert want.sum() > 0
+        h = hostcheck(vb, ib, s.bound)
+        for R in (16, 256):
+            h.lists(R)
+            got, ovf = h.voxelize(N, mode=12, stack=8)
+            assert ovf == 0 and np.array_equal(got, want), (n_tris, N, R)
+
+
+@pytest.mark.gpu
+def test_needles_and_slivers_lists_superset(dxvlib, orc):
+    """Adversarial coverage of the lists' superset claim on the device: needles and slivers (short edge 1e-7 .. 1e-4) aimed
+    at the rays, map resolutions 16 / 256 / 4096, every grid against the oracle's brute force, and the exhaustive on-device
+    check (dxv_debug_list_check): every triangle the canonical step accepts for a ray is selectable from the ray's list."""
+    import dxrvoxelizer_amd as dxv
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 2)
+    rng = np.random.default_rng(2024)
+    pairs = 0
+    for n_tris, N in ((1, 16), (30, 16), (300, 32), (1500, 32), (600, 64)):
+        vb, ib = needle_mesh(rng, n_tris, N)
+        s = orc.Scene(vb, ib)
+        want = s.voxelize(N, algo=orc.ALGO_BRUTE)
+        v.InitFromArrays(vb, ib)
+        for res in (16, 256, 4096):
+            v.set_option("listres", res)
+            v.Voxelize(N)
+            assert v.stats()["list_entries"] > 0 and v.stats()["list_res"] == res
+            assert np.array_equal(v.Grid(), want), (n_tris, N, res)
+            accepted, violations, first = v.list_check(N)
+            assert violations == 0, (n_tris, N, res, first)
+            pairs += accepted
+        v.set_option("listres", 0)
+    assert pairs > 5000                                        # the needles are hit: the check is not vacuous
+    # the assets as well, at the resolution the library picks
+    for name, N in (("bunny", 128), ("turingbowl", 96)):
+        d = np.load(__import__("os").path.join(__import__("conftest").GOLD, "meshes", name + ".npz"))
+        v.InitFromArrays(d["vb"], d["ib"])
+        accepted, violations, first = v.list_check(N)
+        assert accepted > 0 and violations == 0, (name, first)
     v.close()
 
 
