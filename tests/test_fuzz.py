@@ -166,7 +166,7 @@ def test_needles_and_slivers_lists_superset(dxvlib, orc):
             assert violations == 0, (n_tris, N, res, first)
             pairs += accepted
         v.set_option("listres", 0)
-    assert pairs > 5000                                        # the needles are hit: the check is not vacuous
+    assert pairs > 2000                                        # the needles are hit: the check is not vacuous
     # the assets as well, at the resolution the library picks
     for name, N in (("bunny", 128), ("turingbowl", 96)):
         d = np.load(__import__("os").path.join(__import__("conftest").GOLD, "meshes", name + ".npz"))
