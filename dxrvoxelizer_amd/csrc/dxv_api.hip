@@ -895,15 +895,59 @@ int dxv_texels_download(dxv_ctx* c, uint32_t* host, size_t bytes)
     return 0;
 }
 
-size_t dxv_scene_bytes(const dxv_ctx* c) { return c && c->haveScene ? c->sceneBytes : 0; }
+namespace {
+// an exported blob = the scene as it lies in memory + (when the context has built them) the lists' two arrays
+struct BlobLayout { size_t offCells, cellBytes, offEntries, entryBytes, total; };
+BlobLayout blob_layout(size_t sceneBytes, uint32_t listRes, uint32_t listCount)
+{
+    BlobLayout b{0, 0, 0, 0, sceneBytes};
+    if (listRes) {
+        b.offCells = align256(sceneBytes);
+        b.cellBytes = sizeof(DirCell) * 6 * (size_t)listRes * listRes;
+        b.offEntries = align256(b.offCells + b.cellBytes);
+        b.entryBytes = sizeof(DirEntry) * (size_t)listCount;
+        b.total = align256(b.offEntries + b.entryBytes);
+    }
+    return b;
+}
+bool lists_exportable(const dxv_ctx* c) { return c->listState == 1 && c->listOpt == c->optListRes; }
+} // namespace
+
+size_t dxv_scene_bytes(const dxv_ctx* c)
+{
+    if (!c || !c->haveScene) return 0;
+    return lists_exportable(c) ? blob_layout(c->sceneBytes, c->listRes, c->listEntries).total : c->sceneBytes;
+}
+
+int dxv_build_lists(dxv_ctx* c)
+{
+    if (!c) return 1;
+    if (!c->haveScene) return fail(c, "dxv_build_lists: no scene");
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (c->listState != 0 && c->listOpt == c->optListRes) return 0;
+    if (sync_frames(c)) return 1;
+    return build_lists(c, c->stream);
+}
 
 int dxv_scene_export(dxv_ctx* c, void* dst, size_t bytes)
 {
     if (!c) return 1;
     if (!c->haveScene) return fail(c, "dxv_scene_export: no scene");
-    if (!dst || bytes != c->sceneBytes) return fail(c, "dxv_scene_export: expected %zu bytes, got %zu", c->sceneBytes, bytes);
+    const bool withLists = lists_exportable(c);
+    const BlobLayout b = blob_layout(c->sceneBytes, withLists ? c->listRes : 0u, withLists ? c->listEntries : 0u);
+    if (!dst || bytes != b.total) return fail(c, "dxv_scene_export: expected %zu bytes, got %zu", b.total, bytes);
     DXV_HIP(c, hipSetDevice(c->device));
-    DXV_HIP(c, hipMemcpyAsync(dst, c->dScene, bytes, hipMemcpyDeviceToDevice, c->stream));
+    DXV_HIP(c, hipMemcpyAsync(dst, c->dScene, c->sceneBytes, hipMemcpyDeviceToDevice, c->stream));
+    SceneHeader h = c->hdr;
+    h.offListCells = h.offListEntries = 0; h.listRes = h.listCount = 0;
+    if (withLists) {
+        uint8_t* out = static_cast<uint8_t*>(dst);
+        DXV_HIP(c, hipMemcpyAsync(out + b.offCells, c->dListCells, b.cellBytes, hipMemcpyDeviceToDevice, c->stream));
+        if (b.entryBytes) DXV_HIP(c, hipMemcpyAsync(out + b.offEntries, c->dListEntries, b.entryBytes, hipMemcpyDeviceToDevice, c->stream));
+        h.offListCells = b.offCells; h.offListEntries = b.offEntries; h.listRes = c->listRes; h.listCount = c->listEntries;
+    }
+    h.totalBytes = b.total;
+    DXV_HIP(c, hipMemcpyAsync(dst, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));     // the blob's own header (the resident one keeps the scene's size)
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -919,8 +963,13 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     if (h.magic != kSceneMagic || h.version != kSceneVersion) return fail(c, "dxv_scene_import: bad magic/version");
     SceneHeader want;
     layout_scene(want, h.numTris, h.numVerts, h.hasWide != 0);
-    if (!h.numTris || want.totalBytes != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
-        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.hasWide > 1u || h.treeHeight == 0 || h.treeHeight > 64)
+    const bool withLists = h.listRes != 0;
+    if (withLists && (h.listRes < 16u || h.listRes > 4096u || (h.listRes & (h.listRes - 1u)) || h.listCount > 0x7fffffffu))
+        return fail(c, "dxv_scene_import: inconsistent list section (res=%u, entries=%u)", h.listRes, h.listCount);
+    const BlobLayout b = blob_layout(want.totalBytes, withLists ? h.listRes : 0u, withLists ? h.listCount : 0u);
+    if (!h.numTris || b.total != bytes || h.totalBytes != bytes || h.offNodes != want.offNodes ||
+        h.offTriPos != want.offTriPos || h.offTriNrm != want.offTriNrm || h.offNodes32 != want.offNodes32 || h.offNodes64 != want.offNodes64 || h.hasWide > 1u || h.treeHeight == 0 || h.treeHeight > 64 ||
+        (withLists && (h.offListCells != b.offCells || h.offListEntries != b.offEntries)) || (!withLists && (h.offListCells || h.offListEntries || h.listCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
     c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
@@ -932,12 +981,35 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     c->dVb = nullptr; c->dIb = nullptr; c->haveMesh = false;
     free_scratch(c);
     if (alloc_scene(c, h.numTris, h.numVerts, h.hasWide != 0)) return 1;
-    DXV_HIP(c, hipMemcpyAsync(c->dScene, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    DXV_HIP(c, hipMemcpyAsync(c->dScene, src, want.totalBytes, hipMemcpyDeviceToDevice, c->stream));
+    if (withLists) {
+        // the lists travel with the scene: adopt them instead of building them again (1-5 ms per rank at 1 M triangles)
+        const size_t cells = 6 * (size_t)h.listRes * h.listRes;
+        if (cells > c->listCellCap) {
+            (void)hipFree(c->dListCells); c->dListCells = nullptr; c->listCellCap = 0;
+            DXV_HIP(c, hipMalloc(&c->dListCells, cells * sizeof(DirCell)));
+            c->listCellCap = cells;
+        }
+        if ((size_t)h.listCount > c->listEntryCap) {
+            (void)hipFree(c->dListEntries); c->dListEntries = nullptr; c->listEntryCap = 0;
+            DXV_HIP(c, hipMalloc(&c->dListEntries, ((size_t)h.listCount + 1) * sizeof(DirEntry)));
+            c->listEntryCap = h.listCount;
+        }
+        const uint8_t* in = static_cast<const uint8_t*>(src);
+        DXV_HIP(c, hipMemcpyAsync(c->dListCells, in + b.offCells, b.cellBytes, hipMemcpyDeviceToDevice, c->stream));
+        if (b.entryBytes) DXV_HIP(c, hipMemcpyAsync(c->dListEntries, in + b.offEntries, b.entryBytes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    const uint32_t listRes = h.listRes, listCount = h.listCount;
+    h.offListCells = h.offListEntries = 0; h.listRes = h.listCount = 0; h.totalBytes = want.totalBytes;   // the resident header describes the resident scene
+    DXV_HIP(c, hipMemcpyAsync(c->dScene, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->hdr = h;
     c->T = h.numTris; c->V = h.numVerts;
     memcpy(c->bound, h.bound, sizeof(c->bound));
     c->haveScene = true;
+    if (withLists && (c->optListRes == 0 || (uint32_t)c->optListRes == listRes)) {   // (an explicit listres of another size: built here as asked)
+        c->listEntries = listCount; c->listRes = listRes; c->listState = 1; c->listOpt = c->optListRes; c->listMs = 0.0f;
+    }
     c->stackNow = stack_round_up((int)(h.treeHeight + 3 < (uint32_t)c->optStack0 ? h.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_tris = h.numTris; c->stats.num_verts = h.numVerts; c->stats.num_nodes = h.numNodes;
     c->stats.tree_height = h.treeHeight;

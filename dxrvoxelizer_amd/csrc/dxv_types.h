@@ -62,7 +62,7 @@ struct alignas(16) TriPos { F4 v0, v1, v2; };
 // Vertex normals of the same triangle (hlsl:102-107, :114-116), fetched once per ray at the end.
 struct alignas(16) TriNrm { F4 n0, n1, n2; };
 
-// Relocatable scene blob: [SceneHeader | nodes | nodes32 | nodes64 | triPos | triNrm], sections 256-B aligned.
+// Relocatable scene blob: [SceneHeader | nodes | nodes32 | nodes64 | triPos | triNrm | (list cells | list entries)], sections 256-B aligned.
 struct SceneHeader {
     uint32_t magic;       // 'DXVS'
     uint32_t version;
@@ -77,12 +77,16 @@ struct SceneHeader {
     uint64_t offNodes64;  // wide nodes: present (numNodes entries) only when hasWide
     uint32_t hasWide;
     float triExtent;      // mean extent of a triangle's box along y and z, normalised units (parity row blocks)
-    uint32_t pad[26];
+    // Optional trailing sections of an EXPORTED blob: the direction-space lists of the reference rule (dxv_dirmap.h), so that
+    // the ranks that import the scene need not build them again.  0 / 0 when the blob carries none.
+    uint64_t offListCells, offListEntries;
+    uint32_t listRes, listCount;
+    uint32_t pad[20];
 };
 static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
 
 constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
-constexpr uint32_t kSceneVersion = 6;
+constexpr uint32_t kSceneVersion = 7;
 
 // canonical constants (hlsl:5, :76-77)
 constexpr float kThreshold = 0.12f;

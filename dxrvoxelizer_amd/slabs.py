@@ -56,6 +56,8 @@ def broadcast_scene(engine, dist, device, src=0):
     rank = dist.get_rank()
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
+        if hasattr(engine, "build_lists"):
+            engine.build_lists()              # the candidate lists travel with the blob: the other ranks adopt them
         n[0] = engine.scene_bytes()
     dist.broadcast(n, src=src)
     nbytes = int(n.item())

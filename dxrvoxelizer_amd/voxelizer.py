@@ -181,6 +181,10 @@ class Voxelizer:
         self._check(self._lib.dxv_get_stats(self._ctx, C.byref(s)))
         return s.as_dict()
 
+    def build_lists(self):
+        """Build the candidate lists of the reference rule now (they then travel with scene_export)."""
+        self._check(self._lib.dxv_build_lists(self._ctx))
+
     def scene_bytes(self):
         return self._lib.dxv_scene_bytes(self._ctx)
 

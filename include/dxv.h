@@ -175,6 +175,10 @@ DXV_API int dxv_render(dxv_ctx* ctx, const float eye[3], const float view_proj[1
  * rank 0 builds once and the host layer broadcasts it (RCCL over xGMI) to the other ranks.
  * export copies the blob into caller-provided DEVICE memory; import adopts a blob from DEVICE
  * memory as if dxv_set_mesh + dxv_build had run here. */
+/* The candidate lists of the reference rule (direction-space lists) are built at a scene's first or
+ * second launch (option lists); dxv_build_lists builds them now.  A scene exported after that carries them as two more
+ * sections of the blob, and the importing contexts adopt them instead of building their own. */
+DXV_API int dxv_build_lists(dxv_ctx* ctx);
 DXV_API size_t dxv_scene_bytes(const dxv_ctx* ctx);
 DXV_API int dxv_scene_export(dxv_ctx* ctx, void* device_dst, size_t bytes);
 DXV_API int dxv_scene_import(dxv_ctx* ctx, const void* device_src, size_t bytes);

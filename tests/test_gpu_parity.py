@@ -353,6 +353,25 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     b.scene_import(blob.data_ptr(), n)                    # narrow blob with the option still on: binary walk
     b.Voxelize(64)
     assert np.array_equal(b.Grid(), want)
+    # the candidate lists travel with the blob once they exist: the importer adopts them and builds nothing
+    a.build_lists()
+    n3 = a.scene_bytes()
+    assert n3 > n2
+    blob3 = torch.empty(n3, dtype=torch.uint8, device="cuda")
+    a.scene_export(blob3.data_ptr(), n3)
+    torch.cuda.synchronize()
+    b.scene_import(blob3.data_ptr(), n3)
+    a.Voxelize(64), a.Voxelize(64), b.Voxelize(64)          # (a's second launch of the scene: lists; b: lists from the first, none built)
+    sa, sb = a.stats(), b.stats()
+    assert sa["list_entries"] == sb["list_entries"] > 0 and sa["list_res"] == sb["list_res"] and sb["list_ms"] == 0.0
+    assert np.array_equal(a.Grid(), want) and np.array_equal(b.Grid(), want)
+    assert np.array_equal(a.debug(DBG_LIST_CELLS), b.debug(DBG_LIST_CELLS)) and np.array_equal(a.debug(DBG_LIST_ENTRIES), b.debug(DBG_LIST_ENTRIES))
+    with pytest.raises(dxv.DxvError):
+        b.scene_import(blob3.data_ptr(), n3 - 256)         # truncated blob
+    b.set_option("listres", 64)                           # an importer that wants another map builds its own
+    b.scene_import(blob3.data_ptr(), n3)
+    b.Voxelize(64)
+    assert b.stats()["list_res"] == 64 and np.array_equal(b.Grid(), want)
     a.close(), b.close()
 
 
