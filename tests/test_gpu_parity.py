@@ -369,6 +369,7 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     with pytest.raises(dxv.DxvError):
         b.scene_import(blob3.data_ptr(), n3 - 256)         # truncated blob
     b.set_option("listres", 64)                           # an importer that wants another map builds its own
+    b.set_option("lists", 2)                              # (at its first launch)
     b.scene_import(blob3.data_ptr(), n3)
     b.Voxelize(64)
     assert b.stats()["list_res"] == 64 and np.array_equal(b.Grid(), want)
