@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void k_dm_hints(DirCell* __restrict__ cel
 }
 
 // count and far radius of every texel: the thread of a texel's LAST key (the lists are sorted by far radius) reads the begin
-// its first key wrote in k_dm_cells; also the longest list of the map (the count field has 16 bits)
+// its first key wrote in k_dm_cells; lists too long for the 16-bit count field are reported through `longest`
 __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restrict__ keys, uint32_t n, uint32_t R, DirCell* __restrict__ cells,
                                                        const DirEntry* __restrict__ entries, uint32_t* __restrict__ longest)
 {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
     uint32_t* words = reinterpret_cast<uint32_t*>(cells + cell);
     const uint32_t count = i + 1u - words[0];
     words[1] = (count < 0xffffu ? count : 0xffffu) | (((entries[i].rr >> 16) & 0x7fffu) << 16);
-    atomicMax(longest, count);
+    if (count > 0xffffu) atomicMax(longest, count);                    // (only what does not fit is reported: one address, 300 k texels)
 }
 } // namespace
 

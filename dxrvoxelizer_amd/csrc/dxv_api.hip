@@ -91,6 +91,8 @@ struct dxv_ctx {
                                      // 1 = from a scene's second launch on, 2 = from the first, 0 = tree walk
     int optListRes = 0;              // texels per face side; 0 = by triangle count (list_resolution)
     float listMs = 0.0f;
+    uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
+    size_t listScratchACap = 0, listScratchBCap = 0;
     uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
     int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
@@ -273,9 +275,19 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
     const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
     // scratch in two allocations (an allocation costs ~0.1 ms, as much as a pass): per-(triangle, face)
     // arrays now, the key buffers once the number of entries is known
+    // (kept with the context up to 1 GiB each: an allocation costs ~0.1 ms, as much as a pass of the build)
     uint8_t *scratchA = nullptr, *scratchB = nullptr;
+    auto scratch = [&](uint8_t*& keep, size_t& cap, size_t bytes, uint8_t*& out) -> hipError_t {
+        if (bytes <= cap) { out = keep; return hipSuccess; }
+        (void)hipFree(keep); keep = nullptr; cap = 0;
+        const hipError_t err = hipMalloc(&out, bytes);
+        if (err == hipSuccess && bytes <= (1ull << 30)) { keep = out; cap = bytes; }
+        return err;
+    };
     auto release = [&]() {
-        (void)hipFree(scratchA); (void)hipFree(scratchB);
+        if (scratchA != c->dListScratchA) (void)hipFree(scratchA);
+        if (scratchB != c->dListScratchB) (void)hipFree(scratchB);
+        scratchA = scratchB = nullptr;
         if (t0) (void)hipEventDestroy(t0);
         if (t1) (void)hipEventDestroy(t1);
         t0 = t1 = nullptr;
@@ -294,7 +306,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
     hipError_t e;
     const size_t offCounts = align256(n6 * sizeof(DirRecord)), offOffsets = offCounts + align256(n6 * 4),
                  offSums = offOffsets + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
-    if ((e = hipMalloc(&scratchA, offTotal + 256)) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = scratch(c->dListScratchA, c->listScratchACap, offTotal + 256, scratchA)) != hipSuccess) return bail(e, "hipMalloc");
     DirRecord* rec = reinterpret_cast<DirRecord*>(scratchA);
     uint32_t* counts = reinterpret_cast<uint32_t*>(scratchA + offCounts);
     uint32_t* offsets = reinterpret_cast<uint32_t*>(scratchA + offOffsets);
@@ -347,7 +359,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
         c->listEntryCap = n;
     }
     const size_t keyBytes = align256(((size_t)n + 1) * 8);
-    if ((e = hipMalloc(&scratchB, 2 * keyBytes + sizeof(uint32_t) * (size_t)radix_sort_hist_words(n ? n : 1))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = scratch(c->dListScratchB, c->listScratchBCap, 2 * keyBytes + sizeof(uint32_t) * (size_t)radix_sort_hist_words(n ? n : 1), scratchB)) != hipSuccess) return bail(e, "hipMalloc");
     uint64_t* keys = reinterpret_cast<uint64_t*>(scratchB);
     uint64_t* keysTmp = reinterpret_cast<uint64_t*>(scratchB + keyBytes);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratchB + 2 * keyBytes);
@@ -404,7 +416,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
             p.lists = 1u;
             p.ablate = (uint32_t)c->optAblate;
             p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
-            st = 8;                                                 // no stack: the smallest column (the queue of selected triangles)
+            st = c->optStack == 16 ? 16 : 8;                        // no stack: the column is the queue of selected triangles
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
             f.list_entries = c->listEntries; f.list_res = c->listRes;
         }
@@ -487,7 +499,7 @@ void dxv_destroy(dxv_ctx* c)
     }
     free_scratch(c);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene);
-    (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries);
+    (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
     (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);

@@ -379,11 +379,13 @@ DXV_HD DirEntry dm_local_entry(const DirRecord& rec, uint32_t R, uint32_t i, uin
         if (cd < -16256.0) cd = -16256.0;                               // (more permissive: safe)
         const int c = (int)cd;
         const int c1b = c / 127, c2b = c - 127 * c1b;                   // truncation: |c2b| < 127
-        // how much of the box does it remove?  (4 x 4 cell samples)
-        int cut = 0;
-        for (int sy = 0; sy < 4; ++sy)
-            for (int sx = 0; sx < 4; ++sx) {
-                const int x = (int)x0 + (int)((x1 - x0) * (2 * sx + 1) / 8), y = (int)y0 + (int)((y1 - y0) * (2 * sy + 1) / 8);
+        // how much of the box does it remove?  Nothing when the box's corner farthest outside is still inside; else 3 x 3 samples
+        const int worst = a * (int)(a < 0 ? x1 : x0) + b * (int)(b < 0 ? y1 : y0) + c;
+        if (worst >= 0) continue;
+        int cut = 1;
+        for (int sy = 0; sy < 3; ++sy)
+            for (int sx = 0; sx < 3; ++sx) {
+                const int x = (int)x0 + (int)((x1 - x0) * (2 * sx + 1) / 6), y = (int)y0 + (int)((y1 - y0) * (2 * sy + 1) / 6);
                 if (a * x + b * y + c < 0) ++cut;
             }
         if (cut > bestCut) {

@@ -530,9 +530,10 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 g((uint32_t)grid), b(B::threads);
     if (p.mode == 0 && p.lists) {
-        // direction-space lists: no stack (the caller passes the smallest column)
-        if constexpr (STACK == 8) {
-            if constexpr (B::threads == 64 && B::x == 4) {     // timing-only ablations of the default shape (tools/ablate.py)
+        // direction-space lists: no stack, the column is the queue of selected triangles (8 entries; 16 for deep scenes,
+        // where a ray meets many candidates before its first flush)
+        if constexpr (STACK == 8 || STACK == 16) {
+            if constexpr (B::threads == 64 && B::x == 4 && STACK == 8) {     // timing-only ablations of the default shape (tools/ablate.py)
                 switch (p.ablate) {
                 case 0: break;
                 case 1: k_voxelize<B, 8, 0, false, 4, 1><<<g, b, 0, s>>>(p); return hipGetLastError();
@@ -543,8 +544,8 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
                 default: return hipErrorInvalidValue;
                 }
             }
-            if (p.texels) k_voxelize<B, 8, 0, true, 4><<<g, b, 0, s>>>(p);
-            else k_voxelize<B, 8, 0, false, 4><<<g, b, 0, s>>>(p);
+            if (p.texels) k_voxelize<B, STACK, 0, true, 4><<<g, b, 0, s>>>(p);
+            else k_voxelize<B, STACK, 0, false, 4><<<g, b, 0, s>>>(p);
         } else return hipErrorInvalidValue;
     } else if (p.mode == 0) {
         if (p.texels) {

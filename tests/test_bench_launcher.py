@@ -51,3 +51,20 @@ def test_parent_does_not_touch_torch_before_launching():
                         "assert 'torch' not in sys.modules and 'dxrvoxelizer_amd' not in sys.modules" % ROOT],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_real_ranks_on_one_gpu_through_the_launcher(grids_json):
+    """The whole multi-rank path with real engines: `python bench.py --gpus 2` starts two ranks (both on cuda:0, gloo:
+    RCCL refuses two ranks per GPU), rank 0 builds the LBVH and the lists, the blob is broadcast, rank 1 imports it, each
+    rank voxelizes its share of the block-cyclic Z partition; the summed solid count must be the oracle's."""
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--same-device", "--no-cpu-baseline", "--no-extras", "--mesh", "bunny",
+                  "--grid", "128", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["slab_slices_rank0"] == 64
+    assert out["config"]["solid_voxels"] == grids_json["bunny/128/reference"]["solid"]
+    assert out["config"]["candidates"]["structure"] == "direction-space lists" and out["value"] > 0
