@@ -279,6 +279,75 @@ __attribute__((visibility("default"))) void hc_trace_stats(void* p, uint32_t N, 
 }
 
 static bool scells_any(const bool* b) { for (int t = 0; t < 64; ++t) if (b[t]) return true; return false; }
+// Lists replay per 4x4x4 brick (design aid; tools/list_stats.py): out[0] waves with a live lane, [1] live lanes, [2] lanes
+// ended by the texel's far radius, [3] waves without a scanning lane, [4] distinct texels of the scanning lanes (sum over
+// waves), [5] their lists' lengths together, [6] entries scanned (start search to early stop), [7] sum over waves of the
+// longest lane scan, [8] entries whose byte box contains the ray, [9] ... that also pass the edge = triangles selected,
+// [10] sum over waves of the most selections of a lane (= triangle-step rounds), [11] lanes with a hit
+__attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, uint32_t bstep, uint64_t* out)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    float rootLo[3], rootHi[3];
+    {
+        const float* w = reinterpret_cast<const float*>(&s->nodes[0]);
+        for (int a = 0; a < 3; ++a) { rootLo[a] = min_(w[a], w[6 + a]); rootHi[a] = max_(w[3 + a], w[9 + a]); }
+    }
+    const uint32_t nb = N / 4, R = s->dmR;
+    uint64_t o[12] = {0};
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : o[:12])
+    for (int64_t bzi = 0; bzi < (int64_t)nb; bzi += bstep) {
+        for (uint32_t byi = 0; byi < nb; ++byi) for (uint32_t bxi = 0; bxi < nb; ++bxi) {
+            int nlive = 0;
+            std::vector<uint32_t> cellsSeen;
+            uint64_t mScan = 0, mSel = 0;
+            for (int t = 0; t < 64; ++t) {
+                const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
+                Ray r;
+                ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+                if (origin_leaves_root(r.ox, r.oy, r.oz, rootLo, rootHi)) continue;
+                finish_ray_reference(r);
+                nlive++;
+                uint32_t face, ti, tj, cx, cy; float u, v, rho;
+                dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
+                dm_local(u, R, ti, cx); dm_local(v, R, tj, cy);
+                const uint32_t ci = (face * R + tj) * R + ti;
+                const DirCell cell = s->dmCells[ci];
+                const float near = rho * 0.999f;
+                if (half_bits_to_float(cell.r1max) < near || !cell.count) { o[2]++; continue; }
+                cellsSeen.push_back(ci);
+                const DirRayLocal loc = dm_ray_local(cx, cy);
+                uint32_t i = cell.begin, hi = cell.begin + cell.count;
+                while (hi > i) { const uint32_t mid = i + ((hi - i) >> 1); if (dm_entry_r1(s->dmEntries[mid]) < near) i = mid + 1u; else hi = mid; }
+                const float thick = half_bits_to_float(cell.thick);
+                Hit best; best.t = kTMax; best.k = 0xffffffffu; best.leaf = -1; best.b1 = best.b2 = 0;
+                uint64_t scan = 0, sel = 0;
+                for (uint32_t e = i; e < cell.begin + cell.count; ++e) {
+                    const DirEntry& en = s->dmEntries[e];
+                    const float bound = (rho + best.t) * 1.001f + 1e-4f;
+                    if (dm_entry_r1(en) - thick > bound) break;
+                    scan++;
+                    DirEntry boxOnly = en; boxOnly.edge = 0u;
+                    const uint32_t rc = dm_radial_word(near, bound);
+                    if (dm_local_pass(boxOnly, loc, rc)) o[8]++;
+                    if (dm_local_pass(en, loc, rc)) { sel++; leaf_reference(r, s->triPos.data(), (int32_t)en.tri, best); }
+                }
+                o[6] += scan; o[9] += sel;
+                if (scan > mScan) mScan = scan;
+                if (sel > mSel) mSel = sel;
+                if (best.k != 0xffffffffu) o[11]++;
+            }
+            if (!nlive) continue;
+            o[0]++; o[1] += nlive; o[7] += mScan; o[10] += mSel;
+            if (cellsSeen.empty()) o[3]++;
+            std::sort(cellsSeen.begin(), cellsSeen.end());
+            cellsSeen.erase(std::unique(cellsSeen.begin(), cellsSeen.end()), cellsSeen.end());
+            o[4] += cellsSeen.size();
+            for (uint32_t ci : cellsSeen) o[5] += s->dmCells[ci].count;
+        }
+    }
+    for (int i = 0; i < 12; ++i) out[i] = o[i];
+}
+
 static uint64_t g_uniform = 0, g_distinct = 0;
 #pragma omp threadprivate(g_uniform, g_distinct)
 // Lockstep (SIMT) replay of the reference-mode loop for 4x4x4-voxel waves: every iteration each
