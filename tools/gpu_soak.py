@@ -15,11 +15,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dxrvoxelizer_amd as dxv  # noqa: E402
 from dxrvoxelizer_amd import camera, meshes  # noqa: E402
 from oracle import orc  # noqa: E402
-from test_fuzz import lattice_mesh  # noqa: E402
+from test_fuzz import lattice_mesh, needle_mesh  # noqa: E402
 
 
 def random_mesh(rng):
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 7)
+    if kind == 6:
+        n = int(rng.choice([5, 60, 400, 2500]))
+        return needle_mesh(rng, n, int(rng.choice([8, 16, 32]))), f"needles{n}"
     if kind == 0:
         n = int(rng.choice([1, 2, 3, 7, 30, 200, 1500]))
         return lattice_mesh(rng, n, int(rng.choice([8, 16, 32]))), f"lattice{n}"
@@ -71,6 +74,7 @@ def main():
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))
+            v.SetFrame(int(rng.integers(0, 3)))               # any of the context's frames in flight
             try:
                 if part == 0:
                     v.Voxelize(N, mode)
