@@ -152,6 +152,22 @@ __global__ __launch_bounds__(kThreads) void k_dm_hints(DirCell* __restrict__ cel
     if (h.has3) cells[c].q3 = r1(h.m3);
 }
 
+// stop codes (dm_stop_code): one thread per texel walks its list from the far end, carrying the earliest start seen so far
+__global__ __launch_bounds__(kThreads) void k_dm_stops(const DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries)
+{
+    const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= ncells) return;
+    const DirCell cell = cells[c];
+    const float step = dm_stop_step(half_bits_to_float(cell.thick));
+    float s = 3.0e38f;
+    for (uint32_t k = cell.count; k-- > 0u;) {
+        DirEntry& e = entries[cell.begin + k];
+        const float r0 = dm_entry_r0(e);
+        if (r0 < s) s = r0;
+        e.tri = (e.tri & kDmTriMask) | (dm_stop_code(dm_entry_r1(e), s, step) << kDmTriBits);
+    }
+}
+
 // count and far radius of every texel: the thread of a texel's LAST key (the lists are sorted by far radius) reads the begin
 // its first key wrote in k_dm_cells; lists too long for the 16-bit count field are reported through `longest`
 __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restrict__ keys, uint32_t n, uint32_t R, DirCell* __restrict__ cells,
@@ -213,6 +229,7 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums);
     const uint32_t ncells = 6u * R * R;
     k_dm_hints<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
+    k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     return hipGetLastError();
 }

@@ -339,7 +339,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
         if (total > (320ull << 20) && recount(128u)) return 1;
     }
     const unsigned long long cap = 256ull * T + (64ull << 20);
-    if (total > cap || total > 0x7fffffffull || (unsigned long long)T > (1ull << dm_key_layout(R).triBits)) {
+    if (total > cap || total > 0x7fffffffull || (unsigned long long)T > (1ull << dm_key_layout(R).triBits) || T > kDmTriMask) {
         release();
         c->listState = -1;
         c->listEntries = 0;

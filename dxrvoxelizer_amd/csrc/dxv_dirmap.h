@@ -36,7 +36,10 @@ namespace dxv {
 //         edge crosses the box).  A triangle fills at most half of its box: this halves the triangle tests.
 //   rr    (0x7fff - r0) | r1 << 16 | 0x80008000, r0 / r1 the outward-rounded radial range as halfs: positive halfs
 //         order like integers, so r1 >= near and r0 <= (start + closest hit) are one packed subtraction as well.
-//   tri   position in the scene's triangle order (TriPos index)
+//   tri   position in the scene's triangle order (TriPos index) in the low 26 bits; the high 6 bits say how far behind this
+//         entry's far radius the EARLIEST start of any later entry of the texel lies, in 63rds of the texel's thickest
+//         entry (rounded up): the scan stops at the first entry for which that point is beyond the closest hit
+//         (dm_stop_radius).  Lists therefore serve scenes of up to 2^26 triangles.
 struct alignas(16) DirEntry {
     uint32_t box, edge, rr, tri;
 };
@@ -59,7 +62,7 @@ struct alignas(16) DirCell {                        // one 16-byte load per ray
     uint32_t begin;                                 // the texel's entries: [begin, begin + count)
     uint16_t count;                                 // (a scene with more than 65,535 entries in one texel keeps the tree walk)
     uint16_t r1max;                                 // far radius of its last entry (half bits): a ray that starts beyond it has no candidate
-    uint16_t thick;                                 // largest radial extent r1 - r0 of its entries (half bits, rounded up): where a scan may stop
+    uint16_t thick;                                 // largest radial extent r1 - r0 of its entries (half bits, rounded up): the unit of the entries' stop codes
     // The first two steps of the binary search for a ray's start need no load: the far radii (half bits) of the entries
     // the search would look at -- the middle one, and the middles of both halves (dm_search_hints).  Lists of up to 35
     // entries (all of a surface mesh's) are then down to the eight entries a scan round starts with anyway.
@@ -150,6 +153,19 @@ DXV_HD uint32_t dm_radial_word(float near, float bound)
 DXV_HD bool dm_local_pass(const DirEntry& e, const DirRayLocal& l, uint32_t rc)
 {
     return ((l.q - e.box) & 0x80808080u) == 0x80808080u && ((e.rr - rc) & 0x80008000u) == 0x80008000u && dm_dot4(e.edge, l.p) >= 0;
+}
+constexpr uint32_t kDmTriBits = 26u, kDmTriMask = (1u << kDmTriBits) - 1u;
+DXV_HD uint32_t dm_entry_tri(const DirEntry& e) { return e.tri & kDmTriMask; }
+// The lists are sorted by far radius.  No entry from this one on starts before  r1 - q * (thick / 63):  q is chosen by
+// the builder (dm_stop_code) with this very expression, so the float arithmetic is the same on both sides.
+DXV_HD float dm_stop_step(float thick) { return thick * 0.015873017f; }                     // a little more than 1 / 63
+DXV_HD float dm_stop_radius(const DirEntry& e, float step) { return half_bits_to_float((e.rr >> 16) & 0x7fffu) - (float)(e.tri >> kDmTriBits) * step; }
+// smallest q in [0, 63] with r1 - q * step <= suffixMinR0 (r1 - 63 * step <= r1 - thick <= every later start: always found)
+DXV_HD uint32_t dm_stop_code(float r1, float suffixMinR0, float step)
+{
+    uint32_t q = 0;
+    while (q < 63u && r1 - (float)q * step > suffixMinR0) ++q;
+    return q;
 }
 DXV_HD float dm_entry_r1(const DirEntry& e) { return half_bits_to_float((e.rr >> 16) & 0x7fffu); }
 DXV_HD float dm_entry_r0(const DirEntry& e) { return half_bits_to_float(0x7fffu - (e.rr & 0x7fffu)); }
@@ -454,7 +470,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         if (dm_entry_r1(dm.entries[mid]) < near) i = mid + 1u; else hi = mid;
     }
     int qn = 0;
-    const float thick = half_bits_to_float(cell.thick);
+    const float step = dm_stop_step(half_bits_to_float(cell.thick));
     DirRayLocal loc = dm_ray_local(cx, cy);
     uint32_t rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);   // radial cut: r1 >= near, r0 not beyond the closest hit so far
     for (;;) {
@@ -468,15 +484,16 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             const DirEntry e0 = dm.entries[i], e1 = dm.entries[i + 1u < last ? i + 1u : last];
             DirEntry e2 = e0, e3 = e0;
             if (wide) { e2 = dm.entries[i + 2u < last ? i + 2u : last]; e3 = dm.entries[i + 3u < last ? i + 3u : last]; }
-            // The list is sorted by far radius and no entry of the texel is thicker than `thick`: once an entry ends more
-            // than that beyond the closest hit so far, it and everything behind it START beyond the hit.  (Surface meshes
-            // have short lists and gain little; in a deep soup a ray stops after the first few of hundreds of entries.)
-            if (dm_entry_r1(e0) - thick > (rho + best.t) * 1.001f + 1e-4f) i = end;
+            // The list is sorted by far radius and every entry knows (in 63rds of the texel's thickest entry) how far behind
+            // its far radius the earliest start of any LATER entry lies: once that point is beyond the closest hit so far,
+            // this entry and everything behind it start beyond the hit.  (Surface meshes have short lists and gain
+            // little; in a deep soup a ray stops after the first few of hundreds of entries.)
+            if (dm_stop_radius(e0, step) > (rho + best.t) * 1.001f + 1e-4f) i = end;
             else {
-                if (dm_local_pass(e0, loc, rc)) stk.put(qn++, (int32_t)e0.tri);
-                if (i + 1u <= last && dm_local_pass(e1, loc, rc)) stk.put(qn++, (int32_t)e1.tri);
-                if (i + 2u <= last && dm_local_pass(e2, loc, rc)) stk.put(qn++, (int32_t)e2.tri);
-                if (i + 3u <= last && dm_local_pass(e3, loc, rc)) stk.put(qn++, (int32_t)e3.tri);
+                if (dm_local_pass(e0, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e0));
+                if (i + 1u <= last && dm_local_pass(e1, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e1));
+                if (i + 2u <= last && dm_local_pass(e2, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e2));
+                if (i + 3u <= last && dm_local_pass(e3, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e3));
                 i += 4u;
             }
         }

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 // Test hook (dxv_debug_list_check): the lists' superset claim, checked exhaustively on the device.  For every voxel the
 // LBVH is walked WITHOUT distance culling; every triangle the canonical step accepts for the ray (own padded box passed,
 // watertight hit at 0 < t < TMax, box entry <= t) must be found in the ray's texel list and pass that entry's integer
-// test (box, edge, radial range) even with the radial cut already drawn at its own t -- then no order of scanning, no
+// test (box, edge, radial range) even with the radial cut already drawn at its own t, and lie in front of the point where a
+// scan holding a hit at that t stops -- then no order of scanning, no
 // cut by an earlier hit and no early stop can keep the closest hit out of the queue (dxv_dirmap.h).
 // out[0] accepted (ray, triangle) pairs, out[1] violations, out[2 + 2 k], out[3 + 2 k]: voxel id and triangle slot of the
 // first 16 violations.  Not a product path.
@@ -131,10 +132,12 @@ __global__ __launch_bounds__(64) void k_list_check(VoxelizeParams p, unsigned lo
         atomicAdd(out, 1ull);
         const uint32_t rc = dm_radial_word(near, (rho + t) * 1.001f + 1e-4f);
         bool found = false;
+        const float step = dm_stop_step(half_bits_to_float(cell.thick)), bound = (rho + t) * 1.001f + 1e-4f;
         if (!(half_bits_to_float(cell.r1max) < near))
             for (uint32_t k = cell.begin; k < cell.begin + cell.count && !found; ++k) {
                 const DirEntry e = dm.entries[k];
-                found = e.tri == (uint32_t)l && dm_local_pass(e, loc, rc);
+                if (dm_stop_radius(e, step) > bound) break;             // a scan with this hit in hand would stop here: the entry must come before
+                found = dm_entry_tri(e) == (uint32_t)l && dm_local_pass(e, loc, rc);
             }
         if (!found) {
             const unsigned long long slot = atomicAdd(out + 1, 1ull);

@@ -120,6 +120,8 @@ def hostcheck():
     L.hc_half_down.restype = C.c_uint32
     L.hc_half_up.argtypes = [C.c_float]
     L.hc_half_up.restype = C.c_uint32
+    L.hc_dm_half_pos.argtypes = [C.c_float, C.c_int]
+    L.hc_dm_half_pos.restype = C.c_uint32
     L.hc_half_to_float.argtypes = [C.c_uint32]
     L.hc_half_to_float.restype = C.c_float
     L.hc_voxelize.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_int, u8p, C.c_void_p]

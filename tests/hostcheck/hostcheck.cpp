@@ -149,6 +149,13 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
         if (th > s->dmCells[cell].thick) s->dmCells[cell].thick = (uint16_t)th;
     }
     for (DirCell& cell : s->dmCells) {
+        const float step = dm_stop_step(half_bits_to_float(cell.thick));   // stop codes: from the far end, earliest start so far
+        float smin = 3.0e38f;
+        for (uint32_t k = cell.count; k-- > 0u;) {
+            DirEntry& e = s->dmEntries[cell.begin + k];
+            if (dm_entry_r0(e) < smin) smin = dm_entry_r0(e);
+            e.tri = (e.tri & kDmTriMask) | (dm_stop_code(dm_entry_r1(e), smin, step) << kDmTriBits);
+        }
         if (cell.count <= 8u) continue;
         const DirSearchHints h = dm_search_hints(cell.count);
         auto r1 = [&](uint32_t k) { return (uint16_t)((s->dmEntries[cell.begin + k].rr >> 16) & 0x7fffu); };
@@ -166,6 +173,7 @@ __attribute__((visibility("default"))) void hc_dirmap_get(void* p, void* cells, 
 }
 
 __attribute__((visibility("default"))) void hc_scene_nodes32(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes32.data(), s->nodes32.size() * sizeof(Node32)); }
+__attribute__((visibility("default"))) uint32_t hc_dm_half_pos(float x, int up) { return up ? dm_half_up_pos(x) : dm_half_down_pos(x); }
 __attribute__((visibility("default"))) uint32_t hc_half_down(float x) { return half_down(x); }
 __attribute__((visibility("default"))) uint32_t hc_half_up(float x) { return half_up(x); }
 __attribute__((visibility("default"))) float hc_half_to_float(uint32_t h) { return half_to_float((uint16_t)h); }
@@ -324,12 +332,12 @@ __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, u
                 for (uint32_t e = i; e < cell.begin + cell.count; ++e) {
                     const DirEntry& en = s->dmEntries[e];
                     const float bound = (rho + best.t) * 1.001f + 1e-4f;
-                    if (dm_entry_r1(en) - thick > bound) break;
+                    if (dm_stop_radius(en, dm_stop_step(thick)) > bound) break;
                     scan++;
                     DirEntry boxOnly = en; boxOnly.edge = 0u;
                     const uint32_t rc = dm_radial_word(near, bound);
                     if (dm_local_pass(boxOnly, loc, rc)) o[8]++;
-                    if (dm_local_pass(en, loc, rc)) { sel++; leaf_reference(r, s->triPos.data(), (int32_t)en.tri, best); }
+                    if (dm_local_pass(en, loc, rc)) { sel++; leaf_reference(r, s->triPos.data(), (int32_t)dm_entry_tri(en), best); }
                 }
                 o[6] += scan; o[9] += sel;
                 if (scan > mScan) mScan = scan;

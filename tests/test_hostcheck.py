@@ -234,3 +234,19 @@ def test_direction_space_lists_give_the_tree_walk_grid(orc, hostcheck, bunny):
                 h.lists(R)
                 got, ovf = h.voxelize(N, mode=12, stack=8)
                 assert ovf == 0 and np.array_equal(got, want), (n_tris, N, R)
+
+
+def test_ray_side_half_conversions_equal_the_general_ones(hostcheck):
+    """dm_half_down_pos / dm_half_up_pos (two integer instructions, what a ray uses for its radii in the lists' integer
+    radial test) == half_down / half_up on their domain: positive floats in the half's normal range [2^-14, 65504)."""
+    L = hostcheck.lib
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([
+        np.float32(2.0) ** rng.uniform(-14, 15.99, 20000).astype(np.float32),
+        np.array([2.0 ** -14, 0.999, 1.0, 1.0009765625, 1.001, 1.73, 1.75, 4e-4, 65503.9, 10010.0], np.float32),
+        (np.arange(1, 0x7bff, 7, dtype=np.uint32).astype(np.uint16).view(np.float16)).astype(np.float32)[15:],   # exact halfs (normal ones)
+    ]).astype(np.float32)
+    xs = xs[(xs >= np.float32(2.0 ** -14)) & (xs < np.float32(65504.0))]
+    for x in xs[:: max(1, len(xs) // 6000)]:
+        assert L.hc_dm_half_pos(float(x), 0) == L.hc_half_down(float(x)), x
+        assert L.hc_dm_half_pos(float(x), 1) == L.hc_half_up(float(x)), x
