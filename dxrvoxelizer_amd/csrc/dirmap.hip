@@ -152,12 +152,16 @@ __global__ __launch_bounds__(kThreads) void k_dm_hints(DirCell* __restrict__ cel
     if (h.has3) cells[c].q3 = r1(h.m3);
 }
 
-// stop codes (dm_stop_code): one thread per texel walks its list from the far end, carrying the earliest start seen so far
+// stop codes (dm_stop_code): the list is walked from the far end, carrying the earliest start seen so far.  Short lists
+// (all of a surface mesh's): one thread per texel; long ones (deep scenes: hundreds of entries): one wave per texel, 64
+// entries per step, the running minimum by a prefix scan across the lanes (lane 0 = the entry nearest the far end).
+constexpr uint32_t kStopsShort = 32u;
 __global__ __launch_bounds__(kThreads) void k_dm_stops(const DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries)
 {
     const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
     if (c >= ncells) return;
     const DirCell cell = cells[c];
+    if (cell.count > kStopsShort) return;
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
     float s = 3.0e38f;
     for (uint32_t k = cell.count; k-- > 0u;) {
@@ -167,7 +171,30 @@ __global__ __launch_bounds__(kThreads) void k_dm_stops(const DirCell* __restrict
         e.tri = (e.tri & kDmTriMask) | (dm_stop_code(dm_entry_r1(e), s, step) << kDmTriBits);
     }
 }
-
+__global__ __launch_bounds__(64) void k_dm_stops_long(const DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries)
+{
+    const uint32_t c = blockIdx.x;
+    if (c >= ncells) return;
+    const DirCell cell = cells[c];
+    if (cell.count <= kStopsShort) return;
+    const float step = dm_stop_step(half_bits_to_float(cell.thick));
+    const uint32_t lane = threadIdx.x;
+    float carry = 3.0e38f;
+    for (uint32_t base = 0; base < cell.count; base += 64u) {
+        const bool valid = base + lane < cell.count;
+        const uint32_t k = valid ? cell.begin + cell.count - 1u - base - lane : cell.begin;
+        const DirEntry e = entries[k];
+        float v = valid ? dm_entry_r0(e) : 3.0e38f;
+        for (int off = 1; off < 64; off <<= 1) {
+            const float o = __shfl_up(v, off);
+            if ((int)lane >= off && o < v) v = o;
+        }
+        const float s = v < carry ? v : carry;
+        if (valid) entries[k].tri = (e.tri & kDmTriMask) | (dm_stop_code(dm_entry_r1(e), s, step) << kDmTriBits);
+        const float last = __shfl(v, 63);
+        if (last < carry) carry = last;
+    }
+}
 // count and far radius of every texel: the thread of a texel's LAST key (the lists are sorted by far radius) reads the begin
 // its first key wrote in k_dm_cells; lists too long for the 16-bit count field are reported through `longest`
 __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restrict__ keys, uint32_t n, uint32_t R, DirCell* __restrict__ cells,
@@ -230,6 +257,7 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     const uint32_t ncells = 6u * R * R;
     k_dm_hints<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
     k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
+    k_dm_stops_long<<<ncells, 64, 0, s>>>(cells, ncells, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     return hipGetLastError();
 }

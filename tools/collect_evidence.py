@@ -92,7 +92,7 @@ def main():
             "round": int(ROUND[1:])}
         with open(tj, "w") as fh:
             json.dump(traffic, fh, indent=1)
-    print(json.dumps({k: {n: round(v, 1) for n, v in c.items()} for k, c in out["kernels"].items()}, indent=1)[:3000])
+    print(json.dumps({k: {n: (round(v, 1) if isinstance(v, float) else v) for n, v in c.items()} for k, c in out["kernels"].items()}, indent=1)[:3000])
 
 
 if __name__ == "__main__":
