@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--set", default="")
     ap.add_argument("--tree", action="store_true")
+    ap.add_argument("--frames", type=int, default=0, help="also the throughput with this many voxelizations in flight (frames of the one context)")
     a = ap.parse_args()
     v = dxv.Voxelizer(0)
     v.set_option("lists", 2)
@@ -43,6 +44,18 @@ def main():
                 out.update({"entries": st["list_entries"], "res": st["list_res"], "list_ms": round(st["list_ms"], 3)})
             out[f"{tag}_solid"] = v.CountSolid()
         v.set_option("lists", 2)
+        if a.frames > 1:
+            import time
+            for f in range(a.frames):
+                v.Voxelize(a.grid, 0, sync=False, frameIndex=f)
+            v.SyncAll()
+            steps = 12
+            t0 = time.perf_counter()
+            for k in range(steps):
+                v.Voxelize(a.grid, 0, sync=False, frameIndex=k % a.frames)
+            v.SyncAll()
+            out[f"ms_per_voxelize_{a.frames}_in_flight"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+            v.SetFrame(0)
         print(json.dumps(out), flush=True)
 
 
