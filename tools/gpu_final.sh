@@ -58,4 +58,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_tcc.log 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcp -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_tcp.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_parity -- python3 $R torus1m 512 3 parity > $OUT/pmc_fetch_parity.log 2>&1
+# the deep scene's kernel (BASELINE config 5): counters of the same launch on the 10 M-triangle soup
+bash $GRAFT_REPO_ROOT/tools/gpu_pmc_quick.sh soup10m soup10m 512 > $OUT/pmc_soup10m.log 2>&1
+cp $GRAFT_REPO_ROOT/gpurun_out/pmcq/soup10m/summary.json $OUT/pmc_soup10m_summary.json 2>/dev/null
+python $GRAFT_REPO_ROOT/tools/quick_times.py --meshes soup10m,torus1m,dragon9 --frames 3 --reps 5 > $OUT/frames3.jsonl 2>&1
+python $GRAFT_REPO_ROOT/tools/list_check_configs.py --quick > $OUT/list_check_quick.jsonl 2>&1
 exit 0
