@@ -163,7 +163,9 @@ DXV_HD float dm_stop_radius(const DirEntry& e, float step) { return half_bits_to
 // smallest q in [0, 63] with r1 - q * step <= suffixMinR0 (r1 - 63 * step <= r1 - thick <= every later start: always found)
 DXV_HD uint32_t dm_stop_code(float r1, float suffixMinR0, float step)
 {
-    uint32_t q = 0;
+    // start two below the quotient (every smaller q misses by more than a whole step, far beyond rounding) and count up
+    const float x = step > 0.0f ? (r1 - suffixMinR0) / step : 0.0f;
+    uint32_t q = x > 2.0f ? (x < 65.0f ? (uint32_t)x - 2u : 63u) : 0u;
     while (q < 63u && r1 - (float)q * step > suffixMinR0) ++q;
     return q;
 }
