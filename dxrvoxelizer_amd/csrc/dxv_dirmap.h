@@ -492,23 +492,34 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             // little; in a deep soup a ray stops after the first few of hundreds of entries.)
             if (dm_stop_radius(e0, step) > (rho + best.t) * 1.001f + 1e-4f) i = end;
             else {
-                if (dm_local_pass(e0, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e0));
-                if (i + 1u <= last && dm_local_pass(e1, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e1));
-                if (i + 2u <= last && dm_local_pass(e2, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e2));
-                if (i + 3u <= last && dm_local_pass(e3, loc, rc)) stk.put(qn++, (int32_t)dm_entry_tri(e3));
+                // (a queued item is two words: the triangle, and the entry's radial word for the second look below)
+                if (dm_local_pass(e0, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e0)); stk.put(2 * qn + 1, (int32_t)e0.rr); ++qn; }
+                if (i + 1u <= last && dm_local_pass(e1, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e1)); stk.put(2 * qn + 1, (int32_t)e1.rr); ++qn; }
+                if (i + 2u <= last && dm_local_pass(e2, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e2)); stk.put(2 * qn + 1, (int32_t)e2.rr); ++qn; }
+                if (i + 3u <= last && dm_local_pass(e3, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e3)); stk.put(2 * qn + 1, (int32_t)e3.rr); ++qn; }
                 i += 4u;
             }
         }
         const bool scanning = wave_any(i < end);
-        if (scanning && !wave_any(qn + 4 > cap)) continue;
+        if (scanning && !wave_any(2 * (qn + 4) > cap)) continue;
         if (ABL & 2) { if (qn > 100) best.k = 0u; }
         else {
             // direction, 1 / d, -o / d (hlsl:52 and the slab constants): only now, after the scan of the short lists of a
             // surface mesh is over -- two waves in five never get here, and the scan runs with a dozen registers less
             finish_ray_reference(r);
-            for (int k = 0; wave_any(k < qn); ++k)
-                if (k < qn) leaf_reference(r, tris, stk.get(k), best);
-            rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);
+            // Every lane takes its queued triangles in turn, but looks at an item's near radius once more first: what starts
+            // beyond a hit found since it was queued is dropped unfetched, so a round is one triangle for every lane that
+            // still has a live item (the most loaded lane of a wave decides how many rounds there are).
+            int k = 0;
+            for (;;) {
+                while (k < qn && (((uint32_t)stk.get(2 * k + 1) - rc) & 0x00008000u) == 0u) ++k;      // r0 beyond the closest hit so far
+                if (!wave_any(k < qn)) break;
+                if (k < qn) {
+                    leaf_reference(r, tris, stk.get(2 * k), best);
+                    rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);
+                    ++k;
+                }
+            }
         }
         qn = 0;
         if (!scanning) break;

@@ -536,14 +536,14 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
         // direction-space lists: no stack, the column is the queue of selected triangles (8 entries; 16 for deep scenes,
         // where a ray meets many candidates before its first flush)
         if constexpr (STACK == 8 || STACK == 16) {
-            if constexpr (B::threads == 64 && B::x == 4 && STACK == 8) {     // timing-only ablations of the default shape (tools/ablate.py)
+            if constexpr (B::threads == 64 && B::x == 4 && STACK == 16) {    // timing-only ablations of the default shape (tools/ablate.py)
                 switch (p.ablate) {
                 case 0: break;
-                case 1: k_voxelize<B, 8, 0, false, 4, 1><<<g, b, 0, s>>>(p); return hipGetLastError();
-                case 2: k_voxelize<B, 8, 0, false, 4, 2><<<g, b, 0, s>>>(p); return hipGetLastError();
-                case 4: k_voxelize<B, 8, 0, false, 4, 4><<<g, b, 0, s>>>(p); return hipGetLastError();
-                case 6: k_voxelize<B, 8, 0, false, 4, 6><<<g, b, 0, s>>>(p); return hipGetLastError();
-                case 8: k_voxelize<B, 8, 0, false, 4, 8><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 1: k_voxelize<B, 16, 0, false, 4, 1><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 2: k_voxelize<B, 16, 0, false, 4, 2><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 4: k_voxelize<B, 16, 0, false, 4, 4><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 6: k_voxelize<B, 16, 0, false, 4, 6><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 8: k_voxelize<B, 16, 0, false, 4, 8><<<g, b, 0, s>>>(p); return hipGetLastError();
                 default: return hipErrorInvalidValue;
                 }
             }
