@@ -472,6 +472,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         if (dm_entry_r1(dm.entries[mid]) < near) i = mid + 1u; else hi = mid;
     }
     int qn = 0;
+    float bestDet = 1.0f;                                               // divisor of the closest hit's barycentrics (finish_hit)
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
     DirRayLocal loc = dm_ray_local(cx, cy);
     uint32_t rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);   // radial cut: r1 >= near, r0 not beyond the closest hit so far
@@ -515,7 +516,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
                 while (k < qn && (((uint32_t)stk.get(2 * k + 1) - rc) & 0x00008000u) == 0u) ++k;      // r0 beyond the closest hit so far
                 if (!wave_any(k < qn)) break;
                 if (k < qn) {
-                    leaf_reference(r, tris, stk.get(2 * k), best);
+                    leaf_reference_deferred(r, tris, stk.get(2 * k), best, bestDet);
                     rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);
                     ++k;
                 }
@@ -524,6 +525,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         qn = 0;
         if (!scanning) break;
     }
+    finish_hit(best, bestDet);
 }
 
 template <class Stack, int ABL>

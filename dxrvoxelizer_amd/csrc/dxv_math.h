@@ -161,8 +161,10 @@ DXV_HD bool slab_parity(const Ray& r, float loy, float loz, float hix, float hiy
 // symbolically perturbed origin o + (eps, eps^2), so a ray through a shared edge or vertex is
 // counted for exactly one incident triangle.
 // ------------------------------------------------------------------------------------------
-template <bool FILL>
-DXV_HD bool tri_test(const Ray& r, const F4& v0, const F4& v1, const F4& v2, float& t, float& b1, float& b2)
+// DEFER: b1, b2 come back as the undivided V, W and *detOut as det; the caller divides once, for the closest hit only
+// (same operands, same correctly rounded divisions: the same b1, b2 bit for bit).
+template <bool FILL, bool DEFER = false>
+DXV_HD bool tri_test(const Ray& r, const F4& v0, const F4& v1, const F4& v2, float& t, float& b1, float& b2, float* detOut = nullptr)
 {
     const float ax = v0.x - r.ox, ay = v0.y - r.oy, az = v0.z - r.oz;
     const float bx = v1.x - r.ox, by = v1.y - r.oy, bz = v1.z - r.oz;
@@ -195,8 +197,8 @@ DXV_HD bool tri_test(const Ray& r, const F4& v0, const F4& v1, const F4& v2, flo
     const float T = (U * Az + V * Bz) + W * Cz;
     t = T / det;
     if (!(t > 0.0f && t < kTMax)) return false;
-    b1 = V / det;
-    b2 = W / det;
+    if (DEFER) { b1 = V; b2 = W; *detOut = det; }
+    else { b1 = V / det; b2 = W / det; }
     return true;
 }
 

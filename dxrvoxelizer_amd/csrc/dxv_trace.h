@@ -95,6 +95,26 @@ DXV_HD void leaf_reference(Ray& r, const TriPos* tris, int32_t leaf, Hit& best)
     if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = b1; best.b2 = b2; best.k = k; best.leaf = leaf; }
 }
 
+// The same step for the lists kernel: the two barycentric divisions wait until the closest hit is known (b1, b2 hold the
+// undivided V, W meanwhile, `det` their divisor; finish_hit divides once).
+DXV_HD void leaf_reference_deferred(Ray& r, const TriPos* tris, int32_t leaf, Hit& best, float& bestDet)
+{
+    const TriPos tp = load_tri(tris, leaf);
+    float lo[3], hi[3], tn;
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+    if (!(slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= best.t)) return;
+    if (r.kz < 0) ray_shear(r);
+    float t, V, W, det;
+    if (!tri_test<false, true>(r, tp.v0, tp.v1, tp.v2, t, V, W, &det)) return;
+    if (tn > t) return;
+    const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
+    if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = V; best.b2 = W; bestDet = det; best.k = k; best.leaf = leaf; }
+}
+DXV_HD void finish_hit(Hit& best, float bestDet)
+{
+    if (best.k != 0xffffffffu) { best.b1 = best.b1 / bestDet; best.b2 = best.b2 / bestDet; }
+}
+
 // Optional per-ray counters (tests / tuning only; compiled out of the shipped kernels).
 struct TraceStats { uint32_t nodes, leaves, maxsp; };
 
