@@ -88,7 +88,7 @@ def main():
                       f"134,217,728 B, which reports {kc.get('FETCH_SIZE', float('nan')):.0f} KB = 1/2. The gathers of k_voxelize are "
                       "not a streaming pattern, so the doubled figure is an upper estimate; uncorrected total = "
                       f"{int((fetch_kb + write_kb) * 1024)} B",
-            "kernel": "k_voxelize<Brick<4,4,4>,8,0,false,4,0> (direction-space lists; the tree walk's figures: profiles/r01/final/tree_walk/)",
+            "kernel": "k_voxelize<Brick<4,4,4>,16,0,false,4,0> (direction-space lists; the tree walk's figures: profiles/r01/final/tree_walk/)",
             "round": int(ROUND[1:])}
         with open(tj, "w") as fh:
             json.dump(traffic, fh, indent=1)
