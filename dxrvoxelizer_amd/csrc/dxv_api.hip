@@ -406,7 +406,11 @@ int launch_now(dxv_ctx* c, uint32_t frame)
     // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
     // builds them at the first launch.
-    const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists && (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0);
+    // (... unless the launch is large: from about 640^3 voxels on, what the lists save on this one launch -- 7 ms of 13 at
+    // 1024^3 for 1 M triangles -- is more than their build costs, 2 ms)
+    const bool largeLaunch = (uint64_t)p.N * p.N * p.nz >= (1ull << 28);
+    const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists &&
+                           (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0 || largeLaunch);
     if (p.mode == DXV_MODE_REFERENCE) ++c->launchesOfScene;
     if (wantLists) {
         if (c->listState == 0 || (c->listState != 0 && c->listOpt != c->optListRes)) {

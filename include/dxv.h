@@ -198,7 +198,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 default), level sweeps (2), one atomic pass (0)
  *   lists  0|1|2  reference rule through direction-space lists (dxv_dirmap.h) or the tree walk (0).  The
  *                 lists are built from the scene's triangle records, 0.3-2.7 ms: at the second launch after
- *                 a build / refit / import (1, default: a mesh refitted every frame stays on the tree walk)
+ *                 a build / refit / import, or at the first if that launch has 2^28 voxels or more (1, default: a
+ *                 mesh refitted every frame stays on the tree walk where that is the faster of the two)
  *                 or at the first (2); scenes whose
  *                 lists would average more than 32 entries per texel, or exceed 256 entries per
  *                 triangle + 64 M, keep the tree walk (stats.list_entries = 0)
