@@ -309,7 +309,12 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
                 const double* F = poly[cur][(i + 1) % n];
                 const double d[3] = {F[0] - E[0], F[1] - E[1], F[2] - E[2]}, q[3] = {P[0] - E[0], P[1] - E[1], P[2] - E[2]};
                 const double cx = d[1] * q[2] - d[2] * q[1], cy = d[2] * q[0] - d[0] * q[2], cz = d[0] * q[1] - d[1] * q[0];
-                inside = cx * nx + cy * ny + cz * nz >= 0.0;            // same turn as the polygon's own orientation (the fan normal)
+                // same turn as the polygon's own orientation (the fan normal).  The clip leaves coincident vertices behind
+                // (an edge through a frustum corner is cut twice at one point): such an edge's product is rounding noise of
+                // either sign, so the test forgives 1e-10 of the operands' scale.  Erring towards "inside" is the safe side:
+                // the distance to the plane never exceeds the distance to any point of the polygon.
+                const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+                inside = cx * nx + cy * ny + cz * nz >= -1e-10 * (1.0 + rmax) * __builtin_sqrt(qq * nn);
             }
             const double dist = __builtin_fabs(k) * __builtin_sqrt(nn);
             if (inside && dist < rmin) rmin = dist;

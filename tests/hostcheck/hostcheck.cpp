@@ -7,6 +7,7 @@
 #include "../../dxrvoxelizer_amd/csrc/dxv_raycast.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -164,6 +165,42 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
         if (h.has3) cell.q3 = r1(h.m3);
     }
     return keys.size();
+}
+// dm_footprint of one triangle (9 floats) on one face: out = u0, u1, v0, v1, r0, r1; returns 0 when the face does not see it
+__attribute__((visibility("default"))) int hc_dm_footprint(const float* tri, uint32_t face, float* out)
+{
+    TriPos tp;
+    tp.v0 = {tri[0], tri[1], tri[2], 0.0f}; tp.v1 = {tri[3], tri[4], tri[5], 0.0f}; tp.v2 = {tri[6], tri[7], tri[8], 0.0f};
+    DirFootprint f;
+    if (!dm_footprint(tp, face, f)) return 0;
+    out[0] = f.u0; out[1] = f.u1; out[2] = f.v0; out[3] = f.v1; out[4] = f.r0; out[5] = f.r1;
+    return 1;
+}
+// Debug aid: every entry of the texel of voxel (ix, iy, iz)'s ray, with the outcome of each test of the scan.
+__attribute__((visibility("default"))) void hc_dirmap_debug(void* p, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, uint32_t wantK)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    uint32_t face; float u, v, rho;
+    dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
+    uint32_t ti, tj, cx, cy;
+    dm_local(u, s->dmR, ti, cx); dm_local(v, s->dmR, tj, cy);
+    const DirCell cell = s->dmCells[(face * s->dmR + tj) * s->dmR + ti];
+    const float near = rho * 0.999f;
+    printf("o=(%g %g %g) face %u u %g v %g rho %.9g texel (%u,%u) local (%u,%u) count %u r1max %g thick %g near %.9g\n", r.ox, r.oy, r.oz, face, u, v, rho, ti, tj, cx, cy,
+           cell.count, half_bits_to_float(cell.r1max), half_bits_to_float(cell.thick), near);
+    const DirRayLocal loc = dm_ray_local(cx, cy);
+    const uint32_t rc = dm_radial_word(near, 3.0e38f);
+    const float step = dm_stop_step(half_bits_to_float(cell.thick));
+    for (uint32_t k = 0; k < cell.count; ++k) {
+        const DirEntry e = s->dmEntries[cell.begin + k];
+        const TriPos tp = load_tri(s->triPos.data(), (int32_t)dm_entry_tri(e));
+        const uint32_t kk = __builtin_bit_cast(uint32_t, tp.v0.w);
+        if (wantK != 0xffffffffu && kk != wantK) continue;
+        printf("  #%u tri %u r0 %.9g r1 %.9g stop %.9g box %08x edge %08x boxpass %d radial %d edge %d (dot %d)\n", k, kk, dm_entry_r0(e), dm_entry_r1(e), dm_stop_radius(e, step), e.box, e.edge,
+               ((loc.q - e.box) & 0x80808080u) == 0x80808080u, ((e.rr - rc) & 0x80008000u) == 0x80008000u, dm_dot4(e.edge, loc.p) >= 0, dm_dot4(e.edge, loc.p));
+    }
 }
 __attribute__((visibility("default"))) void hc_dirmap_get(void* p, void* cells, void* entries)
 {

@@ -177,6 +177,37 @@ def test_needles_and_slivers_lists_superset(dxvlib, orc):
 
 
 @pytest.mark.gpu
+def test_lists_frustum_corner_triangles(dxvlib, orc):
+    """The soak failure of round 2 on the device (tests/test_hostcheck.py::frustum_corner_case: near radius of a triangle
+    whose edge runs through a frustum corner), and lattice-snapped triangles -- which put edges on frustum corners and side
+    planes all the time -- at a size the short soak does not reach: grids and the exhaustive superset check."""
+    import dxrvoxelizer_amd as dxv
+    from test_hostcheck import frustum_corner_case
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 2)
+    vb, ib = frustum_corner_case()
+    want = orc.Scene(vb, ib).voxelize(96, algo=orc.ALGO_BRUTE)
+    v.InitFromArrays(vb, ib)
+    for res in (16, 64, 1024):
+        v.set_option("listres", res)
+        v.Voxelize(96)
+        assert np.array_equal(v.Grid(), want), res
+        assert v.list_check(96)[1] == 0
+    rng = np.random.default_rng(77001)
+    for n_tris, L, N in ((1500, 32, 96), (1500, 16, 64), (400, 8, 48)):
+        vb, ib = lattice_mesh(rng, n_tris, L)
+        want = orc.Scene(vb, ib).voxelize(N, algo=orc.ALGO_BRUTE)
+        v.InitFromArrays(vb, ib)
+        for res in (64, 0):
+            v.set_option("listres", res)
+            v.Voxelize(N)
+            assert np.array_equal(v.Grid(), want), (n_tris, L, N, res)
+            accepted, violations, first = v.list_check(N)
+            assert violations == 0 and accepted > 0, (n_tris, L, N, res, first)
+    v.set_option("listres", 0)
+
+
+@pytest.mark.gpu
 def test_randomised_soak_short(dxvlib, orc):
     """tools/gpu_soak.py for a few seconds: random meshes x grids x partitions x every option."""
     import os

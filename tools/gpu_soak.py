@@ -48,7 +48,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed)
     v = dxv.Voxelizer(0)
-    t0, cases, grids = time.time(), 0, 0
+    t0, cases, grids, checked = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
         (vb, ib), label = random_mesh(rng)
         T = len(ib) // 3
@@ -101,6 +101,14 @@ def main():
                                   "differ": int((got != ref).sum())}))
                 sys.exit(1)
             assert np.array_equal(v.GridBits(), np.packbits(got.reshape(-1), bitorder="little"))
+            if mode == 0 and v.stats()["list_entries"] > 0 and T * N ** 3 < 2e9:
+                # the lists in use, exhaustively: every triangle the canonical step accepts for a ray is selectable from its list
+                accepted, violations, first = v.list_check(N)
+                if violations:
+                    print(json.dumps({"FAIL": label, "list_check": int(violations), "first": [list(map(int, x)) for x in first[:4]], "T": T, "N": N,
+                                      "opts": opts, "seed": seed}))
+                    sys.exit(1)
+                checked += accepted
             if part == 0 and rng.integers(0, 4) == 0:      # display pass: the empty-brick skip changes no pixel
                 eye, vp = camera.default_view_proj(96, 64, eye=tuple(float(x) for x in rng.uniform(-12, 12, 3) + np.array([0, 0, 14.0])))
                 v.set_option("skipempty", 1)
@@ -109,7 +117,7 @@ def main():
                 b = v.Render(eye, vp, 96, 64)
                 v.set_option("skipempty", 1)
                 assert np.array_equal(a, b), (label, N)
-    print(json.dumps({"soak": "ok", "seconds": round(time.time() - t0, 1), "meshes": cases, "grids": grids, "seed": seed}))
+    print(json.dumps({"soak": "ok", "seconds": round(time.time() - t0, 1), "meshes": cases, "grids": grids, "list_pairs_checked": int(checked), "seed": seed}))
 
 
 if __name__ == "__main__":
