@@ -445,7 +445,7 @@ DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32
 // ABL (timing-only builds, tools/ablate.py; 0 in every shipped path): 8 = stop before the texel lookup, 1 = stop after it,
 // 2 = scan the entries but test no triangle
 template <class Stack, int ABL = 0>
-DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, const Stack& stk, int cap, Hit& best)
+DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, const Stack& stk, int cap, Hit& best, float& bestDet)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
     if (ABL & 8) return;
@@ -477,7 +477,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         if (dm_entry_r1(dm.entries[mid]) < near) i = mid + 1u; else hi = mid;
     }
     int qn = 0;
-    float bestDet = 1.0f;                                               // divisor of the closest hit's barycentrics (finish_hit)
+    bestDet = 1.0f;                                                     // divisor of the closest hit's barycentrics (the caller's finish_hit)
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
     DirRayLocal loc = dm_ray_local(cx, cy);
     uint32_t rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);   // radial cut: r1 >= near, r0 not beyond the closest hit so far
@@ -513,6 +513,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             // direction, 1 / d, -o / d (hlsl:52 and the slab constants): only now, after the scan of the short lists of a
             // surface mesh is over -- two waves in five never get here, and the scan runs with a dozen registers less
             finish_ray_reference(r);
+            ray_shear(r);                                               // (here, not at the first triangle: the direction's registers are free through the tests)
             // Every lane takes its queued triangles in turn, but looks at an item's near radius once more first: what starts
             // beyond a hit found since it was queued is dropped unfetched, so a round is one triangle for every lane that
             // still has a live item (the most loaded lane of a wave decides how many rounds there are).
@@ -530,14 +531,13 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
         qn = 0;
         if (!scanning) break;
     }
-    finish_hit(best, bestDet);
 }
 
 template <class Stack, int ABL>
-DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best)
+DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best, float& bestDet)
 {
     const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
-    trace_reference_dm<Stack, ABL>(r, dm, sc.triPos, stk, cap, best);
+    trace_reference_dm<Stack, ABL>(r, dm, sc.triPos, stk, cap, best, bestDet);
 }
 
 } // namespace dxv

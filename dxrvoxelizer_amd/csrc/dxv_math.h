@@ -268,6 +268,63 @@ DXV_HD bool predicate(const Ray& r, const F4& n0, const F4& n1, const F4& n2, fl
     return ((nx * r.dx + ny * r.dy) + nz * r.dz) > kThreshold;
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-triangle shortcut of the predicate (reference rule).  Every ray of the rule is radial, so its direction is the
+// direction of its hit point: on one triangle the predicate is a function of the hit point alone,
+//     angle(N(b), p(b)) < acos(0.12),   N(b), p(b) = the interpolated normal and position.
+// N(b) is a non-negative combination of the vertex normals, p(b) of the vertices, so each stays inside the spherical cap
+// around its generators' mean direction that contains the generators (a cap of less than 90 degrees is convex); with alpha
+// the angle between the two cap axes and theta_n, theta_x the cap radii the predicate's angle lies in
+// [alpha - theta_n - theta_x, alpha + theta_n + theta_x].  A triangle whose whole interval is on one side of the
+// threshold by more than kClassMargin is classified once, at build time (double precision), and its hits need neither the
+// 48-byte normal record nor the barycentrics; everything else -- the band of a surface where the angle is near 83 degrees,
+// big or badly shaped triangles, vertices near the grid centre, zero or wildly unequal normals -- takes the canonical
+// predicate above.  The margin (2e-3 rad, 2e-3 of the cosine) is three orders of magnitude above what the canonical
+// float evaluation, a barycentric a few ulps outside [0, 1] or the watertight test's slack (the ray passes within 1e-5 of
+// the triangle, the vertices are at least 1e-2 from the centre) can move the angle.  0 = undecided, 2 = in, 3 = out.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kClassShift = 28u, kClassIn = 2u, kClassOut = 3u;
+DXV_HD bool class_cap(const double g[3][3], double maxRatio, double minLen, double axis[3], double& cosRadius)
+{
+    double u[3][3], lmin = 1e300, lmax = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const double l = __builtin_sqrt(g[i][0] * g[i][0] + g[i][1] * g[i][1] + g[i][2] * g[i][2]);
+        if (!(l > minLen && l < 1e30)) return false;
+        if (l < lmin) lmin = l;
+        if (l > lmax) lmax = l;
+        for (int a = 0; a < 3; ++a) u[i][a] = g[i][a] / l;
+    }
+    if (!(lmax <= maxRatio * lmin)) return false;
+    double c[3] = {u[0][0] + u[1][0] + u[2][0], u[0][1] + u[1][1] + u[2][1], u[0][2] + u[1][2] + u[2][2]};
+    const double cl = __builtin_sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    if (!(cl > 0.5)) return false;
+    cosRadius = 1.0;
+    for (int a = 0; a < 3; ++a) axis[a] = c[a] / cl;
+    for (int i = 0; i < 3; ++i) {
+        const double d = axis[0] * u[i][0] + axis[1] * u[i][1] + axis[2] * u[i][2];
+        if (d < cosRadius) cosRadius = d;
+    }
+    return cosRadius > 0.5;                                        // caps of less than 60 degrees only
+}
+DXV_HD uint32_t normal_class(const F4& v0, const F4& v1, const F4& v2, const F4& n0, const F4& n1, const F4& n2)
+{
+    const double P[3][3] = {{v0.x, v0.y, v0.z}, {v1.x, v1.y, v1.z}, {v2.x, v2.y, v2.z}};
+    const double N[3][3] = {{n0.x, n0.y, n0.z}, {n1.x, n1.y, n1.z}, {n2.x, n2.y, n2.z}};
+    double an[3], ax[3], cn, cx;
+    if (!class_cap(N, 4.0, 1e-30, an, cn) || !class_cap(P, 1e30, 1e-2, ax, cx)) return 0u;
+    if (cn > 1.0) cn = 1.0;
+    if (cx > 1.0) cx = 1.0;
+    const double sn = __builtin_sqrt(1.0 - cn * cn), sx = __builtin_sqrt(1.0 - cx * cx);
+    const double cb = cn * cx - sn * sx, sb = sn * cx + cn * sx;            // beta = theta_n + theta_x < 120 degrees
+    const double ca = an[0] * ax[0] + an[1] * ax[1] + an[2] * ax[2];        // alpha
+    // cos / sin of acos(0.12) -+ 2e-3
+    constexpr double cosLo = 0.12198530645974026, sinLo = 0.9925319062921469;   // threshold - margin
+    constexpr double cosHi = 0.1180142135404197, sinHi = 0.9930119059721471;   // threshold + margin
+    if (cb > cosLo && ca > cosLo * cb + sinLo * sb) return kClassIn;        // alpha + beta < threshold - margin
+    if (cb > -cosHi && ca < cosHi * cb - sinHi * sb) return kClassOut;      // alpha - beta > threshold + margin (and < 180 degrees)
+    return 0u;
+}
+
 // float4(Normal, 1) stored to R10G10B10A2_UNORM (hlsl:84, Content/Voxelizer.cpp:65):
 // D3D float->UNORM = clamp to [0,1] (NaN -> 0), scale, round to nearest.
 DXV_HD uint32_t unorm10(float v)

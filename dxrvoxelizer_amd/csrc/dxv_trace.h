@@ -100,15 +100,17 @@ DXV_HD void leaf_reference(Ray& r, const TriPos* tris, int32_t leaf, Hit& best)
 DXV_HD void leaf_reference_deferred(Ray& r, const TriPos* tris, int32_t leaf, Hit& best, float& bestDet)
 {
     const TriPos tp = load_tri(tris, leaf);
+    // the slot travels with the triangle's class bits (normal_class: what the closest hit needs afterwards); joined here,
+    // where both are at hand, so that one register instead of two lives through the test
+    const int32_t tagged = leaf | (int32_t)__builtin_bit_cast(uint32_t, tp.v1.w);
     float lo[3], hi[3], tn;
     tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
     if (!(slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= best.t)) return;
-    if (r.kz < 0) ray_shear(r);
-    float t, V, W, det;
+    float t, V, W, det;                                                 // (the caller has sheared the ray: ray_shear)
     if (!tri_test<false, true>(r, tp.v0, tp.v1, tp.v2, t, V, W, &det)) return;
     if (tn > t) return;
     const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
-    if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = V; best.b2 = W; bestDet = det; best.k = k; best.leaf = leaf; }
+    if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = V; best.b2 = W; bestDet = det; best.k = k; best.leaf = tagged; }
 }
 DXV_HD void finish_hit(Hit& best, float bestDet)
 {
@@ -597,7 +599,7 @@ struct SceneView {
 };
 
 template <class Stack, int ABL = 0>
-DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best);      // dxv_dirmap.h
+DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best, float& bestDet);      // dxv_dirmap.h
 
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
@@ -613,7 +615,8 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return 0;   // provably missMain
     if (WALK != 4) finish_ray_reference(r);                                     // (the lists finish the ray when they first test a triangle)
     Hit best;
-    if (WALK == 4) trace_reference_lists<Stack, ABL>(r, sc, stk, cap, best);                           // no tree, no stack: cannot overflow
+    float bestDet = 1.0f;
+    if (WALK == 4) trace_reference_lists<Stack, ABL>(r, sc, stk, cap, best, bestDet);                           // no tree, no stack: cannot overflow
     const bool ok = WALK == 4 ? true
                   : WALK == 3 ? trace_reference_h(r, sc.nodes, sc.wide, sc.triPos, stk, cap, best)
                   : WALK == 2 ? trace_reference_w(r, sc.wide, sc.triPos, stk, cap, best)
@@ -622,6 +625,14 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
     if (!ok) { overflow = true; return 0; }
     if (best.k == 0xffffffffu) return 0;                                         // missMain
     if (ABL & 4) return 1;
+    if (WALK == 4) {
+        // most triangles answer the predicate for every ray that can hit them (normal_class): no normals, no barycentrics
+        const uint32_t cls = (uint32_t)best.leaf >> kClassShift;
+        best.leaf &= (int32_t)((1u << kClassShift) - 1u);
+        if (cls != 0u && !texel) return cls == kClassIn ? 1 : 0;
+        finish_hit(best, bestDet);
+        finish_ray_reference(r);                                        // the direction again (not kept through the scan)
+    }
     const TriNrm tn = sc.triNrm[best.leaf];
     float nx, ny, nz;
     const bool in = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz);

@@ -76,7 +76,6 @@ __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict
     gather_tri(vb, ib, k, bnd, a, b, c, idx);
     a.w = __builtin_bit_cast(float, k);
     TriPos tp; tp.v0 = a; tp.v1 = b; tp.v2 = c;
-    triPos[i] = tp;
     TriNrm tn;
     const float* n0 = vb + 6ull * idx[0] + 3;
     const float* n1 = vb + 6ull * idx[1] + 3;
@@ -85,6 +84,8 @@ __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict
     tn.n1 = F4{n1[0], n1[1], n1[2], 0.0f};
     tn.n2 = F4{n2[0], n2[1], n2[2], 0.0f};
     triNrm[i] = tn;
+    tp.v1.w = __builtin_bit_cast(float, normal_class(a, b, c, tn.n0, tn.n1, tn.n2) << kClassShift);   // spare word of the record
+    triPos[i] = tp;
 }
 
 // parents[0 .. T-2]: internal nodes, parents[T-1 .. 2T-2]: leaves; word = (parent << 1) | side.

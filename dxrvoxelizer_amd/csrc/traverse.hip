@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t compact1by2(uint32_t x)
 
 // WALK: 0 = leaves tested as met, 1 = postponed-leaf walk, 2 = the same over the wide nodes (MODE 0)
 template <class B, int STACK, int MODE, bool TEXELS, int WALK, int ABL = 0>
-__global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs (lists: 6, no LDS to speak of)
+__global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs (lists: the bound is 6, the kernel needs 62 and runs 8)
 {
     __shared__ int32_t stack[STACK * B::threads];
     const uint32_t N = p.N;

@@ -89,11 +89,12 @@ __attribute__((visibility("default"))) void* hc_scene_create(const float* vb, ui
         F4 a, b, c;
         gather(k, a, b, c);
         a.w = __builtin_bit_cast(float, k);
-        s->triPos[i] = TriPos{a, b, c};
         const float* n0 = vb + 6ull * ib[3ull * k] + 3;
         const float* n1 = vb + 6ull * ib[3ull * k + 1] + 3;
         const float* n2 = vb + 6ull * ib[3ull * k + 2] + 3;
         s->triNrm[i] = TriNrm{F4{n0[0], n0[1], n0[2], 0}, F4{n1[0], n1[1], n1[2], 0}, F4{n2[0], n2[1], n2[2], 0}};
+        b.w = __builtin_bit_cast(float, normal_class(a, b, c, s->triNrm[i].n0, s->triNrm[i].n1, s->triNrm[i].n2) << kClassShift);
+        s->triPos[i] = TriPos{a, b, c};
     }
     s->nodes.resize(T > 1 ? T - 1 : 1);
     memset(s->nodes.data(), 0xff, s->nodes.size() * sizeof(Node));
@@ -176,6 +177,12 @@ __attribute__((visibility("default"))) int hc_dm_footprint(const float* tri, uin
     out[0] = f.u0; out[1] = f.u1; out[2] = f.v0; out[3] = f.v1; out[4] = f.r0; out[5] = f.r1;
     return 1;
 }
+__attribute__((visibility("default"))) uint32_t hc_normal_class(const float* tri, const float* nrm)
+{
+    return normal_class(F4{tri[0], tri[1], tri[2], 0}, F4{tri[3], tri[4], tri[5], 0}, F4{tri[6], tri[7], tri[8], 0},
+                        F4{nrm[0], nrm[1], nrm[2], 0}, F4{nrm[3], nrm[4], nrm[5], 0}, F4{nrm[6], nrm[7], nrm[8], 0});
+}
+__attribute__((visibility("default"))) void hc_scene_tripos(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->triPos.data(), s->triPos.size() * sizeof(TriPos)); }
 // Debug aid: every entry of the texel of voxel (ix, iy, iz)'s ray, with the outcome of each test of the scan.
 __attribute__((visibility("default"))) void hc_dirmap_debug(void* p, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, uint32_t wantK)
 {

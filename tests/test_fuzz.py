@@ -202,6 +202,9 @@ def test_lists_frustum_corner_triangles(dxvlib, orc):
             v.set_option("listres", res)
             v.Voxelize(N)
             assert np.array_equal(v.Grid(), want), (n_tris, L, N, res)
+            if v.stats()["list_entries"] == 0:                  # cube-spanning triangles on the automatic (fine) map: over the
+                assert res == 0                                 # size cap, the tree walk answered
+                continue
             accepted, violations, first = v.list_check(N)
             assert violations == 0 and accepted > 0, (n_tris, L, N, res, first)
     v.set_option("listres", 0)

@@ -324,3 +324,62 @@ def test_list_near_radius_through_a_frustum_corner(orc, hostcheck):
         h.lists(R)
         got, ovf = h.voxelize(96, mode=12, stack=8)
         assert ovf == 0 and np.array_equal(got, want), R
+
+
+def test_normal_class_agrees_with_the_predicate_everywhere_on_the_triangle(hostcheck, bunny, dragon):
+    """normal_class (dxv_math.h) classifies a triangle once for all rays that can hit it.  Every ray of the reference rule is
+    radial, so the predicate at a hit point is  cos(angle(N(b), p(b))) > 0.12  with the interpolated normal and position:
+    sampled densely over classified triangles it must always give the class, and by far more than rounding (the classes keep
+    2e-3 rad of margin).  Triangles: smooth-ish fields around the threshold angle, random ones, degenerate normals, vertices
+    near the grid centre; and the assets, where most triangles must be classified for the shortcut to be worth anything."""
+    import ctypes as C
+    L = hostcheck.lib
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+    L.hc_normal_class.argtypes = [f32p, f32p]
+    L.hc_normal_class.restype = C.c_uint32
+    rng = np.random.default_rng(31337)
+    w = np.linspace(-1e-6, 1.0 + 1e-6, 21)                     # a hair beyond the edges, like the hit test's barycentrics
+    b1, b2 = np.meshgrid(w, w)
+    keep = b1 + b2 <= 1.0 + 2e-6
+    b1, b2 = b1[keep][:, None], b2[keep][:, None]
+    thr = np.arccos(0.12)
+    counts = {0: 0, 2: 0, 3: 0}
+    closest = np.inf
+    for it in range(6000):
+        c = rng.normal(size=3); c *= rng.uniform(0.02, 1.7) / np.linalg.norm(c)
+        size = 10.0 ** rng.uniform(-3, -0.3)
+        tri = (c + rng.normal(size=(3, 3)) * size).astype(np.float32)
+        # a normal at a chosen angle from the radial direction, often near the threshold; then perturbed per vertex
+        d = c / np.linalg.norm(c)
+        t = np.cross(d, rng.normal(size=3)); t /= np.linalg.norm(t)
+        ang = thr + rng.normal() * 0.15 if it % 2 else rng.uniform(0, np.pi)
+        n = np.cos(ang) * d + np.sin(ang) * t
+        nrm = (n + rng.normal(size=(3, 3)) * 10.0 ** rng.uniform(-3, -0.2)) * rng.uniform(0.3, 3.0, size=(3, 1))
+        if it % 97 == 0:
+            nrm[rng.integers(0, 3)] = 0.0                      # a zero normal: never classified
+        nrm = nrm.astype(np.float32)
+        cls = L.hc_normal_class(np.ascontiguousarray(tri.reshape(-1)), np.ascontiguousarray(nrm.reshape(-1)))
+        counts[cls] += 1
+        if it % 97 == 0:
+            assert cls == 0
+        if cls == 0:
+            continue
+        P = tri[0].astype(np.float64) * (1 - b1 - b2) + tri[1] * b1 + tri[2] * b2
+        N = nrm[0].astype(np.float64) * (1 - b1 - b2) + nrm[1] * b1 + nrm[2] * b2
+        cosv = (P * N).sum(1) / np.linalg.norm(P, axis=1) / np.linalg.norm(N, axis=1)
+        if cls == 2:
+            assert (cosv > 0.12 + 1e-3).all(), (tri, nrm, cosv.min())
+            closest = min(closest, cosv.min() - 0.12)
+        else:
+            assert (cosv < 0.12 - 1e-3).all(), (tri, nrm, cosv.max())
+            closest = min(closest, 0.12 - cosv.max())
+    assert counts[2] > 500 and counts[3] > 500 and counts[0] > 500, counts
+    assert closest < 0.02                                      # the classes reach close to the threshold: the bound is not lazy
+    for vb, ib, _ in (bunny, dragon):
+        from oracle import orc as _o
+        h = hostcheck(vb, ib, _o.Scene(vb, ib).bound)
+        tp = np.empty((h.T, 12), np.float32)
+        L.hc_scene_tripos.argtypes = [C.c_void_p, C.c_void_p]
+        L.hc_scene_tripos(h.h, tp.ctypes.data_as(C.c_void_p))
+        cls = tp[:, 7].view(np.uint32) >> 28
+        assert set(np.unique(cls)) <= {0, 2, 3} and (cls != 0).mean() > 0.7, (cls != 0).mean()   # bunny 0.9, dragon 0.76

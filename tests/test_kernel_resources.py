@@ -20,9 +20,10 @@ def test_default_kernels_do_not_spill_and_keep_full_occupancy(dxvlib):
     binary_ref = [v for k, v in res.items() if "k_voxelizeINS_5BrickILi4ELi4ELi4EEELi20ELi0ELb0ELi1E" in k]
     default_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi1ELb1E" in k]   # 512-voxel runs, one row per wave, four-box nodes
     block_par = [v for k, v in res.items() if "k_parity_rowsILi8ELi2ELb1E" in k]     # ... 2 x 2 rows per wave
-    # WALK 4, no ablation: direction-space lists (default): 70 registers = 7 waves per SIMD (8 would need 64: 32 B of scratch)
+    # WALK 4, no ablation: direction-space lists (default): 62 registers = 8 waves per SIMD (the ray's direction is not kept
+    # through the triangle tests: 70 before that)
     lists_ref = [v for k, v in res.items() if "k_voxelizeINS_5BrickILi4ELi4ELi4EEELi16ELi0ELb0ELi4ELi0E" in k]
-    assert len(lists_ref) == 1 and lists_ref[0]["scratch"] == 0 and lists_ref[0]["vgprs"] <= 72 and lists_ref[0]["occupancy"] >= 7
+    assert len(lists_ref) == 1 and lists_ref[0]["scratch"] == 0 and lists_ref[0]["vgprs"] <= 64 and lists_ref[0]["occupancy"] == 8
     assert len(default_ref) == 1 and len(binary_ref) == 1 and len(default_par) == 1 and len(block_par) == 1
     assert block_par[0]["scratch"] == 0 and block_par[0]["occupancy"] >= 6
     for r in (default_ref[0], binary_ref[0]):
