@@ -1,6 +1,6 @@
 // dirmap.hip -- device build of the direction-space lists (dxv_dirmap.h) from a scene's triangle
 // records.  One-off per scene (and per refit), HBM-bound passes:
-//   k_dm_records  one thread per (triangle, face): footprint record + number of texels it covers
+//   k_dm_records  one thread per triangle: footprint records of the faces that see it + number of texels each covers
 //   k_dm_emit     one thread per (triangle, face): (texel | far radius | triangle) keys for its texels
 //   radix sort    by texel, then far radius (stable: then triangle)
 //   k_dm_cells    first / last entry of every texel
@@ -19,18 +19,27 @@ __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restric
                                                          DirRecord* __restrict__ rec, uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ total)
 {
-    // thread -> (face, triangle) face-major: the 64 triangles of a wave are neighbours in Morton order and
-    // mostly see the same faces, so the expensive clip runs with full waves or not at all (records and
-    // counts keep their triangle-major slots: the emit order, hence the list order, does not change)
-    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+    // one thread per triangle, its six faces in turn: the triangle is loaded once, the 64 triangles of a wave are neighbours
+    // in Morton order and mostly see the same one or two faces (the clip runs with nearly full waves), and a face that does
+    // not see the triangle costs a dozen comparisons and no record -- its count of 0 is all k_dm_emit looks at
+    const uint32_t tri = blockIdx.x * kThreads + threadIdx.x;
     unsigned long long n = 0;
-    if (t < 6u * T) {
-        const uint32_t face = t / T, tri = t % T, i = tri * 6u + face;
-        const DirRecord e = dm_record(triPos[tri], face);
-        rec[i] = e;
-        uint32_t i0, i1, j0, j1;
-        if (dm_rect(e, R, i0, i1, j0, j1)) n = (unsigned long long)(i1 - i0 + 1u) * (j1 - j0 + 1u);
-        counts[i] = (uint32_t)n;
+    if (tri < T) {
+        const TriPos tp = triPos[tri];
+#pragma unroll 1
+        for (uint32_t face = 0; face < 6u; ++face) {
+            const uint32_t i = tri * 6u + face;
+            DirFootprint f;
+            uint32_t c = 0;
+            if (dm_footprint(tp, face, f)) {
+                const DirRecord e = dm_record(f);
+                rec[i] = e;
+                uint32_t i0, i1, j0, j1;
+                if (dm_rect(e, R, i0, i1, j0, j1)) c = (i1 - i0 + 1u) * (j1 - j0 + 1u);
+            }
+            counts[i] = c;
+            n += c;
+        }
     }
     for (int off = 32; off; off >>= 1) n += __shfl_down(n, off);
     __shared__ unsigned long long part[kThreads / 64];
@@ -106,11 +115,11 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ offsets, uint32_t T,
-                                                      uint32_t R, uint64_t* __restrict__ keys)
+__global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ counts,
+                                                      const uint32_t* __restrict__ offsets, uint32_t T, uint32_t R, uint64_t* __restrict__ keys)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= 6u * T) return;
+    if (i >= 6u * T || counts[i] == 0u) return;                        // (no record behind a count of 0)
     const uint32_t tri = i / 6u, face = i % 6u;
     uint32_t i0, i1, j0, j1;
     if (!dm_rect(rec[i], R, i0, i1, j0, j1)) return;
@@ -171,14 +180,14 @@ __global__ __launch_bounds__(kThreads) void k_dm_stops(const DirCell* __restrict
         e.tri = (e.tri & kDmTriMask) | (dm_stop_code(dm_entry_r1(e), s, step) << kDmTriBits);
     }
 }
-__global__ __launch_bounds__(64) void k_dm_stops_long(const DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries)
+// (the texels with long lists were listed by k_dm_close: longCount[0] of them in longCells)
+__global__ __launch_bounds__(64) void k_dm_stops_long(const DirCell* __restrict__ cells, const uint32_t* __restrict__ longCells,
+                                                      const uint32_t* __restrict__ longCount, DirEntry* __restrict__ entries)
 {
-    const uint32_t c = blockIdx.x;
-    if (c >= ncells) return;
-    const DirCell cell = cells[c];
-    if (cell.count <= kStopsShort) return;
+    const uint32_t lane = threadIdx.x, nLong = *longCount;
+    for (uint32_t which = blockIdx.x; which < nLong; which += gridDim.x) {
+    const DirCell cell = cells[longCells[which]];
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
-    const uint32_t lane = threadIdx.x;
     float carry = 3.0e38f;
     for (uint32_t base = 0; base < cell.count; base += 64u) {
         const bool valid = base + lane < cell.count;
@@ -194,11 +203,13 @@ __global__ __launch_bounds__(64) void k_dm_stops_long(const DirCell* __restrict_
         const float last = __shfl(v, 63);
         if (last < carry) carry = last;
     }
+    }
 }
 // count and far radius of every texel: the thread of a texel's LAST key (the lists are sorted by far radius) reads the begin
 // its first key wrote in k_dm_cells; lists too long for the 16-bit count field are reported through `longest`
 __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restrict__ keys, uint32_t n, uint32_t R, DirCell* __restrict__ cells,
-                                                       const DirEntry* __restrict__ entries, uint32_t* __restrict__ longest)
+                                                       const DirEntry* __restrict__ entries, uint32_t* __restrict__ longest,
+                                                       uint32_t* __restrict__ longCells)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
     const uint32_t count = i + 1u - words[0];
     words[1] = (count < 0xffffu ? count : 0xffffu) | (((entries[i].rr >> 16) & 0x7fffu) << 16);
     if (count > 0xffffu) atomicMax(longest, count);                    // (only what does not fit is reported: one address, 300 k texels)
+    if (count > kStopsShort) longCells[atomicAdd(longest + 1, 1u)] = cell;   // k_dm_stops_long's work list (at most n / 33 texels)
 }
 } // namespace
 
@@ -226,7 +238,7 @@ hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord*
 {
     hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    k_dm_records<<<(6u * T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total);
+    k_dm_records<<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total);
     return hipGetLastError();
 }
 
@@ -243,7 +255,7 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_scan_apply<<<nb, 256, 0, s>>>(counts, n6, sums, offsets);
     if ((e = hipMemsetAsync(cells, 0, sizeof(DirCell) * 6 * (size_t)R * R, s)) != hipSuccess) return e;
     if (n == 0) return hipGetLastError();
-    k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, offsets, T, R, keys);
+    k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, counts, offsets, T, R, keys);
     // sort by (texel, far radius): the bits above the triangle field, in whole 8-bit digits
     const DirKeyLayout lay = dm_key_layout(R);
     const int passes = (int)((lay.cellBits + 16u + 7u) / 8u), loBit = 64 - 8 * passes;
@@ -252,12 +264,14 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_dm_cells<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, rec, R, cells, entries);
     // the texel words count entries in 16 bits: the caller reads `*longest` (sums[0] is free by now) when it synchronises
     // and keeps the tree walk for a scene with a longer list
-    if ((e = hipMemsetAsync(sums, 0, sizeof(uint32_t), s)) != hipSuccess) return e;
-    k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums);
+    // (sums[1]: number of texels with a long list; their indices go where the sort's other buffer was)
+    if ((e = hipMemsetAsync(sums, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    uint32_t* longCells = reinterpret_cast<uint32_t*>(sorted == keys ? keysTmp : keys);
+    k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums, longCells);
     const uint32_t ncells = 6u * R * R;
     k_dm_hints<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
     k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
-    k_dm_stops_long<<<ncells, 64, 0, s>>>(cells, ncells, entries);
+    k_dm_stops_long<<<4096, 64, 0, s>>>(cells, longCells, sums + 1, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     return hipGetLastError();
 }

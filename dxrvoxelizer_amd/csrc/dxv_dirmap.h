@@ -334,6 +334,16 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
 }
 
 // the record of a (triangle, face) pair; u0 > u1 when there is no footprint
+DXV_HD DirRecord dm_record(const DirFootprint& f)
+{
+    DirRecord r;
+    r.spare[0] = r.spare[1] = 0u;
+    r.u0 = f.u0; r.u1 = f.u1; r.v0 = f.v0; r.v1 = f.v1;
+    r.r0 = half_down(f.r0); r.r1 = half_up(f.r1);
+    r.hasTri = f.hasTri ? 1u : 0u; r.pad = f.pad;
+    for (int i = 0; i < 3; ++i) { r.px[i] = f.px[i]; r.py[i] = f.py[i]; }
+    return r;
+}
 DXV_HD DirRecord dm_record(const TriPos& tp, uint32_t face)
 {
     DirRecord r;
