@@ -141,9 +141,7 @@ __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restric
     uint32_t* words = reinterpret_cast<uint32_t*>(cells + cell);      // [0] begin, [1] count | r1max << 16, [2] thick | q1 << 16, [3] q2 | q3 << 16
     if (i == 0u || dm_key_cell(lay, keys[i - 1u]) != cell) words[0] = i;
     const DirRecord rc = rec[(size_t)tri * 6u + cell / (R * R)];
-    // (count and far radius: k_dm_close, once every texel's begin is in place)
-    // radial extent of the thickest entry of the texel (halfs convert and subtract exactly; positive halfs order like integers)
-    atomicMax(words + 2, (uint32_t)half_up(half_bits_to_float(rc.r1) - half_bits_to_float(rc.r0)));
+    // (count and far radius: k_dm_close, once every texel's begin is in place; thickest entry: k_dm_stops / k_dm_stops_long)
     const uint32_t inFace = cell % (R * R);
     entries[i] = dm_local_entry(rc, R, inFace % R, inFace / R, tri);    // the record cut to this texel
 }
@@ -165,12 +163,33 @@ __global__ __launch_bounds__(kThreads) void k_dm_hints(DirCell* __restrict__ cel
 // (all of a surface mesh's): one thread per texel; long ones (deep scenes: hundreds of entries): one wave per texel, 64
 // entries per step, the running minimum by a prefix scan across the lanes (lane 0 = the entry nearest the far end).
 constexpr uint32_t kStopsShort = 32u;
-__global__ __launch_bounds__(kThreads) void k_dm_stops(const DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries)
+__global__ __launch_bounds__(kThreads) void k_dm_stops(DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries,
+                                                       uint32_t* __restrict__ longCells, uint32_t* __restrict__ longCount)
 {
     const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= ncells) return;
-    const DirCell cell = cells[c];
-    if (cell.count > kStopsShort) return;
+    DirCell cell{};
+    if (c < ncells) cell = cells[c];
+    // texels with a long list go on k_dm_stops_long's work list (at most n / 33 of them): one atomic per wave, consecutive
+    // slots for its lanes (one atomic per texel on one address: 0.1 ms at 50 k long texels)
+    const bool isLong = cell.count > kStopsShort;
+    const unsigned long long m = __ballot(isLong);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(longCount, (uint32_t)__builtin_popcountll(m));
+        base = __shfl(base, (int)leader);
+        if (isLong) longCells[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = c;
+    }
+    if (c >= ncells || isLong || cell.count == 0u) return;
+    // radial extent of the thickest entry of the texel: the unit of the stop codes (halfs convert and subtract exactly)
+    uint32_t thick = 0;
+    for (uint32_t k = 0; k < cell.count; ++k) {
+        const DirEntry& e = entries[cell.begin + k];
+        const uint32_t th = half_up(dm_entry_r1(e) - dm_entry_r0(e));
+        if (th > thick) thick = th;
+    }
+    cells[c].thick = (uint16_t)thick;
+    cell.thick = (uint16_t)thick;
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
     float s = 3.0e38f;
     for (uint32_t k = cell.count; k-- > 0u;) {
@@ -180,13 +199,23 @@ __global__ __launch_bounds__(kThreads) void k_dm_stops(const DirCell* __restrict
         e.tri = (e.tri & kDmTriMask) | (dm_stop_code(dm_entry_r1(e), s, step) << kDmTriBits);
     }
 }
-// (the texels with long lists were listed by k_dm_close: longCount[0] of them in longCells)
-__global__ __launch_bounds__(64) void k_dm_stops_long(const DirCell* __restrict__ cells, const uint32_t* __restrict__ longCells,
+// (the texels with long lists were listed by k_dm_stops: longCount[0] of them in longCells)
+__global__ __launch_bounds__(64) void k_dm_stops_long(DirCell* __restrict__ cells, const uint32_t* __restrict__ longCells,
                                                       const uint32_t* __restrict__ longCount, DirEntry* __restrict__ entries)
 {
     const uint32_t lane = threadIdx.x, nLong = *longCount;
     for (uint32_t which = blockIdx.x; which < nLong; which += gridDim.x) {
-    const DirCell cell = cells[longCells[which]];
+    DirCell cell = cells[longCells[which]];
+    uint32_t thick = 0;                                                 // thickest entry first (the unit of the stop codes)
+    for (uint32_t base = 0; base < cell.count; base += 64u)
+        if (base + lane < cell.count) {
+            const DirEntry e = entries[cell.begin + base + lane];
+            const uint32_t th = half_up(dm_entry_r1(e) - dm_entry_r0(e));
+            if (th > thick) thick = th;
+        }
+    for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(thick, off); if (o > thick) thick = o; }
+    if (lane == 0u) cells[longCells[which]].thick = (uint16_t)thick;
+    cell.thick = (uint16_t)thick;
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
     float carry = 3.0e38f;
     for (uint32_t base = 0; base < cell.count; base += 64u) {
@@ -208,8 +237,7 @@ __global__ __launch_bounds__(64) void k_dm_stops_long(const DirCell* __restrict_
 // count and far radius of every texel: the thread of a texel's LAST key (the lists are sorted by far radius) reads the begin
 // its first key wrote in k_dm_cells; lists too long for the 16-bit count field are reported through `longest`
 __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restrict__ keys, uint32_t n, uint32_t R, DirCell* __restrict__ cells,
-                                                       const DirEntry* __restrict__ entries, uint32_t* __restrict__ longest,
-                                                       uint32_t* __restrict__ longCells)
+                                                       const DirEntry* __restrict__ entries, uint32_t* __restrict__ longest)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
@@ -220,7 +248,6 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
     const uint32_t count = i + 1u - words[0];
     words[1] = (count < 0xffffu ? count : 0xffffu) | (((entries[i].rr >> 16) & 0x7fffu) << 16);
     if (count > 0xffffu) atomicMax(longest, count);                    // (only what does not fit is reported: one address, 300 k texels)
-    if (count > kStopsShort) longCells[atomicAdd(longest + 1, 1u)] = cell;   // k_dm_stops_long's work list (at most n / 33 texels)
 }
 } // namespace
 
@@ -267,10 +294,10 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     // (sums[1]: number of texels with a long list; their indices go where the sort's other buffer was)
     if ((e = hipMemsetAsync(sums, 0, 2 * sizeof(uint32_t), s)) != hipSuccess) return e;
     uint32_t* longCells = reinterpret_cast<uint32_t*>(sorted == keys ? keysTmp : keys);
-    k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums, longCells);
+    k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums);
     const uint32_t ncells = 6u * R * R;
     k_dm_hints<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
-    k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
+    k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries, longCells, sums + 1);
     k_dm_stops_long<<<4096, 64, 0, s>>>(cells, longCells, sums + 1, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     return hipGetLastError();

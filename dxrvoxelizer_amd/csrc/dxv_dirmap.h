@@ -196,25 +196,148 @@ DXV_HD float dm_down(float x) { return -dm_up(-x); }
 // the result only has to be a superset.
 struct DirFootprint { float u0, u1, v0, v1, r0, r1, pad, px[3], py[3]; bool hasTri; };
 
+// The polygon a face sees of a triangle (its vertices in the face's own coordinates b, c, +-a) -> footprint.  FIXED = 3: the
+// triangle itself, whole inside the face's frustum -- by far the common case; all loops have constant bounds then and the
+// polygon stays in registers (the general case indexes it dynamically: scratch memory on the device).
+template <int FIXED>
+DXV_HD void dm_footprint_finish(const double (*poly)[3], int n, const double (*tri)[3], DirFootprint& out)
+{
+    const int m = FIXED ? FIXED : n;
+    const double delta = (double)kDmDelta;
+    double dmin = poly[0][2], rmax2 = 0.0;                        // (radii squared until the end: the root is monotone)
+    for (int i = 0; i < m; ++i) {
+        const double* q = poly[i];
+        if (q[2] < dmin) dmin = q[2];
+        const double r2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+        if (r2 > rmax2) rmax2 = r2;
+    }
+    const double full = kDmFrustum + 1.0 / 256.0;
+    double u0 = -full, u1 = full, v0 = -full, v1 = full;
+    out.hasTri = false; out.pad = 0.0f;
+    for (int i = 0; i < 3; ++i) out.px[i] = out.py[i] = 0.0f;
+    if (dmin >= 64.0 * delta) {
+        u0 = v0 = 1e300; u1 = v1 = -1e300;
+        for (int i = 0; i < m; ++i) {
+            const double* q = poly[i];
+            const double u = q[0] / q[2], v = q[1] / q[2];
+            if (u < u0) u0 = u;
+            if (u > u1) u1 = u;
+            if (v < v0) v0 = v;
+            if (v > v1) v1 = v;
+        }
+        // a point moved by delta sideways and in depth at depth >= dmin >= 64 delta, |u| <= 1.006:
+        // du <= (1 + |u|) delta / (dmin - delta) <= 2.04 delta / dmin
+        const double pad = 2.25 * delta / dmin + 1e-6;
+        u0 -= pad; u1 += pad; v0 -= pad; v1 += pad;
+        // the projected triangle itself, when all of it lies in front of the face plane: its edges, pushed out by the same
+        // pad, bound the footprint too (the part cut off by the frustum's side planes only makes the polygon smaller)
+        const double d0 = tri[0][2], d1 = tri[1][2], d2 = tri[2][2];           // (tri: the unclipped triangle in the face's coordinates)
+        if (d0 >= 64.0 * delta && d1 >= 64.0 * delta && d2 >= 64.0 * delta) {
+            const double dd[3] = {d0, d1, d2};
+            for (int i = 0; i < 3; ++i) { out.px[i] = (float)(tri[i][0] / dd[i]); out.py[i] = (float)(tri[i][1] / dd[i]); }
+            out.hasTri = true;
+            out.pad = (float)(pad + 1e-6);                      // (+ the rounding of the stored vertices)
+        }
+        if (u0 < -full) u0 = -full;
+        if (v0 < -full) v0 = -full;
+        if (u1 > full) u1 = full;
+        if (v1 > full) v1 = full;
+    }
+    // radial range: the farthest point of a convex polygon is a vertex; the nearest is the foot of the perpendicular from
+    // the centre onto its plane when that lies inside the polygon, else the nearest point of its boundary.  (A tight near
+    // radius matters twice: it is what culls entries behind a hit, and the thickest entry of a texel decides how far
+    // behind a hit the scan of that texel goes on.)
+    double rmin2 = 1e300;
+    for (int i = 0; i < m; ++i) {                                      // nearest point of every edge (covers degenerate polygons)
+        const double* A = poly[i];
+        const double* B = poly[(i + 1) % m];
+        const double d[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+        const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        double w = dd > 0.0 ? -(A[0] * d[0] + A[1] * d[1] + A[2] * d[2]) / dd : 0.0;
+        w = w < 0.0 ? 0.0 : w > 1.0 ? 1.0 : w;
+        const double x = A[0] + w * d[0], y = A[1] + w * d[1], z = A[2] + w * d[2];
+        const double dist2 = x * x + y * y + z * z;
+        if (dist2 < rmin2) rmin2 = dist2;
+    }
+    if (m >= 3) {
+        // plane through the polygon (its vertices are coplanar: clipped from one triangle), in the polygon's own coordinates
+        const double* A = poly[0];
+        double nx = 0.0, ny = 0.0, nz = 0.0;
+        for (int i = 1; i + 1 < m; ++i) {                              // summed fan normals: robust for thin clips
+            const double* B = poly[i];
+            const double* C = poly[i + 1];
+            const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+            nx += e1[1] * e2[2] - e1[2] * e2[1]; ny += e1[2] * e2[0] - e1[0] * e2[2]; nz += e1[0] * e2[1] - e1[1] * e2[0];
+        }
+        const double nn = nx * nx + ny * ny + nz * nz;
+        if (nn > 1e-60) {
+            const double k = (nx * A[0] + ny * A[1] + nz * A[2]) / nn;
+            const double P[3] = {k * nx, k * ny, k * nz};               // foot of the perpendicular from the centre
+            bool inside = true;
+            for (int i = 0; i < m && inside; ++i) {
+                const double* E = poly[i];
+                const double* F = poly[(i + 1) % m];
+                const double d[3] = {F[0] - E[0], F[1] - E[1], F[2] - E[2]}, q[3] = {P[0] - E[0], P[1] - E[1], P[2] - E[2]};
+                const double cx = d[1] * q[2] - d[2] * q[1], cy = d[2] * q[0] - d[0] * q[2], cz = d[0] * q[1] - d[1] * q[0];
+                // same turn as the polygon's own orientation (the fan normal).  The clip leaves coincident vertices behind
+                // (an edge through a frustum corner is cut twice at one point): such an edge's product is rounding noise of
+                // either sign, so the test forgives 1e-10 of the operands' scale.  Erring towards "inside" is the safe side:
+                // the distance to the plane never exceeds the distance to any point of the polygon.
+                const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+                inside = cx * nx + cy * ny + cz * nz >= -1e-10 * (1.0 + rmax2) * __builtin_sqrt(qq * nn);
+            }
+            const double dist2 = k * k * nn;
+            if (inside && dist2 < rmin2) rmin2 = dist2;
+        }
+    }
+    double rmin = __builtin_sqrt(rmin2), rmax = __builtin_sqrt(rmax2);
+    rmin *= 1.0 - 1e-6;
+    rmin -= 4.0 * delta;
+    if (rmin < 0.0) rmin = 0.0;
+    rmax += 4.0 * delta;
+    out.u0 = (float)u0; out.u1 = (float)u1; out.v0 = (float)v0; out.v1 = (float)v1;
+    out.r0 = (float)rmin; out.r1 = (float)rmax;
+    // float conversion rounds to nearest: one more ulp outward
+    out.u0 = dm_down(out.u0); out.v0 = dm_down(out.v0); out.u1 = dm_up(out.u1); out.v1 = dm_up(out.v1);
+    out.r0 = out.r0 > 0.0f ? dm_down(out.r0) : 0.0f;
+    out.r1 = dm_up(out.r1);
+}
+
+
 DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
 {
     const uint32_t a = face >> 1, b = (a + 1u) % 3u, c = (a + 2u) % 3u;
     const double s = (face & 1u) ? -1.0 : 1.0;
-    const float vx[3][3] = {{tp.v0.x, tp.v0.y, tp.v0.z}, {tp.v1.x, tp.v1.y, tp.v1.z}, {tp.v2.x, tp.v2.y, tp.v2.z}};
-    double poly[2][10][3];
-    int n = 3, cur = 0;
-    for (int i = 0; i < 3; ++i) { poly[0][i][0] = vx[i][b]; poly[0][i][1] = vx[i][c]; poly[0][i][2] = s * (double)vx[i][a]; }
+    // the triangle in the face's coordinates (b, c, +-a); the axes are picked by selects, not by indexing (no scratch memory)
+    const float X[3] = {tp.v0.x, tp.v1.x, tp.v2.x}, Y[3] = {tp.v0.y, tp.v1.y, tp.v2.y}, Z[3] = {tp.v0.z, tp.v1.z, tp.v2.z};
+    double tri[3][3];
+    for (int i = 0; i < 3; ++i) {
+        tri[i][0] = b == 0u ? X[i] : b == 1u ? Y[i] : Z[i];
+        tri[i][1] = c == 0u ? X[i] : c == 1u ? Y[i] : Z[i];
+        tri[i][2] = s * (double)(a == 0u ? X[i] : a == 1u ? Y[i] : Z[i]);
+    }
     const double delta = (double)kDmDelta;
     // the four side planes of the widened frustum, pushed out by the dilation: kF * d +- b + 2 delta >= 0
     const double planes[4][2] = {{1.0, 0.0}, {-1.0, 0.0}, {0.0, 1.0}, {0.0, -1.0}};
     // most (triangle, face) pairs end here: all three vertices outside one side plane (what the clip
     // below would find, without its arrays)
+    bool allIn = true;
     for (int pl = 0; pl < 4; ++pl) {
         bool anyIn = false;
-        for (int i = 0; i < 3; ++i)
-            anyIn = anyIn || kDmFrustum * poly[0][i][2] + planes[pl][0] * poly[0][i][0] + planes[pl][1] * poly[0][i][1] + 2.0 * delta >= 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const bool in = kDmFrustum * tri[i][2] + planes[pl][0] * tri[i][0] + planes[pl][1] * tri[i][1] + 2.0 * delta >= 0.0;
+            anyIn = anyIn || in;
+            allIn = allIn && in;
+        }
         if (!anyIn) return false;
     }
+    if (allIn) {                                                        // nothing to clip: the polygon is the triangle
+        dm_footprint_finish<3>(tri, 3, tri, out);
+        return true;
+    }
+    double poly[2][10][3];
+    int n = 3, cur = 0;
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) poly[0][i][k] = tri[i][k];
     for (int pl = 0; pl < 4 && n > 0; ++pl) {
         const double nb = planes[pl][0], nc = planes[pl][1];
         int m = 0;
@@ -234,102 +357,7 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
         n = m;
     }
     if (n == 0) return false;
-    double dmin = poly[cur][0][2], rmax = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const double* q = poly[cur][i];
-        if (q[2] < dmin) dmin = q[2];
-        const double r = __builtin_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
-        if (r > rmax) rmax = r;
-    }
-    const double full = kDmFrustum + 1.0 / 256.0;
-    double u0 = -full, u1 = full, v0 = -full, v1 = full;
-    out.hasTri = false; out.pad = 0.0f;
-    for (int i = 0; i < 3; ++i) out.px[i] = out.py[i] = 0.0f;
-    if (dmin >= 64.0 * delta) {
-        u0 = v0 = 1e300; u1 = v1 = -1e300;
-        for (int i = 0; i < n; ++i) {
-            const double* q = poly[cur][i];
-            const double u = q[0] / q[2], v = q[1] / q[2];
-            if (u < u0) u0 = u;
-            if (u > u1) u1 = u;
-            if (v < v0) v0 = v;
-            if (v > v1) v1 = v;
-        }
-        // a point moved by delta sideways and in depth at depth >= dmin >= 64 delta, |u| <= 1.006:
-        // du <= (1 + |u|) delta / (dmin - delta) <= 2.04 delta / dmin
-        const double pad = 2.25 * delta / dmin + 1e-6;
-        u0 -= pad; u1 += pad; v0 -= pad; v1 += pad;
-        // the projected triangle itself, when all of it lies in front of the face plane: its edges, pushed out by the same
-        // pad, bound the footprint too (the part cut off by the frustum's side planes only makes the polygon smaller)
-        const double d0 = s * (double)vx[0][a], d1 = s * (double)vx[1][a], d2 = s * (double)vx[2][a];
-        if (d0 >= 64.0 * delta && d1 >= 64.0 * delta && d2 >= 64.0 * delta) {
-            const double dd[3] = {d0, d1, d2};
-            for (int i = 0; i < 3; ++i) { out.px[i] = (float)((double)vx[i][b] / dd[i]); out.py[i] = (float)((double)vx[i][c] / dd[i]); }
-            out.hasTri = true;
-            out.pad = (float)(pad + 1e-6);                      // (+ the rounding of the stored vertices)
-        }
-        if (u0 < -full) u0 = -full;
-        if (v0 < -full) v0 = -full;
-        if (u1 > full) u1 = full;
-        if (v1 > full) v1 = full;
-    }
-    // radial range: the farthest point of a convex polygon is a vertex; the nearest is the foot of the perpendicular from
-    // the centre onto its plane when that lies inside the polygon, else the nearest point of its boundary.  (A tight near
-    // radius matters twice: it is what culls entries behind a hit, and the thickest entry of a texel decides how far
-    // behind a hit the scan of that texel goes on.)
-    double rmin = 1e300;
-    for (int i = 0; i < n; ++i) {                                      // nearest point of every edge (covers degenerate polygons)
-        const double* A = poly[cur][i];
-        const double* B = poly[cur][(i + 1) % n];
-        const double d[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
-        const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-        double w = dd > 0.0 ? -(A[0] * d[0] + A[1] * d[1] + A[2] * d[2]) / dd : 0.0;
-        w = w < 0.0 ? 0.0 : w > 1.0 ? 1.0 : w;
-        const double x = A[0] + w * d[0], y = A[1] + w * d[1], z = A[2] + w * d[2];
-        const double dist = __builtin_sqrt(x * x + y * y + z * z);
-        if (dist < rmin) rmin = dist;
-    }
-    if (n >= 3) {
-        // plane through the polygon (its vertices are coplanar: clipped from one triangle), in the polygon's own coordinates
-        const double* A = poly[cur][0];
-        double nx = 0.0, ny = 0.0, nz = 0.0;
-        for (int i = 1; i + 1 < n; ++i) {                              // summed fan normals: robust for thin clips
-            const double* B = poly[cur][i];
-            const double* C = poly[cur][i + 1];
-            const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
-            nx += e1[1] * e2[2] - e1[2] * e2[1]; ny += e1[2] * e2[0] - e1[0] * e2[2]; nz += e1[0] * e2[1] - e1[1] * e2[0];
-        }
-        const double nn = nx * nx + ny * ny + nz * nz;
-        if (nn > 1e-60) {
-            const double k = (nx * A[0] + ny * A[1] + nz * A[2]) / nn;
-            const double P[3] = {k * nx, k * ny, k * nz};               // foot of the perpendicular from the centre
-            bool inside = true;
-            for (int i = 0; i < n && inside; ++i) {
-                const double* E = poly[cur][i];
-                const double* F = poly[cur][(i + 1) % n];
-                const double d[3] = {F[0] - E[0], F[1] - E[1], F[2] - E[2]}, q[3] = {P[0] - E[0], P[1] - E[1], P[2] - E[2]};
-                const double cx = d[1] * q[2] - d[2] * q[1], cy = d[2] * q[0] - d[0] * q[2], cz = d[0] * q[1] - d[1] * q[0];
-                // same turn as the polygon's own orientation (the fan normal).  The clip leaves coincident vertices behind
-                // (an edge through a frustum corner is cut twice at one point): such an edge's product is rounding noise of
-                // either sign, so the test forgives 1e-10 of the operands' scale.  Erring towards "inside" is the safe side:
-                // the distance to the plane never exceeds the distance to any point of the polygon.
-                const double qq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
-                inside = cx * nx + cy * ny + cz * nz >= -1e-10 * (1.0 + rmax) * __builtin_sqrt(qq * nn);
-            }
-            const double dist = __builtin_fabs(k) * __builtin_sqrt(nn);
-            if (inside && dist < rmin) rmin = dist;
-        }
-    }
-    rmin *= 1.0 - 1e-6;
-    rmin -= 4.0 * delta;
-    if (rmin < 0.0) rmin = 0.0;
-    rmax += 4.0 * delta;
-    out.u0 = (float)u0; out.u1 = (float)u1; out.v0 = (float)v0; out.v1 = (float)v1;
-    out.r0 = (float)rmin; out.r1 = (float)rmax;
-    // float conversion rounds to nearest: one more ulp outward
-    out.u0 = dm_down(out.u0); out.v0 = dm_down(out.v0); out.u1 = dm_up(out.u1); out.v1 = dm_up(out.v1);
-    out.r0 = out.r0 > 0.0f ? dm_down(out.r0) : 0.0f;
-    out.r1 = dm_up(out.r1);
+    dm_footprint_finish<0>(poly[cur], n, tri, out);
     return true;
 }
 
@@ -398,13 +426,16 @@ DXV_HD DirEntry dm_local_entry(const DirRecord& rec, uint32_t R, uint32_t i, uin
     int bestCut = 0;
     for (int k = 0; k < 3; ++k) {
         const double ex = (double)rec.px[(k + 1) % 3] - rec.px[k], ey = (double)rec.py[(k + 1) % 3] - rec.py[k];
-        const double len = __builtin_sqrt(ex * ex + ey * ey);
-        if (!(len > 1e-12)) continue;
-        const double nx = -ey / len * sgn, ny = ex / len * sgn;          // unit inward normal
+        const double len2 = ex * ex + ey * ey;
+        if (!(len2 > 1e-24)) continue;
+        // inward normal, unit to 3e-7 (single-precision root and reciprocal: the test is homogeneous in the normal except for
+        // `pad`, which carries 10 % of slack)
+        const double rl = (double)(1.0f / __builtin_sqrtf((float)len2)) * sgn;
+        const double nx = -ey * rl, ny = ex * rl;
         const double A = nx * perCell, B = ny * perCell;
         const double C = (ou - rec.px[k]) * nx + (ov - rec.py[k]) * ny + rec.pad;
         const double big = __builtin_fabs(A) > __builtin_fabs(B) ? __builtin_fabs(A) : __builtin_fabs(B);
-        const double sc = 127.0 / big;
+        const double sc = (double)(127.0f / (float)big);                // (one scale for A, B and C: its last bits do not matter)
         const double ka = A * sc, kb = B * sc;
         const int a = (int)__builtin_floor(ka + 0.5), b = (int)__builtin_floor(kb + 0.5);
         double cd = __builtin_ceil(C * sc + __builtin_fabs(ka) + __builtin_fabs(kb) + 127.0 + 13.0);
