@@ -47,6 +47,7 @@ SYMBOLS = {
     "dxv_set_mesh": (C.c_int, [C.c_void_p, _F32P, C.c_uint32, _U32P, C.c_uint32]),
     "dxv_build": (C.c_int, [C.c_void_p]),
     "dxv_update_vertices": (C.c_int, [C.c_void_p, _F32P, C.c_uint32]),
+    "dxv_update_vertices_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "dxv_refit": (C.c_int, [C.c_void_p]),
     "dxv_voxelize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]),
     "dxv_voxelize_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]),

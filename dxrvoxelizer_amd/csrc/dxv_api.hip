@@ -94,6 +94,8 @@ struct dxv_ctx {
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
     uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
+    bool nodesStale = false;         // a refit left nodes32 / nodes64 behind (ensure_nodes brings them up to date before anything reads them)
+    bool listFirstLaunch = false;    // the lists were built at the scene's first launch: base resolution only (build_lists)
     int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
     size_t emptyCap = 0;
@@ -267,7 +269,13 @@ uint32_t list_resolution(const dxv_ctx* c)
     return c->hdr.numTris < 20000u ? 128u : c->hdr.numTris < 3000000u ? 256u : 512u;
 }
 
-int build_lists(dxv_ctx* c, hipStream_t stream)
+// firstLaunchVoxels != 0: called for the FIRST launch of a scene (option lists=1), which may be its only one -- a mesh that
+// is refitted every frame.  The build then has to pay for itself on this launch: after the counting pass (0.1 ms) it goes
+// on only when what the lists save over the tree walk (about 10 ps per voxel; more in deep scenes, in proportion to the
+// mean list length) exceeds what the rest of the build costs (0.1 ms + 0.15 ns per entry: 0.65 ms for 3.8 M entries), and
+// it keeps the base resolution (a 512 map is 3 - 9 % faster for some scenes but takes 2 - 3 x as long to build; a scene
+// that is still the same at its third launch gets it then).  Declined: listState stays 0, the launch walks the tree.
+int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
 {
     const uint32_t T = c->hdr.numTris;
     uint32_t R = list_resolution(c);
@@ -333,7 +341,12 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
     //    scan stops behind the hit, dxv_dirmap.h), so what matters is the size of the structure, which grows with the
     //    square of the map: the 256 map while it stays below 320 M entries, else the 128 map.
     auto perTexel = [&]() { return (double)total / (6.0 * R * R); };
-    if (!c->optListRes && R == 256u && perTexel() > 10.0 && perTexel() <= 32.0) {
+    if (firstLaunchVoxels) {
+        const double depth = perTexel() > 10.0 ? perTexel() / 10.0 : 1.0;
+        const double gainMs = (double)firstLaunchVoxels * 1e-8 * depth, buildMs = 0.1 + 0.15e-6 * (double)total;
+        if (gainMs < buildMs) { release(); return 0; }
+    }
+    if (!c->optListRes && !firstLaunchVoxels && R == 256u && perTexel() > 10.0 && perTexel() <= 32.0) {
         if (recount(512u)) return 1;
     } else if (!c->optListRes && perTexel() > 32.0) {
         if (R != 256u && recount(256u)) return 1;
@@ -380,6 +393,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream)
     c->listRes = R;
     c->listState = 1;
     c->listOpt = c->optListRes;
+    c->listFirstLaunch = firstLaunchVoxels != 0;
     return 0;
 }
 
@@ -408,11 +422,21 @@ int launch_now(dxv_ctx* c, uint32_t frame)
     // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
     // builds them at the first launch.
-    // (... unless the launch is large: from about 640^3 voxels on, what the lists save on this one launch -- 7 ms of 13 at
-    // 1024^3 for 1 M triangles -- is more than their build costs, 2 ms)
-    const bool largeLaunch = (uint64_t)p.N * p.N * p.nz >= (1ull << 28);
+    // (... unless the launch is large enough for the build to pay for itself at once: build_lists decides after its
+    // counting pass -- 1 M triangles at 512^3: 0.65 ms of build + 1.0 ms against 2.7 ms through the tree)
+    const uint64_t voxels = (uint64_t)p.N * p.N * p.nz;
+    if (p.mode == DXV_MODE_REFERENCE && c->optLists == 1 && c->launchesOfScene == 0 && c->listState == 0 && voxels >= (1ull << 26)) {
+        if (sync_frames(c)) return 1;
+        if (build_lists(c, fs, voxels)) return 1;
+    }
+    // a scene still unchanged at its third launch: the resolution the full policy picks
+    if (p.mode == DXV_MODE_REFERENCE && c->optLists == 1 && c->listState == 1 && c->listFirstLaunch && c->launchesOfScene >= 2 && !c->optListRes &&
+        c->listRes == 256u && (double)c->listEntries > 10.0 * 6.0 * 65536.0 && (double)c->listEntries <= 32.0 * 6.0 * 65536.0) {
+        if (sync_frames(c)) return 1;
+        if (build_lists(c, fs)) return 1;
+    }
     const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists &&
-                           (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0 || largeLaunch);
+                           (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0);
     if (p.mode == DXV_MODE_REFERENCE) ++c->launchesOfScene;
     if (wantLists) {
         if (c->listState == 0 || (c->listState != 0 && c->listOpt != c->optListRes)) {
@@ -428,6 +452,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         }
     }
     f.stack_entries = (uint32_t)st;
+    if (!p.lists && ensure_nodes(c, fs)) return 1;                     // a tree walk after a refit: its copies of the hierarchy first
     DXV_HIP(c, hipEventRecord(f.ev0, fs));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {
         // rows whose triangles span several voxels share a walk: 4 x 4 rows per wave above 1.5 voxels of
@@ -568,7 +593,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
+    c->haveMesh = false; c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->nodesStale = false;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -592,6 +617,19 @@ void fill_build_buffers(dxv_ctx* c, BuildBuffers& b)
     b.keys = c->dKeys; b.keysTmp = c->dKeysTmp; b.hist = c->dHist; b.parents = c->dParents;
     b.flags = c->dFlags; b.flags2 = c->dFlags2; b.rootInfo = c->dRootInfo; b.pyramid = c->dPyramid;
     b.nodes = scene_nodes(c); b.nodes32 = scene_nodes32(c); b.nodes64 = c->hdr.hasWide ? scene_nodes64(c) : nullptr; b.triPos = scene_tripos(c); b.triNrm = scene_trinrm(c);
+}
+
+// The half-float / four-box copies of the hierarchy after a refit that skipped them (dxv_refit): made now, on `stream`, and
+// finished before anyone else can launch a walk on another stream.
+int ensure_nodes(dxv_ctx* c, hipStream_t stream)
+{
+    if (!c->nodesStale) return 0;
+    BuildBuffers b{};
+    fill_build_buffers(c, b);
+    DXV_HIP(c, lbvh_traversal_copies(b, stream));
+    DXV_HIP(c, hipStreamSynchronize(stream));
+    c->nodesStale = false;
+    return 0;
 }
 
 // min/max pyramid of the box merge (refit = 1): 24 B box + 4 B deepest leaf per slot
@@ -644,6 +682,17 @@ int dxv_update_vertices(dxv_ctx* c, const float* vb, uint32_t V)
     return 0;
 }
 
+int dxv_update_vertices_device(dxv_ctx* c, const void* dvb, uint32_t V)
+{
+    if (!c) return 1;
+    if (!c->haveMesh || !c->dVb) return fail(c, "dxv_update_vertices_device: no mesh resident on this context");
+    if (!dvb || V != c->V) return fail(c, "dxv_update_vertices_device: vertex count must stay %u, got %u", c->V, V);
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
+    DXV_HIP(c, hipMemcpyAsync(c->dVb, dvb, sizeof(float) * 6 * (size_t)V, hipMemcpyDeviceToDevice, c->stream));
+    return 0;                                                          // (dxv_refit, on the same stream, comes next)
+}
+
 int dxv_refit(dxv_ctx* c)
 {
     if (!c) return 1;
@@ -656,7 +705,11 @@ int dxv_refit(dxv_ctx* c)
     BuildBuffers b{};
     fill_build_buffers(c, b);
     if (c->optRefit != 1) b.pyramid = nullptr;
+    // the walks' copies of the hierarchy (0.12 ms of the refit's 0.25 at 1 M triangles) wait until a walk needs them: the
+    // next launch of a refitted mesh usually goes through the lists, which are built from the triangle records alone
+    b.deferCopies = c->optLists != 0;
     DXV_HIP(c, lbvh_refit(b, c->optRefit, c->hdr.treeHeight, c->stream, c->ev + 3));
+    c->nodesStale = b.deferCopies;
     if (finish_build(c, "dxv_refit")) return 1;
     c->stats.refit_ms = elapsed(c->ev[3], c->ev[4]);
     return 0;
@@ -668,7 +721,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->nodesStale = false;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -955,6 +1008,7 @@ int dxv_scene_export(dxv_ctx* c, void* dst, size_t bytes)
     const BlobLayout b = blob_layout(c->sceneBytes, withLists ? c->listRes : 0u, withLists ? c->listEntries : 0u);
     if (!dst || bytes != b.total) return fail(c, "dxv_scene_export: expected %zu bytes, got %zu", b.total, bytes);
     DXV_HIP(c, hipSetDevice(c->device));
+    if (ensure_nodes(c, c->stream)) return 1;
     DXV_HIP(c, hipMemcpyAsync(dst, c->dScene, c->sceneBytes, hipMemcpyDeviceToDevice, c->stream));
     SceneHeader h = c->hdr;
     h.offListCells = h.offListEntries = 0; h.listRes = h.listCount = 0;
@@ -990,7 +1044,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         (withLists && (h.offListCells != b.offCells || h.offListEntries != b.offEntries)) || (!withLists && (h.offListCells || h.offListEntries || h.listCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->nodesStale = false;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
     // triangle count over the old, smaller buffers.
@@ -1122,6 +1176,7 @@ int dxv_debug_list_check(dxv_ctx* c, uint32_t N, uint64_t out[34])
         if (build_lists(c, c->stream)) return 1;
     }
     if (c->listState != 1) return fail(c, "dxv_debug_list_check: this scene has no lists (over the caps)");
+    if (ensure_nodes(c, c->stream)) return 1;
     unsigned long long* dOut = nullptr;
     DXV_HIP(c, hipMalloc(&dOut, 34 * sizeof(unsigned long long)));
     VoxelizeParams p{};
@@ -1145,6 +1200,7 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     const void* src = nullptr;
     size_t want = 0;
     const size_t T = c->T;
+    if ((what == DXV_DBG_NODES32 || what == DXV_DBG_NODES64) && c->haveScene && ensure_nodes(c, c->stream)) return 1;
     switch (what) {
     case DXV_DBG_SORTED_KEYS: src = c->dKeys; want = sizeof(uint64_t) * T; if (c->scratchT != c->T) src = nullptr; break;
     case DXV_DBG_PARENTS: src = c->dParents; want = sizeof(uint32_t) * (2 * T - 1); if (c->scratchT != c->T) src = nullptr; break;

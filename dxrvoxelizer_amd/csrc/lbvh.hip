@@ -277,8 +277,10 @@ static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t 
             rootReadyFlag = ready;
         }
     }
-    if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
-    else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    if (!b.deferCopies) {
+        if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
+        else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    }
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, rootReadyFlag);
     return hipGetLastError();
 }
@@ -481,9 +483,21 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
         if (P > kPyrLeaves) k_pyramid_high<false><<<1, 1024, 0, s>>>(P, pyr, nullptr);
         k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr);
     }
+    if (!b.deferCopies) {
+        if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
+        else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    }
+    k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
+    return hipGetLastError();
+}
+
+// The copies of the hierarchy the tree walks read (half-float boxes; four-box nodes), from the exact nodes: what a refit
+// with deferCopies left undone -- a scene whose next launch goes through the direction-space lists never needs them.
+hipError_t lbvh_traversal_copies(const BuildBuffers& b, hipStream_t s)
+{
+    const uint32_t numNodes = b.T > 1 ? b.T - 1 : 1;
     if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
     else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
-    k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
     return hipGetLastError();
 }
 

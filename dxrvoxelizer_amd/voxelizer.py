@@ -83,6 +83,14 @@ class Voxelizer:
             self._check(self._lib.dxv_refit(self._ctx))
         return True
 
+    def UpdateVerticesDevice(self, device_ptr, num_verts, refit=True):
+        """The same from a device buffer (6 floats per vertex on this GPU, e.g. a torch tensor's data_ptr()): a mesh animated
+        on the GPU never passes through the host."""
+        self._check(self._lib.dxv_update_vertices_device(self._ctx, C.c_void_p(int(device_ptr)), int(num_verts)))
+        if refit:
+            self._check(self._lib.dxv_refit(self._ctx))
+        return True
+
     def SetFrame(self, frameIndex):
         """The frame (0 .. FrameCount-1) the following Voxelize / Sync / Grid / Texels / Render / stats calls refer
         to: the reference's frameIndex argument (Content/Voxelizer.h:20-22) and its m_grids[FrameCount] (:110)."""

@@ -103,6 +103,11 @@ DXV_API int dxv_build(dxv_ctx* ctx);
  * same index buffer; the normalising bound stays the one of dxv_set_mesh, as the reference's
  * m_bound stays the one of Init) and dxv_refit recomputes the boxes of the existing hierarchy. */
 DXV_API int dxv_update_vertices(dxv_ctx* ctx, const float* vb, uint32_t num_verts);
+/* The same from a DEVICE buffer (6 floats per vertex, on this context's GPU): the reference's vertex buffer is a GPU
+ * resource (createVB, Content/Voxelizer.cpp:115-126), and a mesh animated on the GPU -- skinning, simulation -- never
+ * passes through the host.  A device-to-device copy on the context's stream; the caller's buffer may be reused as soon as
+ * the call returns only if it was written on that stream, else after dxv_sync_all. */
+DXV_API int dxv_update_vertices_device(dxv_ctx* ctx, const void* device_vb, uint32_t num_verts);
 DXV_API int dxv_refit(dxv_ctx* ctx);
 
 /* Voxelize slices [z0, z0+nz) of a grid_dim^3 grid: replaces Voxelizer::voxelize =

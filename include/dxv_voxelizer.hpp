@@ -78,6 +78,13 @@ public:
 		return dxv_update_vertices(m_ctx, vb, numVerts) == 0 && dxv_refit(m_ctx) == 0;
 	}
 
+	// ... from a device buffer (a mesh animated on the GPU)
+	bool UpdateVerticesDevice(const void* deviceVb, uint32_t numVerts)
+	{
+		if (!m_ctx) return setError("UpdateVerticesDevice before Init");
+		return dxv_update_vertices_device(m_ctx, deviceVb, numVerts) == 0 && dxv_refit(m_ctx) == 0;
+	}
+
 	// Content/Voxelizer.h:20-22: UpdateFrame(frameIndex, eyePt, viewProj) stores the camera, Render
 	// runs voxelize + the ray-cast display pass.  eyePt[3]; viewProj row-major, row vectors
 	// (XMFLOAT4X4 of view * proj, DXRVoxelizer.cpp:249-254).

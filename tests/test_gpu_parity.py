@@ -800,3 +800,70 @@ def test_lists_follow_the_scene_and_fall_back_over_the_cap(dxv, orc, bunny):
     assert v.stats()["list_entries"] == 0
     assert np.array_equal(v.Grid(), orc.Scene(big, np.arange(3 * T, dtype=np.uint32)).voxelize(32, algo=orc.ALGO_BRUTE))
     v.close()
+
+
+@pytest.mark.gpu
+def test_first_launch_list_policy(dxv, dragon):
+    """Option lists=1 (default): a scene's FIRST launch builds the lists only when that pays on this one launch (build_lists'
+    estimate after its counting pass) -- a mesh refitted every frame never has a second one -- at the base resolution; a
+    scene still unchanged at its third launch gets the resolution of the full policy.  Same grid every way."""
+    from bench import make_mesh
+    vb, ib, _ = dragon
+    v = dxv.Voxelizer(0)
+    v.InitFromArrays(vb, ib)
+    v.Voxelize(128)                                                    # 2 M voxels: the tree walk is cheaper than any build
+    assert v.stats()["list_entries"] == 0
+    v.InitFromArrays(vb, ib)
+    v.Voxelize(416)                                                    # 72 M voxels, 2.7 M entries: the build pays at once
+    st = v.stats()
+    assert st["list_entries"] > 0 and st["list_res"] == 256
+    solid = v.CountSolid()
+    v.UpdateVertices(np.ascontiguousarray(vb, np.float32))             # a refit: the next launch is a first launch again
+    v.Voxelize(416)
+    assert v.stats()["list_entries"] > 0 and v.CountSolid() == solid
+    v.set_option("lists", 0)
+    v.Voxelize(416)
+    assert v.stats()["list_entries"] == 0 and v.CountSolid() == solid
+    v.set_option("lists", 1)
+    vb9, ib9, _ = make_mesh("dragon9")                                  # 11 entries per texel of the 256 map: the full policy takes 512
+    v.InitFromArrays(vb9, ib9)
+    res, counts = [], []
+    for _ in range(4):
+        v.Voxelize(416)
+        res.append(v.stats()["list_res"]); counts.append(v.CountSolid())
+    assert res == [256, 256, 512, 512] and len(set(counts)) == 1, (res, counts)
+    v.close()
+
+
+@pytest.mark.gpu
+def test_update_vertices_from_a_device_buffer(dxv, orc, bunny):
+    """dxv_update_vertices_device (a mesh animated on the GPU): same grid as the host-buffer update and as the oracle on the
+    moved mesh; wrong counts and null pointers are refused."""
+    import torch
+    vb, ib, _ = bunny
+    moved = np.array(vb, np.float32, copy=True)
+    moved[:, 1] *= 0.7
+    moved[:, 0] += 0.1 * np.sin(7.0 * moved[:, 2])
+    v = dxv.Voxelizer(0)
+    v.InitFromArrays(vb, ib)
+    v.Voxelize(64)
+    d = torch.from_numpy(moved).cuda()
+    torch.cuda.synchronize()
+    v.UpdateVerticesDevice(d.data_ptr(), len(moved))
+    v.Voxelize(64)
+    a = v.Grid().copy()
+    v.InitFromArrays(vb, ib)
+    v.UpdateVertices(moved)
+    v.Voxelize(64)
+    assert np.array_equal(a, v.Grid())
+    s = orc.Scene(moved, ib)                                           # (the oracle normalises by the moved mesh's own bound: compare
+    w = dxv.Voxelizer(0)                                               # with a context built on the moved mesh only when bounds agree)
+    w.InitFromArrays(moved, ib)
+    w.Voxelize(64)
+    if np.allclose(s.bound, orc.Scene(vb, ib).bound):
+        assert np.array_equal(a, w.Grid())
+    with pytest.raises(dxv.DxvError):
+        v.UpdateVerticesDevice(d.data_ptr(), len(moved) - 1)
+    with pytest.raises(dxv.DxvError):
+        v.UpdateVerticesDevice(0, len(moved))
+    v.close(); w.close()
