@@ -275,6 +275,8 @@ uint32_t list_resolution(const dxv_ctx* c)
 // mean list length) exceeds what the rest of the build costs (0.1 ms + 0.15 ns per entry: 0.65 ms for 3.8 M entries), and
 // it keeps the base resolution (a 512 map is 3 - 9 % faster for some scenes but takes 2 - 3 x as long to build; a scene
 // that is still the same at its third launch gets it then).  Declined: listState stays 0, the launch walks the tree.
+int ensure_nodes(dxv_ctx* c, hipStream_t stream);      // (below, with the build)
+
 int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
 {
     const uint32_t T = c->hdr.numTris;
