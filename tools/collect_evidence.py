@@ -38,6 +38,9 @@ def main():
     ks = newest(os.path.join(SRC, "prof_bench", "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks, os.path.join(DST, "bench_kernel_stats.csv"))
+    ks = newest(os.path.join(SRC, "prof_refit_loop", "*", "*_kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks, os.path.join(DST, "refit_loop_kernel_stats.csv"))
     summary = defaultdict(lambda: defaultdict(list))
     for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
         if not os.path.isdir(d):

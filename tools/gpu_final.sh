@@ -42,6 +42,9 @@ python tools/rowblock_table.py > $OUT/rowblock.jsonl 2>&1
 python tools/small_grid_latency.py > $OUT/small_grid_latency.jsonl 2>&1
 python tools/texel_time.py > $OUT/texel_time.jsonl 2>&1
 python tools/frame_loop.py > $OUT/frame_loop.jsonl 2>&1
+python tools/refit_loop.py torus1m 512 40 > $OUT/refit_loop.jsonl 2>&1
+python tools/refit_loop.py bunny16 512 20 >> $OUT/refit_loop.jsonl 2>&1
+python tools/refit_loop.py dragon9 512 20 >> $OUT/refit_loop.jsonl 2>&1
 python tools/ablate.py --meshes torus1m,bunny16 > $OUT/ablate.jsonl 2>&1
 python tools/quick_times.py --meshes torus1m,bunny16,dragon9,bunny,dragon,soup10m --tree > $OUT/quick_times.jsonl 2>&1
 python bench.py --gpus 2 --backend gloo --same-device --no-cpu-baseline > $OUT/bench_2rank_same_gpu_gloo.json 2> $OUT/bench_2rank_same_gpu_gloo.err
@@ -50,6 +53,8 @@ cd /tmp && export TMPDIR=/tmp
 # the timed region alone (no second occupancy rule, tree walk, second mesh or two-in-flight region behind it), so that the
 # kernel's average over this command is the average bench.py itself reports
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $OUT/prof_bench.log 2>&1
+# the refit-per-frame loop: kernels of refit + list build + voxelize, per frame
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_refit_loop -- python3 $GRAFT_REPO_ROOT/tools/refit_loop.py torus1m 512 20 > $OUT/prof_refit_loop.log 2>&1
 R=$GRAFT_REPO_ROOT/tools/run_once.py
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq1 -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_sq2 -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_sq2.log 2>&1
