@@ -88,14 +88,13 @@ struct dxv_ctx {
     uint32_t listEntries = 0, listRes = 0;
     int listState = 0;               // 0: not built for this scene, 1: built, -1: over the cap for this scene (tree walk)
     int optLists = 1;                // reference rule through the lists (-40...-60 % against the tree walk, profiles/r01/final/ab_lists.jsonl):
-                                     // 1 = from a scene's second launch on, 2 = from the first, 0 = tree walk
+                                     // 1 = from a scene's second launch on (from the first when that launch is large: build_lists), 2 = from the first, 0 = tree walk
     int optListRes = 0;              // texels per face side; 0 = by triangle count (list_resolution)
     float listMs = 0.0f;
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
     uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
     bool nodesStale = false;         // a refit left nodes32 / nodes64 behind (ensure_nodes brings them up to date before anything reads them)
-    bool listFirstLaunch = false;    // the lists were built at the scene's first launch: base resolution only (build_lists)
     int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
     size_t emptyCap = 0;
@@ -262,7 +261,7 @@ int safe_stack(const dxv_ctx* c, int mode)
 // faces) keep the tree walk: listState = -1.
 // Texels per face side.  Measured optimum (tools/ab_lists.py): 5-10 entries per texel -- coarser maps
 // have long lists, finer ones stop fitting the caches: 128 below 20 k triangles, 256 up to 3 M (512 when the
-// 256 map holds more than 10 entries per texel: build_lists), 512 beyond.
+// 256 map holds more than 10 entries per texel and the scene is presumed static: build_lists), 512 beyond.
 uint32_t list_resolution(const dxv_ctx* c)
 {
     if (c->optListRes) return (uint32_t)c->optListRes;
@@ -272,11 +271,9 @@ uint32_t list_resolution(const dxv_ctx* c)
 // firstLaunchVoxels != 0: called for the FIRST launch of a scene (option lists=1), which may be its only one -- a mesh that
 // is refitted every frame.  The build then has to pay for itself on this launch: after the counting pass (0.1 ms) it goes
 // on only when what the lists save over the tree walk (about 10 ps per voxel; more in deep scenes, in proportion to the
-// mean list length) exceeds what the rest of the build costs (0.1 ms + 0.15 ns per entry: 0.65 ms for 3.8 M entries), and
-// it keeps the base resolution (a 512 map is 3 - 9 % faster for some scenes but takes 2 - 3 x as long to build; a scene
-// that is still the same at its third launch gets it then).  Declined: listState stays 0, the launch walks the tree.
+// mean list length) exceeds what the rest of the build costs (0.1 ms + 0.15 ns per entry: 0.65 ms for 3.8 M entries).
+// Declined: listState stays 0, the launch walks the tree, the second launch builds the lists.
 int ensure_nodes(dxv_ctx* c, hipStream_t stream);      // (below, with the build)
-
 int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
 {
     const uint32_t T = c->hdr.numTris;
@@ -336,8 +333,9 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     };
     // automatic resolution, from the mean list length A = entries per texel (it hardly depends on the map: it is the
     // number of triangles a direction meets, at any depth):
-    //  * 10 < A <= 32 on the 256 map: the 512 map is faster (bunny x16 1.94 -> 1.77 ms, dragon x9 1.14 -> 1.11; torus-1M,
-    //    9.8 per texel, is the same on both);
+    //  * 10 < A <= 32 on the 256 map: the 512 map is faster for some scenes (bunny x16 1.49 -> 1.42 ms; dragon x9 0.79 ->
+    //    0.82, torus-1M with 9.6 per texel the same) at 2 - 3 x the build time and memory -- taken when the scene is
+    //    presumed static (not on a first-launch build, which must pay for itself at once);
     //  * A > 32: the scene is deep in every direction (soups: hundreds of triangles behind one another).  A ray still
     //    reads only the part of its list between its start and its first hit (the lists are sorted by far radius and the
     //    scan stops behind the hit, dxv_dirmap.h), so what matters is the size of the structure, which grows with the
@@ -395,7 +393,6 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     c->listRes = R;
     c->listState = 1;
     c->listOpt = c->optListRes;
-    c->listFirstLaunch = firstLaunchVoxels != 0;
     return 0;
 }
 
@@ -430,12 +427,6 @@ int launch_now(dxv_ctx* c, uint32_t frame)
     if (p.mode == DXV_MODE_REFERENCE && c->optLists == 1 && c->launchesOfScene == 0 && c->listState == 0 && voxels >= (1ull << 26)) {
         if (sync_frames(c)) return 1;
         if (build_lists(c, fs, voxels)) return 1;
-    }
-    // a scene still unchanged at its third launch: the resolution the full policy picks
-    if (p.mode == DXV_MODE_REFERENCE && c->optLists == 1 && c->listState == 1 && c->listFirstLaunch && c->launchesOfScene >= 2 && !c->optListRes &&
-        c->listRes == 256u && (double)c->listEntries > 10.0 * 6.0 * 65536.0 && (double)c->listEntries <= 32.0 * 6.0 * 65536.0) {
-        if (sync_frames(c)) return 1;
-        if (build_lists(c, fs)) return 1;
     }
     const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists &&
                            (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0);
