@@ -109,7 +109,6 @@ struct dxv_ctx {
     int optStack = 0;        // 0 = adaptive (start small, grow on overflow), else forced depth
     int optRefit = 1;        // box merge of build and refit: 1 = min/max pyramid (default), 2 = level sweeps, 0 = atomic one-pass climb (17-30x slower, cross-check)
     int optMorton = 1;       // Morton brick order
-    int optQuadAxis = 0;     // lists kernel: quads along the brick's dominant axis
     int optQueue = 1;        // postponed-leaf traversal
     int optSubbox = 1;       // launch only the bricks around the scene's root box, memset the rest
     int optWide = 2;         // reference rule: 2 = four-box nodes on wave-uniform visits (-2...-7 % everywhere measured),
@@ -411,7 +410,6 @@ int launch_now(dxv_ctx* c, uint32_t frame)
     p.zShift = 0;
     while ((1u << p.zShift) < p.zBlock) ++p.zShift;
     p.morton = (uint32_t)c->optMorton;
-    p.quadAxis = (uint32_t)c->optQuadAxis;
     p.regionBits = (uint32_t)c->optRegion;
     p.queued = (uint32_t)c->optQueue;
     p.subbox = (uint32_t)c->optSubbox;
@@ -1147,9 +1145,6 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "region")) {
         if (value < 0 || value > 24) return fail(c, "option region: %lld not in [0,24]", (long long)value);
         c->optRegion = (int)value;
-    } else if (!strcmp(key, "quadaxis")) {
-        if (value != 0 && value != 1) return fail(c, "option quadaxis: %lld not in {0,1}", (long long)value);
-        c->optQuadAxis = (int)value;
     } else if (!strcmp(key, "morton")) {
         if (value != 0 && value != 1) return fail(c, "option morton: %lld not in {0,1}", (long long)value);
         c->optMorton = (int)value;

@@ -74,7 +74,6 @@ struct VoxelizeParams {
     uint32_t subbox;        // 1: launch only bricks the root early-out cannot clear (default)
     uint32_t wide;          // 1: reference rule walks the wide nodes (default when the stack bound allows)
     uint32_t lists;         // 1: reference rule reads the direction-space lists of p.scene (no tree walk)
-    uint32_t quadAxis;      // lists kernel, cubic bricks: 1 = the four lanes of a quad run along the brick's dominant axis (the most radial one)
     uint32_t ablate;        // timing-only builds of the lists kernel (wrong grids; tools/ablate.py), 0 = the real kernel
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);

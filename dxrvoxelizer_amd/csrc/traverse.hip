@@ -63,35 +63,6 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
     }
     bx += p.bx0; by += p.by0; bz += p.bz0;
     const uint32_t tid = threadIdx.x;
-    constexpr bool kCubic = WALK == 4 && MODE == 0 && !TEXELS && B::x == 4 && B::y == 4 && B::z == 4;
-    if (kCubic && p.quadAxis) {
-        // Lists, one wave per 4 x 4 x 4 brick: the vector L1 merges the accesses of the four consecutive lanes of a quad when
-        // they fall into one 64-byte line (tools/micro/ta_merge.hip), and two rays read the same list when their directions
-        // fall into one texel.  Along the brick's dominant axis -- the most radial of the three -- the direction changes
-        // least from voxel to voxel, so the quads run along that axis.  The grid bytes are then written the other way round
-        // (x-major again, through a ballot), so that the store still covers whole rows of the brick.
-        const uint32_t zc = bz * 4u;
-        const uint32_t izc = p.zBlock == p.nz ? p.z0 + zc : p.z0 + (zc >> p.zShift) * p.zPeriod + (zc & (p.zBlock - 1u));
-        const int ax = abs((int)(2u * bx * 4u + 4u) - (int)N), ay = abs((int)(2u * by * 4u + 4u) - (int)N), az = abs((int)(2u * izc + 4u) - (int)N);
-        const uint32_t axis = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);      // wave-uniform
-        const uint32_t a = tid & 3u, b = (tid >> 2) & 3u, c = tid >> 4;
-        // lane (a, b, c) computes the voxel with local coordinates: axis 0 (a, b, c), axis 1 (b, a, c), axis 2 (c, b, a);
-        // each is its own inverse, so the lane that STORES local voxel (a, b, c) finds it at lane index swap(tid)
-        const uint32_t tx = axis == 0u ? a : axis == 1u ? b : c, ty = axis == 1u ? a : b, tz = axis == 2u ? a : c;
-        const uint32_t src = tx | (ty << 2) | (tz << 4);
-        const uint32_t ix = bx * 4u + tx, iy = by * 4u + ty, lz = bz * 4u + tz;
-        bool occ = false;
-        if (ix < N && iy < N && lz < p.nz) {
-            const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
-            const StridedStack stk{stack + tid, B::threads};
-            bool overflow = false;                                       // (the lists cannot overflow)
-            occ = voxel_reference<WALK, StridedStack, ABL>(p.scene, N, ix, iy, iz, stk, STACK, nullptr, overflow) != 0;
-        }
-        const unsigned long long mask = __ballot(occ);
-        const uint32_t sx = bx * 4u + a, sy = by * 4u + b, sz = bz * 4u + c;
-        if (sx < N && sy < N && sz < p.nz) p.grid[((size_t)sz * N + sy) * N + sx] = (uint8_t)((mask >> src) & 1ull);
-        return;
-    }
     const uint32_t ix = bx * B::x + tid % B::x;
     const uint32_t iy = by * B::y + (tid / B::x) % B::y;
     const uint32_t lz = bz * B::z + tid / (B::x * B::y);
