@@ -249,6 +249,54 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
     words[1] = (count < 0xffffu ? count : 0xffffu) | (((entries[i].rr >> 16) & 0x7fffu) << 16);
     if (count > 0xffffu) atomicMax(longest, count);                    // (only what does not fit is reported: one address, 300 k texels)
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row lists of the parity rule.  All its rays are +X lines: a row of voxels (fixed y, z) is one point of the (y, z)
+// plane, and the triangles its rays can cross are those whose padded box covers that point (parity_row_setup's first
+// test).  A grid of R x R texels over the plane lists per texel the triangles whose box reaches it: a row reads one
+// 8-byte cell and then its candidates one after the other, instead of walking the tree to them (k_parity_rows waited on
+// that chain of ~17 dependent node fetches per row).  A triangle is in a texel's list at most once, every candidate still
+// takes the exact per-row test, and the order inside a list cannot matter to a count: the lists are filled through atomic
+// cursors, without a sort.  Texels are a monotone function of the coordinate (dm_texel), the same on both sides.
+// ---------------------------------------------------------------------------------------------
+DXV_HD void pl_rect(const TriPos& tp, uint32_t R, uint32_t& j0, uint32_t& j1, uint32_t& k0, uint32_t& k1)
+{
+    float lo[3], hi[3];
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);                              // the canonical padded box parity_row_setup tests
+    j0 = dm_texel(lo[1], R); j1 = dm_texel(hi[1], R); k0 = dm_texel(lo[2], R); k1 = dm_texel(hi[2], R);
+}
+__global__ __launch_bounds__(kThreads) void k_pl_total(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R, unsigned long long* __restrict__ total)
+{
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+    unsigned long long n = 0;
+    if (t < T) {
+        uint32_t j0, j1, k0, k1;
+        pl_rect(triPos[t], R, j0, j1, k0, k1);
+        n = (unsigned long long)(j1 - j0 + 1u) * (k1 - k0 + 1u);
+    }
+    for (int off = 32; off; off >>= 1) n += __shfl_down(n, off);
+    if ((threadIdx.x & 63u) == 0u && n) atomicAdd(total, n);
+}
+// FILL = false: counts[texel] += 1 per covered texel; FILL = true: entries[begin[texel] + cursor[texel]++] = triangle
+template <bool FILL>
+__global__ __launch_bounds__(kThreads) void k_pl_scatter(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R, uint32_t* __restrict__ counts,
+                                                         const uint32_t* __restrict__ begin, uint32_t* __restrict__ entries)
+{
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= T) return;
+    uint32_t j0, j1, k0, k1;
+    pl_rect(triPos[t], R, j0, j1, k0, k1);
+    for (uint32_t k = k0; k <= k1; ++k)
+        for (uint32_t j = j0; j <= j1; ++j) {
+            const uint32_t c = k * R + j, slot = atomicAdd(counts + c, 1u);
+            if (FILL) entries[begin[c] + slot] = t;
+        }
+}
+__global__ __launch_bounds__(kThreads) void k_pl_cells(const uint32_t* __restrict__ begin, const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ cells)
+{
+    const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
+    if (c < n) { cells[2u * c] = begin[c]; cells[2u * c + 1u] = counts[c]; }
+}
 } // namespace
 
 // scratch bytes of a build that emits `entries` keys for T triangles (records, counts/offsets, block sums, keys x 2, histogram)
@@ -300,6 +348,32 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries, longCells, sums + 1);
     k_dm_stops_long<<<4096, 64, 0, s>>>(cells, longCells, sums + 1, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// Row lists of the parity rule (above).  parity_lists_total: entries the lists would have; parity_lists_fill: cells = 2 words
+// (begin, count) per texel of the R x R grid, entries = `total` triangle slots (+ a few spare words behind them).
+// counts / offsets: R R words each, sums: ceil(R R / 1024) + 1 words of scratch.
+hipError_t parity_lists_total(const TriPos* triPos, uint32_t T, uint32_t R, unsigned long long* total, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    k_pl_total<<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, total);
+    return hipGetLastError();
+}
+hipError_t parity_lists_fill(const TriPos* triPos, uint32_t T, uint32_t R, uint32_t* counts, uint32_t* offsets, uint32_t* sums, uint32_t* cells,
+                             uint32_t* entries, hipStream_t s)
+{
+    const uint32_t n = R * R, nb = (n + kScanBlock - 1) / kScanBlock, blocks = (T + kThreads - 1) / kThreads;
+    hipError_t e;
+    if ((e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * n, s)) != hipSuccess) return e;
+    k_pl_scatter<false><<<blocks, kThreads, 0, s>>>(triPos, T, R, counts, nullptr, nullptr);
+    k_scan_sums<<<nb, 256, 0, s>>>(counts, n, sums);
+    k_scan_top<<<1, 1024, 0, s>>>(sums, nb);
+    k_scan_apply<<<nb, 256, 0, s>>>(counts, n, sums, offsets);
+    if ((e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * n, s)) != hipSuccess) return e;
+    k_pl_scatter<true><<<blocks, kThreads, 0, s>>>(triPos, T, R, counts, offsets, entries);
+    k_pl_cells<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(offsets, counts, n, cells);
     return hipGetLastError();
 }
 

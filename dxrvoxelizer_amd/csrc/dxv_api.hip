@@ -94,6 +94,18 @@ struct dxv_ctx {
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
     uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
+    // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
+    // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
+    uint32_t* dPlCells = nullptr;
+    uint32_t* dPlEntries = nullptr;
+    uint32_t* dPlScratch = nullptr;  // counts, offsets, block sums of the build
+    size_t plCellCap = 0, plEntryCap = 0, plScratchCap = 0;
+    uint32_t plEntries = 0, plRes = 0;
+    int plState = 0;                 // 0: not built for this scene, 1: built, -1: over the cap (tree walk)
+    int optPlistRes = 0;             // texels per side of the row lists' grid; 0 = by triangle count
+    int optPlists = 1;               // 1 = from a scene's second parity launch, 2 = from the first, 0 = tree walk
+    uint32_t parityLaunchesOfScene = 0;
+    float plMs = 0.0f;
     bool nodesStale = false;         // a refit left nodes32 / nodes64 behind (ensure_nodes brings them up to date before anything reads them)
     int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
@@ -395,6 +407,76 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     return 0;
 }
 
+// Row lists of the parity rule (dirmap.hip).  Resolution: the finest grid, from 512 (below 20 k triangles), 2048 (up to 3 M) or
+// 4096 texels per side downwards, whose lists stay within 24 entries per triangle + 8 M (an entry is 4 bytes; measured at
+// 512^3, 1 M triangles: 256 -> 0.62 ms, 512 -> 0.34, 1024 -> 0.24, 2048 -> 0.20; the walk over the tree: 0.65); scenes over that
+// cap on every grid (big triangles cover many texels) or with more than 256 entries per texel keep the tree walk
+// (plState = -1), as does a context that cannot allocate the lists.
+int build_plists(dxv_ctx* c, hipStream_t stream)
+{
+    const uint32_t T = c->hdr.numTris;
+    uint32_t R = c->optPlistRes ? (uint32_t)c->optPlistRes : T < 20000u ? 512u : T < 3000000u ? 2048u : 4096u;
+    const size_t n = (size_t)R * R, nb = (n + 1023) / 1024;             // (scratch for the finest grid tried)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, stream);
+    auto done = [&](int state) {
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        c->plState = state;
+        return 0;
+    };
+    auto oom = [&](hipError_t e, const char* what) {
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); c->plEntries = 0; return done(-1); }
+        (void)done(0);
+        return fail(c, "row lists: %s failed: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    const size_t scratchWords = 2 * n + nb + 1 + 2;                     // counts, offsets, sums, the 64-bit total
+    if (scratchWords > c->plScratchCap) {
+        (void)hipFree(c->dPlScratch); c->dPlScratch = nullptr; c->plScratchCap = 0;
+        if ((e = hipMalloc(&c->dPlScratch, scratchWords * sizeof(uint32_t) + 8)) != hipSuccess) return oom(e, "hipMalloc");
+        c->plScratchCap = scratchWords;
+    }
+    uint32_t* counts = c->dPlScratch;
+    uint32_t* offsets = counts + n;
+    uint32_t* sums = offsets + n;
+    unsigned long long* dTotal = reinterpret_cast<unsigned long long*>(c->dPlScratch + ((2 * n + nb + 1 + 1) & ~(size_t)1));
+    unsigned long long total = 0;
+    const unsigned long long cap = 24ull * T + (8ull << 20);
+    for (;;) {
+        if ((e = parity_lists_total(scene_tripos(c), T, R, dTotal, stream)) != hipSuccess) return oom(e, "parity_lists_total");
+        if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return oom(e, "hipMemcpyAsync");
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return oom(e, "hipStreamSynchronize");
+        // the finest grid that fits the cap: a finer grid has more entries but shorter lists (fewer false candidates per row)
+        if (total <= cap || c->optPlistRes || R <= 256u) break;
+        R >>= 1;
+    }
+    // over the cap even on the coarsest grid, or deep in every row (soups: hundreds of triangles behind one another -- the
+    // row's work is the triangles themselves, and a coarse grid only adds false candidates to them): the tree walk stays
+    if (total > cap || total > 0x7ffffff0ull || (double)total > 256.0 * (double)R * (double)R) { c->plEntries = 0; return done(-1); }
+    const size_t cellWords = 2 * (size_t)R * R;
+    if (cellWords > c->plCellCap) {
+        (void)hipFree(c->dPlCells); c->dPlCells = nullptr; c->plCellCap = 0;
+        if ((e = hipMalloc(&c->dPlCells, cellWords * sizeof(uint32_t))) != hipSuccess) return oom(e, "hipMalloc");
+        c->plCellCap = cellWords;
+    }
+    if ((size_t)total + 8 > c->plEntryCap) {
+        (void)hipFree(c->dPlEntries); c->dPlEntries = nullptr; c->plEntryCap = 0;
+        if ((e = hipMalloc(&c->dPlEntries, ((size_t)total + 8) * sizeof(uint32_t))) != hipSuccess) return oom(e, "hipMalloc");
+        c->plEntryCap = (size_t)total + 8;
+    }
+    // (the kernel fetches up to three slots behind the end of a list: spare words, slot 0)
+    if ((e = hipMemsetAsync(c->dPlEntries + total, 0, 8 * sizeof(uint32_t), stream)) != hipSuccess) return oom(e, "hipMemsetAsync");
+    if ((e = parity_lists_fill(scene_tripos(c), T, R, counts, offsets, sums, c->dPlCells, c->dPlEntries, stream)) != hipSuccess)
+        return oom(e, "parity_lists_fill");
+    if (t1) (void)hipEventRecord(t1, stream);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return oom(e, "hipStreamSynchronize");
+    if (t0 && t1) c->plMs = elapsed(t0, t1);
+    c->plEntries = (uint32_t)total;
+    c->plRes = R;
+    return done(1);
+}
+
 int launch_now(dxv_ctx* c, uint32_t frame)
 {
     Frame& f = c->frames[frame];
@@ -443,7 +525,22 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         }
     }
     f.stack_entries = (uint32_t)st;
-    if (!p.lists && ensure_nodes(c, fs)) return 1;                     // a tree walk after a refit: its copies of the hierarchy first
+    if (p.mode == DXV_MODE_PARITY && c->optRows && !c->optRowBlock) {
+        // parity rule: row lists from the scene's second parity launch on (their build, two passes of atomic additions per
+        // entry, costs 2 ms at 1 M triangles -- as much as three launches through the tree at 512^3, five with what the lists
+        // save: a mesh refitted every frame stays on the tree); plists = 2: from the first
+        const bool want = c->optPlists && (c->optPlists == 2 || c->parityLaunchesOfScene > 0 || c->plState != 0);
+        ++c->parityLaunchesOfScene;
+        if (want && c->plState == 0) {
+            if (sync_frames(c)) return 1;
+            if (build_plists(c, fs)) return 1;
+        }
+        if (want && c->plState == 1) {
+            p.scene.plCells = c->dPlCells; p.scene.plEntries = c->dPlEntries; p.scene.plR = c->plRes;
+            f.list_entries = c->plEntries; f.list_res = c->plRes;
+        }
+    }
+    if (!p.lists && !p.scene.plCells && ensure_nodes(c, fs)) return 1;  // a tree walk after a refit: its copies of the hierarchy first
     DXV_HIP(c, hipEventRecord(f.ev0, fs));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {
         // rows whose triangles span several voxels share a walk: 4 x 4 rows per wave above 1.5 voxels of
@@ -458,6 +555,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         if (voxels > 1.5f && waves(4) >= 12288u) rowBlock = 4;
         else if (voxels > 1.2f && waves(2) >= 12288u) rowBlock = 2;
         if (c->optRowBlock) rowBlock = c->optRowBlock;
+        if (p.scene.plCells) rowBlock = 1;                             // row lists: one row per wave
         f.row_block = (uint32_t)rowBlock;
         DXV_HIP(c, launch_parity_rows(p, rowBlock, fs));
         f.lastRedoParity = -1;
@@ -521,7 +619,7 @@ void dxv_destroy(dxv_ctx* c)
     }
     free_scratch(c);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene);
-    (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
+    (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dPlCells); (void)hipFree(c->dPlEntries); (void)hipFree(c->dPlScratch); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
     (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -584,7 +682,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->nodesStale = false;
+    c->haveMesh = false; c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -691,7 +789,7 @@ int dxv_refit(dxv_ctx* c)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0;
     if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
     fill_build_buffers(c, b);
@@ -712,7 +810,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->nodesStale = false;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -1035,7 +1133,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         (withLists && (h.offListCells != b.offCells || h.offListEntries != b.offEntries)) || (!withLists && (h.offListCells || h.offListEntries || h.listCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->nodesStale = false;
+    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
     // triangle count over the old, smaller buffers.
@@ -1088,7 +1186,7 @@ int dxv_get_stats(const dxv_ctx* c, dxv_stats* out)
     const Frame& f = c->frames[c->cur];
     out->voxelize_ms = f.voxelize_ms; out->grid_dim = f.grid_dim; out->z0 = f.z0; out->nz = f.nz;
     out->stack_entries = f.stack_entries; out->redo_rays = f.redo_rays; out->row_block = f.row_block;
-    out->list_entries = f.list_entries; out->list_res = f.list_res; out->list_ms = c->listMs;
+    out->list_entries = f.list_entries; out->list_res = f.list_res; out->list_ms = f.lastMode == DXV_MODE_PARITY ? c->plMs : c->listMs;
     return 0;
 }
 
@@ -1119,6 +1217,13 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "lists")) {
         if (value < 0 || value > 2) return fail(c, "option lists: %lld not in {0,1,2}", (long long)value);
         c->optLists = (int)value;
+    } else if (!strcmp(key, "plistres")) {
+        if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option plistres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
+        if (c->optPlistRes != (int)value) { if (sync_frames(c)) return 1; c->plState = 0; }     // the next parity launch rebuilds the row lists
+        c->optPlistRes = (int)value;
+    } else if (!strcmp(key, "plists")) {
+        if (value < 0 || value > 2) return fail(c, "option plists: %lld not in {0,1,2}", (long long)value);
+        c->optPlists = (int)value;
     } else if (!strcmp(key, "listres")) {
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option listres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
         if (c->optListRes != (int)value && sync_frames(c)) return 1;     // the next launch rebuilds the lists: nothing may still read them

@@ -50,6 +50,10 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
                        uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longest,
                        hipStream_t s);
 
+hipError_t parity_lists_total(const TriPos* triPos, uint32_t T, uint32_t R, unsigned long long* total, hipStream_t s);
+hipError_t parity_lists_fill(const TriPos* triPos, uint32_t T, uint32_t R, uint32_t* counts, uint32_t* offsets, uint32_t* sums, uint32_t* cells,
+                             uint32_t* entries, hipStream_t s);
+
 // traverse.hip
 struct VoxelizeParams {
     SceneView scene;

@@ -596,6 +596,9 @@ struct SceneView {
     const void* dmCells;    // direction-space lists (dxv_dirmap.h, WALK 4): DirCell[6 R R], DirEntry[], R
     const void* dmEntries;
     uint32_t dmR;
+    const uint32_t* plCells;    // row lists of the parity rule (dirmap.hip): (begin, count) per texel of the plR x plR grid over (y, z); NULL: none
+    const uint32_t* plEntries;  // triangle slots
+    uint32_t plR;
 };
 
 template <class Stack, int ABL = 0>

@@ -251,7 +251,9 @@ struct WaveStack {
 // might cross) -- the launcher decides by the mean triangle extent.
 // WIDE: the walk takes the four-box nodes (Node64) -- half as many dependent scalar fetches, which is
 // what the walk waits on (triangle arithmetic is 6 % of the kernel).
-template <int CH, int RB, bool WIDE>
+// LISTS (RB = 1): the candidates of a row come from the row lists of the parity rule (dirmap.hip) -- one cell, then the
+// triangles of its list four at a time -- instead of from a walk of the tree.
+template <int CH, int RB, bool WIDE, bool LISTS = false>
 __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizeParams p)   // <= 64 / 80 VGPRs
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // (the host pass only needs the stub: the body uses SGPR inline asm)
@@ -360,7 +362,24 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizePar
             m = __builtin_elementwise_max(m, xup - H2(xh));
             return (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, m));
         };
-        if (WIDE) {
+        if (LISTS) {
+            static_assert(!LISTS || RB == 1, "row lists: one row per wave");
+            const uint32_t R = sc.plR;
+            const uint32_t cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dm_texel(oz[0], R) * R + dm_texel(oy[0], R)));
+            const uint32_t begin = sc.plCells[2u * cell], count = sc.plCells[2u * cell + 1u];
+            const uint32_t* list = sc.plEntries + begin;
+            for (uint32_t k = 0; k < count; k += 4u) {
+                // four triangle records in flight (the words behind the end of a list are the next list's or the buffer's
+                // spare ones: valid slots either way, fetched and not used)
+                const uint32_t s0 = list[k], s1 = list[k + 1u], s2 = list[k + 2u], s3 = list[k + 3u];
+                const TriPos t0 = load_tri(sc.triPos, (int32_t)s0), t1 = load_tri(sc.triPos, (int32_t)s1);
+                const TriPos t2 = load_tri(sc.triPos, (int32_t)s2), t3 = load_tri(sc.triPos, (int32_t)s3);
+                triangle(t0);
+                if (k + 1u < count) triangle(t1);
+                if (k + 2u < count) triangle(t2);
+                if (k + 3u < count) triangle(t3);
+            }
+        } else if (WIDE) {
             walk_parity_rows_wide(
                 [&](int32_t i) {
                     const WideSgpr n = load_wide_scalar(sc.wide, i);   // words: x lo, x hi, y lo, y hi, z lo, z hi (children 0,1 | 2,3), links
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizePar
 #endif
 }
 
-template <int CH, int RB, bool WIDE>
+template <int CH, int RB, bool WIDE, bool LISTS = false>
 static hipError_t launch_parity_rows_ch(const VoxelizeParams& pin, hipStream_t s)
 {
     VoxelizeParams p = pin;
@@ -419,7 +438,7 @@ static hipError_t launch_parity_rows_ch(const VoxelizeParams& pin, hipStream_t s
     const uint64_t span = 8ull << rb;
     const uint64_t grid = (nwaves + span - 1) / span * span;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    k_parity_rows<CH, RB, WIDE><<<dim3((uint32_t)grid), dim3(64), 0, s>>>(p);
+    k_parity_rows<CH, RB, WIDE, LISTS><<<dim3((uint32_t)grid), dim3(64), 0, s>>>(p);
     return hipGetLastError();
 }
 
@@ -435,6 +454,12 @@ static hipError_t launch_parity_rows_rb(const VoxelizeParams& p, hipStream_t s)
 // rowBlock: rows per side of a wave's block of rows (1, 2 or 4); the walk takes the four-box nodes when the scene has them
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s)
 {
+    if (p.scene.plCells) {                                             // row lists: one row per wave, no walk
+        if (p.N <= 64) return launch_parity_rows_ch<1, 1, false, true>(p, s);
+        if (p.N <= 128) return launch_parity_rows_ch<2, 1, false, true>(p, s);
+        if (p.N <= 256) return launch_parity_rows_ch<4, 1, false, true>(p, s);
+        return launch_parity_rows_ch<8, 1, false, true>(p, s);
+    }
     if (p.scene.wide) {
         if (rowBlock == 4) return launch_parity_rows_rb<4, true>(p, s);
         if (rowBlock == 2) return launch_parity_rows_rb<2, true>(p, s);

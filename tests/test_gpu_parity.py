@@ -866,3 +866,69 @@ def test_update_vertices_from_a_device_buffer(dxv, orc, bunny):
     with pytest.raises(dxv.DxvError):
         v.UpdateVerticesDevice(0, len(moved))
     v.close(); w.close()
+
+
+@pytest.mark.gpu
+def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
+    """The parity rule through its row lists (`plists`, dirmap.hip: per texel of the (y, z) plane the triangles whose padded box
+    reaches it) gives the grids of the row walk over the tree and of the oracle: assets, lattice-snapped adversarial meshes
+    (cube-spanning triangles: over the size cap, the tree answers), slabs, block-cyclic ranks, rows longer than a wave's run,
+    refits, the policy of option plists = 1."""
+    from test_fuzz import lattice_mesh
+    v = dxv.Voxelizer(0)
+    for vb, ib, _ in (bunny, dragon):
+        s = orc.Scene(vb, ib)
+        v.InitFromArrays(vb, ib)
+        for N in (64, 130):
+            want = s.voxelize(N, mode=1)
+            v.set_option("plists", 2)
+            v.Voxelize(N, dxv.MODE_PARITY)
+            st = v.stats()
+            assert st["list_entries"] > 0 and st["row_block"] == 1 and np.array_equal(v.Grid(), want), N
+            v.set_option("plists", 0)
+            v.Voxelize(N, dxv.MODE_PARITY)
+            assert v.stats()["list_entries"] == 0 and np.array_equal(v.Grid(), want), N
+        v.set_option("plists", 2)
+        z0, nz = 17, 40
+        v.Voxelize(130, dxv.MODE_PARITY, z0, nz)
+        assert np.array_equal(v.Grid(), s.voxelize(130, mode=1)[z0:z0 + nz])
+        v.VoxelizeInterleaved(128, 1, 4, 2, dxv.MODE_PARITY)
+        zs = np.concatenate([np.arange(b, b + 2) for b in range(2, 128, 8)])
+        assert np.array_equal(v.Grid(), s.voxelize(128, mode=1)[zs])
+    # rows of 1024 voxels: two runs per row
+    vb, ib, _ = dragon
+    v.InitFromArrays(vb, ib)
+    v.set_option("plists", 2)
+    v.Voxelize(1024, dxv.MODE_PARITY, 500, 24)
+    a = v.Grid().copy()
+    v.set_option("plists", 0)
+    v.Voxelize(1024, dxv.MODE_PARITY, 500, 24)
+    assert a.sum() > 0 and np.array_equal(a, v.Grid())
+    # policy of the default: a small first launch walks the tree, the second one has the lists; a refit starts over
+    v.set_option("plists", 1)
+    v.InitFromArrays(vb, ib)
+    v.Voxelize(64, dxv.MODE_PARITY)
+    assert v.stats()["list_entries"] == 0
+    v.Voxelize(64, dxv.MODE_PARITY)
+    assert v.stats()["list_entries"] > 0
+    moved = np.array(vb, np.float32, copy=True)
+    moved[:, 2] *= 0.6
+    v.UpdateVertices(moved)
+    v.Voxelize(64, dxv.MODE_PARITY)
+    assert v.stats()["list_entries"] == 0
+    b = v.Grid().copy()
+    v.Voxelize(64, dxv.MODE_PARITY)
+    assert v.stats()["list_entries"] > 0 and np.array_equal(v.Grid(), b)
+    # adversarial meshes
+    rng = np.random.default_rng(515)
+    v.set_option("plists", 2)
+    served = 0
+    for n_tris, L, N in ((1, 8, 16), (7, 8, 32), (200, 16, 64), (30, 32, 96), (1500, 32, 64)):
+        vb, ib = lattice_mesh(rng, n_tris, L)
+        want = orc.Scene(vb, ib).voxelize(N, mode=1, algo=orc.ALGO_BRUTE)
+        v.InitFromArrays(vb, ib)
+        v.Voxelize(N, dxv.MODE_PARITY)
+        served += v.stats()["list_entries"] > 0
+        assert np.array_equal(v.Grid(), want), (n_tris, L, N)
+    assert served >= 2
+    v.close()

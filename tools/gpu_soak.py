@@ -70,7 +70,8 @@ def main():
             opts = {"queue": int(rng.integers(0, 2)), "rows": int(rng.integers(0, 2)), "rowblock": int(rng.choice([0, 1, 2, 4])),
                     "wide": int(rng.integers(0, 3)), "brick": int(rng.integers(0, 8)), "stack": int(rng.choice([0, 0, 12, 16, 32])),
                     "subbox": int(rng.integers(0, 2)), "morton": int(rng.integers(0, 2)),
-                    "lists": int(rng.integers(0, 3)), "listres": int(rng.choice([0, 0, 16, 64, 512, 2048]))}
+                    "lists": int(rng.integers(0, 3)), "listres": int(rng.choice([0, 0, 16, 64, 512, 2048])),
+                    "plists": int(rng.integers(0, 3)), "plistres": int(rng.choice([0, 0, 16, 128, 1024]))}
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))
