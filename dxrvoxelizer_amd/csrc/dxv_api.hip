@@ -529,7 +529,12 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         // parity rule: row lists from the scene's second parity launch on (their build, two passes of atomic additions per
         // entry, costs 2 ms at 1 M triangles -- as much as three launches through the tree at 512^3, five with what the lists
         // save: a mesh refitted every frame stays on the tree); plists = 2: from the first
-        const bool want = c->optPlists && (c->optPlists == 2 || c->parityLaunchesOfScene > 0 || c->plState != 0);
+        // ... and only while triangles are small in voxels: a row's candidates are set up per row, and where a triangle spans
+        // many rows the 4 x 4 row blocks of the walk share that work (mean box extent in voxels, lists / walk in ms: torus-1M
+        // at 1024^3 1.7: 1.31 / 2.02; dragon x9 2.3: 1.26 / 1.49; dragon at 512^3 3.5: 0.16 / 0.36; bunny 5: 0.20 / 0.27;
+        // dragon at 1024^3 7: 1.18 / 0.88; bunny 10: 1.36 / 0.98)
+        const bool small = c->hdr.triExtent * 0.5f * (float)p.N <= 6.0f;
+        const bool want = c->optPlists && (c->optPlists == 2 || (small && (c->parityLaunchesOfScene > 0 || c->plState != 0)));
         ++c->parityLaunchesOfScene;
         if (want && c->plState == 0) {
             if (sync_frames(c)) return 1;

@@ -209,6 +209,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 lists would average more than 32 entries per texel, or exceed 256 entries per
  *                 triangle + 64 M, keep the tree walk (stats.list_entries = 0)
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
+ *   plists 0|1|2    parity rule through row lists of the (y, z) plane: 1 (default) from a scene's second parity launch,
+ *                 2 from the first, 0 = always walk the tree; plistres 0|16..4096: texels per side of their grid
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
