@@ -274,8 +274,9 @@ __global__ __launch_bounds__(kThreads) void k_pl_total(const TriPos* __restrict_
         pl_rect(triPos[t], R, j0, j1, k0, k1);
         n = (unsigned long long)(j1 - j0 + 1u) * (k1 - k0 + 1u);
     }
-    for (int off = 32; off; off >>= 1) n += __shfl_down(n, off);
-    if ((threadIdx.x & 63u) == 0u && n) atomicAdd(total, n);
+    unsigned long long m = n;                                          // total[1]: the largest rectangle of one triangle (a thread's loop)
+    for (int off = 32; off; off >>= 1) { n += __shfl_down(n, off); const unsigned long long o = __shfl_down(m, off); if (o > m) m = o; }
+    if ((threadIdx.x & 63u) == 0u && n) { atomicAdd(total, n); atomicMax(total + 1, m); }
 }
 // FILL = false: counts[texel] += 1 per covered texel; FILL = true: entries[begin[texel] + cursor[texel]++] = triangle
 template <bool FILL>
@@ -351,12 +352,13 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     return hipGetLastError();
 }
 
-// Row lists of the parity rule (above).  parity_lists_total: entries the lists would have; parity_lists_fill: cells = 2 words
+// Row lists of the parity rule (above).  parity_lists_total: total[0] = entries the lists would have, total[1] = texels of the
+// largest single rectangle (one thread of the fill walks it); parity_lists_fill: cells = 2 words
 // (begin, count) per texel of the R x R grid, entries = `total` triangle slots (+ a few spare words behind them).
 // counts / offsets: R R words each, sums: ceil(R R / 1024) + 1 words of scratch.
 hipError_t parity_lists_total(const TriPos* triPos, uint32_t T, uint32_t R, unsigned long long* total, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(total, 0, 2 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     k_pl_total<<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, total);
     return hipGetLastError();

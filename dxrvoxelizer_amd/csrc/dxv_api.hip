@@ -431,7 +431,7 @@ int build_plists(dxv_ctx* c, hipStream_t stream)
         return fail(c, "row lists: %s failed: %s", what, hipGetErrorString(e));
     };
     hipError_t e;
-    const size_t scratchWords = 2 * n + nb + 1 + 2;                     // counts, offsets, sums, the 64-bit total
+    const size_t scratchWords = 2 * n + nb + 1 + 6;                     // counts, offsets, sums, two 64-bit words (total, largest rectangle)
     if (scratchWords > c->plScratchCap) {
         (void)hipFree(c->dPlScratch); c->dPlScratch = nullptr; c->plScratchCap = 0;
         if ((e = hipMalloc(&c->dPlScratch, scratchWords * sizeof(uint32_t) + 8)) != hipSuccess) return oom(e, "hipMalloc");
@@ -440,17 +440,20 @@ int build_plists(dxv_ctx* c, hipStream_t stream)
     uint32_t* counts = c->dPlScratch;
     uint32_t* offsets = counts + n;
     uint32_t* sums = offsets + n;
-    unsigned long long* dTotal = reinterpret_cast<unsigned long long*>(c->dPlScratch + ((2 * n + nb + 1 + 1) & ~(size_t)1));
-    unsigned long long total = 0;
-    const unsigned long long cap = 24ull * T + (8ull << 20);
+    unsigned long long* dTotal = reinterpret_cast<unsigned long long*>(c->dPlScratch + ((2 * n + nb + 1 + 1) & ~(size_t)1));     // two words
+    unsigned long long tot[2] = {0, 0};
+    const unsigned long long cap = 24ull * T + (8ull << 20), rectCap = 16384;    // (a thread of the fill walks its triangle's rectangle alone)
     for (;;) {
         if ((e = parity_lists_total(scene_tripos(c), T, R, dTotal, stream)) != hipSuccess) return oom(e, "parity_lists_total");
-        if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return oom(e, "hipMemcpyAsync");
+        if ((e = hipMemcpyAsync(tot, dTotal, sizeof(tot), hipMemcpyDeviceToHost, stream)) != hipSuccess) return oom(e, "hipMemcpyAsync");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return oom(e, "hipStreamSynchronize");
-        // the finest grid that fits the cap: a finer grid has more entries but shorter lists (fewer false candidates per row)
-        if (total <= cap || c->optPlistRes || R <= 256u) break;
+        // the finest grid that fits the caps: a finer grid has more entries but shorter lists (fewer false candidates per row)
+        if ((tot[0] <= cap && tot[1] <= rectCap) || R <= 256u) break;
+        if (c->optPlistRes) break;
         R >>= 1;
     }
+    const unsigned long long total = tot[0];
+    if (tot[1] > rectCap) { c->plEntries = 0; return done(-1); }       // a triangle facing the rays covers the plane: the tree walk stays
     // over the cap even on the coarsest grid, or deep in every row (soups: hundreds of triangles behind one another -- the
     // row's work is the triangles themselves, and a coarse grid only adds false candidates to them): the tree walk stays
     if (total > cap || total > 0x7ffffff0ull || (double)total > 256.0 * (double)R * (double)R) { c->plEntries = 0; return done(-1); }

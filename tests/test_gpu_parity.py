@@ -919,9 +919,22 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
     b = v.Grid().copy()
     v.Voxelize(64, dxv.MODE_PARITY)
     assert v.stats()["list_entries"] > 0 and np.array_equal(v.Grid(), b)
+    # a wall facing the rays covers the whole (y, z) plane: one thread of the fill would walk millions of texels -- the tree stays
+    vb, ib, _ = dragon
+    lo, hi = vb[:, :3].min(0), vb[:, :3].max(0)
+    wall = np.array([[hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [hi[0], hi[1], hi[2]], [hi[0], lo[1], hi[2]]], np.float32)
+    wvb = np.concatenate([vb, np.hstack([wall, np.tile(np.array([[1, 0, 0]], np.float32), (4, 1))])]).astype(np.float32)
+    n0 = len(vb)
+    wib = np.concatenate([ib, np.array([n0, n0 + 1, n0 + 2, n0, n0 + 2, n0 + 3], np.uint32)])
+    v.set_option("plists", 2)
+    v.InitFromArrays(wvb, wib)
+    v.Voxelize(64, dxv.MODE_PARITY)
+    assert v.stats()["list_entries"] == 0
+    assert np.array_equal(v.Grid(), orc.Scene(wvb, wib).voxelize(64, mode=1))
     # adversarial meshes
     rng = np.random.default_rng(515)
     v.set_option("plists", 2)
+    v.set_option("plistres", 64)                                         # (on the automatic grids their rectangles are over the cap)
     served = 0
     for n_tris, L, N in ((1, 8, 16), (7, 8, 32), (200, 16, 64), (30, 32, 96), (1500, 32, 64)):
         vb, ib = lattice_mesh(rng, n_tris, L)
@@ -930,5 +943,5 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
         v.Voxelize(N, dxv.MODE_PARITY)
         served += v.stats()["list_entries"] > 0
         assert np.array_equal(v.Grid(), want), (n_tris, L, N)
-    assert served >= 2
+    assert served >= 4
     v.close()
