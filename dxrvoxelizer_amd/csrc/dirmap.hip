@@ -267,14 +267,16 @@ DXV_HD void pl_rect(const TriPos& tp, uint32_t R, uint32_t& j0, uint32_t& j1, ui
 }
 __global__ __launch_bounds__(kThreads) void k_pl_total(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R, unsigned long long* __restrict__ total)
 {
-    const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
-    unsigned long long n = 0;
-    if (t < T) {
+    // grid-stride: a few thousand waves, one pair of atomics each (one per wave of a 1 M-triangle launch on two addresses
+    // was 0.3 ms of contention)
+    unsigned long long n = 0, m = 0;                                   // entries; the largest rectangle of one triangle (a thread's loop in the fill)
+    for (uint32_t t = blockIdx.x * kThreads + threadIdx.x; t < T; t += gridDim.x * kThreads) {
         uint32_t j0, j1, k0, k1;
         pl_rect(triPos[t], R, j0, j1, k0, k1);
-        n = (unsigned long long)(j1 - j0 + 1u) * (k1 - k0 + 1u);
+        const unsigned long long r = (unsigned long long)(j1 - j0 + 1u) * (k1 - k0 + 1u);
+        n += r;
+        if (r > m) m = r;
     }
-    unsigned long long m = n;                                          // total[1]: the largest rectangle of one triangle (a thread's loop)
     for (int off = 32; off; off >>= 1) { n += __shfl_down(n, off); const unsigned long long o = __shfl_down(m, off); if (o > m) m = o; }
     if ((threadIdx.x & 63u) == 0u && n) { atomicAdd(total, n); atomicMax(total + 1, m); }
 }
@@ -287,11 +289,13 @@ __global__ __launch_bounds__(kThreads) void k_pl_scatter(const TriPos* __restric
     if (t >= T) return;
     uint32_t j0, j1, k0, k1;
     pl_rect(triPos[t], R, j0, j1, k0, k1);
-    for (uint32_t k = k0; k <= k1; ++k)
-        for (uint32_t j = j0; j <= j1; ++j) {
+    for (uint32_t k = k0; k <= k1; ++k) {
+#pragma unroll 4
+        for (uint32_t j = j0; j <= j1; ++j) {                           // (independent atomics: several in flight)
             const uint32_t c = k * R + j, slot = atomicAdd(counts + c, 1u);
             if (FILL) entries[begin[c] + slot] = t;
         }
+    }
 }
 __global__ __launch_bounds__(kThreads) void k_pl_cells(const uint32_t* __restrict__ begin, const uint32_t* __restrict__ counts, uint32_t n, uint32_t* __restrict__ cells)
 {
@@ -360,7 +364,8 @@ hipError_t parity_lists_total(const TriPos* triPos, uint32_t T, uint32_t R, unsi
 {
     hipError_t e = hipMemsetAsync(total, 0, 2 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    k_pl_total<<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, total);
+    const uint32_t blocks = (T + kThreads - 1) / kThreads;
+    k_pl_total<<<blocks < 512u ? blocks : 512u, kThreads, 0, s>>>(triPos, T, R, total);
     return hipGetLastError();
 }
 hipError_t parity_lists_fill(const TriPos* triPos, uint32_t T, uint32_t R, uint32_t* counts, uint32_t* offsets, uint32_t* sums, uint32_t* cells,
