@@ -259,12 +259,6 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
 // takes the exact per-row test, and the order inside a list cannot matter to a count: the lists are filled through atomic
 // cursors, without a sort.  Texels are a monotone function of the coordinate (dm_texel), the same on both sides.
 // ---------------------------------------------------------------------------------------------
-DXV_HD void pl_rect(const TriPos& tp, uint32_t R, uint32_t& j0, uint32_t& j1, uint32_t& k0, uint32_t& k1)
-{
-    float lo[3], hi[3];
-    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);                              // the canonical padded box parity_row_setup tests
-    j0 = dm_texel(lo[1], R); j1 = dm_texel(hi[1], R); k0 = dm_texel(lo[2], R); k1 = dm_texel(hi[2], R);
-}
 __global__ __launch_bounds__(kThreads) void k_pl_total(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R, unsigned long long* __restrict__ total)
 {
     // grid-stride: a few thousand waves, one pair of atomics each (one per wave of a 1 M-triangle launch on two addresses

@@ -574,6 +574,16 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     }
 }
 
+// Row lists of the parity rule (dirmap.hip): the texels of the R x R grid over the (y, z) plane that a triangle's padded box --
+// the box parity_row_setup tests a row against -- reaches; a row's texel is (dm_texel(oy), dm_texel(oz)), monotone in the
+// coordinate, so a row inside the box lies in a texel of the rectangle.
+DXV_HD void pl_rect(const TriPos& tp, uint32_t R, uint32_t& j0, uint32_t& j1, uint32_t& k0, uint32_t& k1)
+{
+    float lo[3], hi[3];
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+    j0 = dm_texel(lo[1], R); j1 = dm_texel(hi[1], R); k0 = dm_texel(lo[2], R); k1 = dm_texel(hi[2], R);
+}
+
 template <class Stack, int ABL>
 DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best, float& bestDet)
 {

@@ -33,6 +33,8 @@ struct HcScene {
     uint32_t height = 0;
     std::vector<DirCell> dmCells;          // direction-space lists (hc_dirmap_build)
     std::vector<DirEntry> dmEntries;
+    std::vector<uint32_t> plBegin, plEntries;   // row lists of the parity rule (CSR over R x R texels)
+    uint32_t plR = 0;
     uint32_t dmR = 0;
 };
 
@@ -183,6 +185,28 @@ __attribute__((visibility("default"))) uint32_t hc_normal_class(const float* tri
                         F4{nrm[0], nrm[1], nrm[2], 0}, F4{nrm[3], nrm[4], nrm[5], 0}, F4{nrm[6], nrm[7], nrm[8], 0});
 }
 __attribute__((visibility("default"))) void hc_scene_tripos(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->triPos.data(), s->triPos.size() * sizeof(TriPos)); }
+// Row lists of the parity rule built on the host with the product's pl_rect; returns the number of entries.
+__attribute__((visibility("default"))) uint64_t hc_plists_build(void* p, uint32_t R)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    std::vector<uint32_t> count((size_t)R * R + 1, 0);
+    for (uint32_t t = 0; t < s->T; ++t) {
+        uint32_t j0, j1, k0, k1;
+        pl_rect(s->triPos[t], R, j0, j1, k0, k1);
+        for (uint32_t k = k0; k <= k1; ++k) for (uint32_t j = j0; j <= j1; ++j) count[(size_t)k * R + j + 1]++;
+    }
+    for (size_t c = 0; c < (size_t)R * R; ++c) count[c + 1] += count[c];
+    s->plBegin = count;
+    s->plEntries.assign(count.back(), 0);
+    std::vector<uint32_t> cur(count.begin(), count.end() - 1);
+    for (uint32_t t = s->T; t-- > 0u;) {                               // (any order inside a list: this one is the reverse of the device's usual)
+        uint32_t j0, j1, k0, k1;
+        pl_rect(s->triPos[t], R, j0, j1, k0, k1);
+        for (uint32_t k = k0; k <= k1; ++k) for (uint32_t j = j0; j <= j1; ++j) s->plEntries[cur[(size_t)k * R + j]++] = t;
+    }
+    s->plR = R;
+    return s->plEntries.size();
+}
 // Debug aid: every entry of the texel of voxel (ix, iy, iz)'s ray, with the outcome of each test of the scan.
 __attribute__((visibility("default"))) void hc_dirmap_debug(void* p, uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, uint32_t wantK)
 {
@@ -270,6 +294,29 @@ __attribute__((visibility("default"))) int hc_voxelize(void* p, uint32_t N, int 
             }
             for (uint32_t r = 0; r < RB * RB; ++r)
                 for (uint32_t ix = 0; ix < N; ++ix) out[((size_t)lz[r / RB] * N + iy[r % RB]) * N + ix] = (uint8_t)(cnt[(size_t)r * N + ix] & 1u);
+        }
+        return 0;
+    }
+    if (mode == 13) {                              // parity through the row lists (what k_parity_rows<.., LISTS> computes): one texel per row
+        if (!s->plR) return -1;
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int64_t row = 0; row < (int64_t)nz * N; ++row) {
+            const uint32_t lz = (uint32_t)(row / N), iy = (uint32_t)(row % N);
+            float ox0, oy, oz, t0, t1;
+            ray_origin(N, 0, iy, z0 + lz, ox0, oy, oz);
+            const size_t cell = (size_t)dm_texel(oz, s->plR) * s->plR + dm_texel(oy, s->plR);
+            std::vector<uint32_t> cnt(N, 0);
+            for (uint32_t e = s->plBegin[cell]; e < s->plBegin[cell + 1]; ++e) {
+                const TriPos& tp = s->triPos[s->plEntries[e]];
+                const ParityRowTri ps = parity_row_setup(oy, oz, tp.v0, tp.v1, tp.v2);
+                if (!ps.hit) continue;
+                for (uint32_t ix = 0; ix < N; ++ix) {
+                    float ox;
+                    ray_origin(N, ix, iy, z0 + lz, ox, t0, t1);
+                    cnt[ix] += parity_row_voxel(ps, ox) ? 1u : 0u;
+                }
+            }
+            for (uint32_t ix = 0; ix < N; ++ix) out[((size_t)lz * N + iy) * N + ix] = (uint8_t)(cnt[ix] & 1u);
         }
         return 0;
     }

@@ -383,3 +383,34 @@ def test_normal_class_agrees_with_the_predicate_everywhere_on_the_triangle(hostc
         L.hc_scene_tripos(h.h, tp.ctypes.data_as(C.c_void_p))
         cls = tp[:, 7].view(np.uint32) >> 28
         assert set(np.unique(cls)) <= {0, 2, 3} and (cls != 0).mean() > 0.7, (cls != 0).mean()   # bunny 0.9, dragon 0.76
+
+
+def test_parity_row_lists_give_the_oracle_grid(orc, hostcheck, bunny):
+    """The parity rule through row lists of the (y, z) plane (pl_rect, dxv_dirmap.h; the device builder and kernel: dirmap.hip,
+    k_parity_rows<.., LISTS>): every triangle whose padded box covers a row's point is in the row's texel, once -- so counting
+    over the list equals counting over all triangles.  Host replay against the oracle on the bunny and on lattice-snapped
+    adversarial meshes (box edges ON texel borders and row coordinates), coarse and fine grids."""
+    import ctypes as C
+    from test_fuzz import lattice_mesh
+    L = hostcheck.lib
+    L.hc_plists_build.argtypes = [C.c_void_p, C.c_uint32]
+    L.hc_plists_build.restype = C.c_uint64
+    vb, ib, _ = bunny
+    s = orc.Scene(vb, ib)
+    h = hostcheck(vb, ib, s.bound)
+    want = s.voxelize(64, mode=1)
+    for R in (64, 512):
+        n = L.hc_plists_build(h.h, R)
+        assert n >= h.T
+        got, _ = h.voxelize(64, mode=13)
+        assert np.array_equal(got, want), R
+    rng = np.random.default_rng(77)
+    for n_tris, Lt, N in ((1, 8, 16), (3, 8, 8), (30, 16, 32), (200, 32, 32), (60, 16, 48)):
+        vb, ib = lattice_mesh(rng, n_tris, Lt)
+        s = orc.Scene(vb, ib)
+        h = hostcheck(vb, ib, s.bound)
+        want = s.voxelize(N, mode=1, algo=orc.ALGO_BRUTE)
+        for R in (16, 32, 256):                                    # 16, 32: texel borders coincide with lattice coordinates
+            L.hc_plists_build(h.h, R)
+            got, _ = h.voxelize(N, mode=13)
+            assert np.array_equal(got, want), (n_tris, Lt, N, R)
