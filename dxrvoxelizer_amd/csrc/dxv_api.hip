@@ -528,7 +528,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         }
     }
     f.stack_entries = (uint32_t)st;
-    if (p.mode == DXV_MODE_PARITY && c->optRows) {
+    if (p.mode == DXV_MODE_PARITY && c->optRows && !c->optRowBlock) {
         // parity rule: row lists from the scene's second parity launch on (their build, two passes of atomic additions per
         // entry, costs 2 ms at 1 M triangles -- as much as three launches through the tree at 512^3, five with what the lists
         // save: a mesh refitted every frame stays on the tree); plists = 2: from the first
@@ -563,6 +563,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         if (voxels > 1.5f && waves(4) >= 12288u) rowBlock = 4;
         else if (voxels > 1.2f && waves(2) >= 12288u) rowBlock = 2;
         if (c->optRowBlock) rowBlock = c->optRowBlock;
+        if (p.scene.plCells) rowBlock = 1;                             // row lists: one row per wave
         f.row_block = (uint32_t)rowBlock;
         DXV_HIP(c, launch_parity_rows(p, rowBlock, fs));
         f.lastRedoParity = -1;

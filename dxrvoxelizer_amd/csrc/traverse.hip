@@ -251,8 +251,8 @@ struct WaveStack {
 // might cross) -- the launcher decides by the mean triangle extent.
 // WIDE: the walk takes the four-box nodes (Node64) -- half as many dependent scalar fetches, which is
 // what the walk waits on (triangle arithmetic is 6 % of the kernel).
-// LISTS: the candidates of a row (of the RB x RB rows) come from the row lists of the parity rule (dirmap.hip) -- a cell, then
-// the triangles of its list four at a time -- instead of from a walk of the tree.
+// LISTS (RB = 1): the candidates of a row come from the row lists of the parity rule (dirmap.hip) -- one cell, then the
+// triangles of its list four at a time -- instead of from a walk of the tree.
 template <int CH, int RB, bool WIDE, bool LISTS = false>
 __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizeParams p)   // <= 64 / 80 VGPRs
 {
@@ -363,38 +363,22 @@ __global__ __launch_bounds__(64, RB == 1 ? 8 : 6) void k_parity_rows(VoxelizePar
             return (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, m));
         };
         if (LISTS) {
-            // The texels the block's rows fall into: one for a single row, up to a few for RB x RB rows.  A triangle whose box
-            // reaches several of them is in each one's list; it is taken at the first texel of the block's range that its own
-            // rectangle (pl_rect, recomputed from the record) covers, and skipped at the others: once per block, as in the walk.
+            static_assert(!LISTS || RB == 1, "row lists: one row per wave");
             const uint32_t R = sc.plR;
-            const uint32_t tj0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dm_texel(ylo, R)), tj1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dm_texel(yhi, R));
-            const uint32_t tk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dm_texel(zlo, R)), tk1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)dm_texel(zhi, R));
-            const bool several = RB > 1 && (tj0 != tj1 || tk0 != tk1);
-            for (uint32_t tk = tk0; tk <= tk1; ++tk)
-                for (uint32_t tj = tj0; tj <= tj1; ++tj) {
-                    const uint32_t cell = tk * R + tj;
-                    const uint32_t begin = sc.plCells[2u * cell], count = sc.plCells[2u * cell + 1u];
-                    const uint32_t* list = sc.plEntries + begin;
-                    auto mine = [&](const TriPos& tp) {
-                        if (!several) return true;
-                        uint32_t j0, j1, k0, k1;
-                        pl_rect(tp, R, j0, j1, k0, k1);
-                        const uint32_t oj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(j0 > tj0 ? j0 : tj0));
-                        const uint32_t ok = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k0 > tk0 ? k0 : tk0));
-                        return oj == tj && ok == tk;
-                    };
-                    for (uint32_t k = 0; k < count; k += 4u) {
-                        // four triangle records in flight (the words behind the end of a list are the next list's or the buffer's
-                        // spare ones: valid slots either way, fetched and not used)
-                        const uint32_t s0 = list[k], s1 = list[k + 1u], s2 = list[k + 2u], s3 = list[k + 3u];
-                        const TriPos t0 = load_tri(sc.triPos, (int32_t)s0), t1 = load_tri(sc.triPos, (int32_t)s1);
-                        const TriPos t2 = load_tri(sc.triPos, (int32_t)s2), t3 = load_tri(sc.triPos, (int32_t)s3);
-                        if (mine(t0)) triangle(t0);
-                        if (k + 1u < count && mine(t1)) triangle(t1);
-                        if (k + 2u < count && mine(t2)) triangle(t2);
-                        if (k + 3u < count && mine(t3)) triangle(t3);
-                    }
-                }
+            const uint32_t cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dm_texel(oz[0], R) * R + dm_texel(oy[0], R)));
+            const uint32_t begin = sc.plCells[2u * cell], count = sc.plCells[2u * cell + 1u];
+            const uint32_t* list = sc.plEntries + begin;
+            for (uint32_t k = 0; k < count; k += 4u) {
+                // four triangle records in flight (the words behind the end of a list are the next list's or the buffer's
+                // spare ones: valid slots either way, fetched and not used)
+                const uint32_t s0 = list[k], s1 = list[k + 1u], s2 = list[k + 2u], s3 = list[k + 3u];
+                const TriPos t0 = load_tri(sc.triPos, (int32_t)s0), t1 = load_tri(sc.triPos, (int32_t)s1);
+                const TriPos t2 = load_tri(sc.triPos, (int32_t)s2), t3 = load_tri(sc.triPos, (int32_t)s3);
+                triangle(t0);
+                if (k + 1u < count) triangle(t1);
+                if (k + 2u < count) triangle(t2);
+                if (k + 3u < count) triangle(t3);
+            }
         } else if (WIDE) {
             walk_parity_rows_wide(
                 [&](int32_t i) {
@@ -458,22 +442,23 @@ static hipError_t launch_parity_rows_ch(const VoxelizeParams& pin, hipStream_t s
     return hipGetLastError();
 }
 
-template <int RB, bool WIDE, bool LISTS = false>
+template <int RB, bool WIDE>
 static hipError_t launch_parity_rows_rb(const VoxelizeParams& p, hipStream_t s)
 {
-    if (p.N <= 64) return launch_parity_rows_ch<1, RB, WIDE, LISTS>(p, s);
-    if (p.N <= 128) return launch_parity_rows_ch<2, RB, WIDE, LISTS>(p, s);
-    if (p.N <= 256) return launch_parity_rows_ch<4, RB, WIDE, LISTS>(p, s);
-    return launch_parity_rows_ch<8, RB, WIDE, LISTS>(p, s);    // 512 voxels per wave; longer rows take several waves
+    if (p.N <= 64) return launch_parity_rows_ch<1, RB, WIDE>(p, s);
+    if (p.N <= 128) return launch_parity_rows_ch<2, RB, WIDE>(p, s);
+    if (p.N <= 256) return launch_parity_rows_ch<4, RB, WIDE>(p, s);
+    return launch_parity_rows_ch<8, RB, WIDE>(p, s);    // 512 voxels per wave; longer rows take several waves
 }
 
 // rowBlock: rows per side of a wave's block of rows (1, 2 or 4); the walk takes the four-box nodes when the scene has them
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s)
 {
-    if (p.scene.plCells) {                                             // row lists: no walk
-        if (rowBlock == 4) return launch_parity_rows_rb<4, false, true>(p, s);
-        if (rowBlock == 2) return launch_parity_rows_rb<2, false, true>(p, s);
-        return launch_parity_rows_rb<1, false, true>(p, s);
+    if (p.scene.plCells) {                                             // row lists: one row per wave, no walk
+        if (p.N <= 64) return launch_parity_rows_ch<1, 1, false, true>(p, s);
+        if (p.N <= 128) return launch_parity_rows_ch<2, 1, false, true>(p, s);
+        if (p.N <= 256) return launch_parity_rows_ch<4, 1, false, true>(p, s);
+        return launch_parity_rows_ch<8, 1, false, true>(p, s);
     }
     if (p.scene.wide) {
         if (rowBlock == 4) return launch_parity_rows_rb<4, true>(p, s);

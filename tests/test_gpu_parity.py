@@ -681,12 +681,10 @@ def test_parity_row_blocks_equal_single_rows(vox, orc, request, name, wide):
     s = orc.Scene(vb, ib)
     want = s.voxelize(64, mode=1)
     try:
-      for plists in (0, 2):                               # candidates from the walk over the tree / from the row lists (a block's rows span texels)
-        vox.set_option("plists", plists)
         for rowblock in (1, 2, 4):
             vox.set_option("rowblock", rowblock)
             vox.Voxelize(64, 1)
-            assert vox.stats()["row_block"] == rowblock and (vox.stats()["list_entries"] > 0) == (plists == 2)
+            assert vox.stats()["row_block"] == rowblock
             assert np.array_equal(vox.Grid(), want), rowblock
             for z0, nz in ((0, 1), (5, 3), (17, 7), (62, 2), (31, 33)):
                 vox.Voxelize(64, 1, z0, nz)
@@ -703,7 +701,6 @@ def test_parity_row_blocks_equal_single_rows(vox, orc, request, name, wide):
         assert np.array_equal(vox.Grid(), want)
     finally:
         vox.set_option("rowblock", 0)
-        vox.set_option("plists", 1)
         vox.set_option("wide", 2)
 
 
@@ -887,7 +884,7 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
             v.set_option("plists", 2)
             v.Voxelize(N, dxv.MODE_PARITY)
             st = v.stats()
-            assert st["list_entries"] > 0 and np.array_equal(v.Grid(), want), N
+            assert st["list_entries"] > 0 and st["row_block"] == 1 and np.array_equal(v.Grid(), want), N
             v.set_option("plists", 0)
             v.Voxelize(N, dxv.MODE_PARITY)
             assert v.stats()["list_entries"] == 0 and np.array_equal(v.Grid(), want), N

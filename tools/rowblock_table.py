@@ -17,7 +17,6 @@ for mesh in sys.argv[1:] or ["bunny", "dragon", "dragon9", "torus1m", "bunny16"]
     for N in (128, 256, 512, 1024):
         ms = {}
         for rb in (1, 2, 4, 0):
-            v.set_option("plists", 0)                  # the walk over the tree (the row lists have their own table: tools/ab_option.py plists)
             v.set_option("rowblock", rb)
             v.Voxelize(N, dxv.MODE_PARITY)
             t = []
