@@ -202,12 +202,12 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   refit  0|1|2  box merge of dxv_build and dxv_refit: min/max pyramid over the leaf order (1,
  *                 default), level sweeps (2), one atomic pass (0)
  *   lists  0|1|2  reference rule through direction-space lists (dxv_dirmap.h) or the tree walk (0).  The
- *                 lists are built from the scene's triangle records, 0.3-2.7 ms: at the second launch after
- *                 a build / refit / import, or at the first if that launch has 2^28 voxels or more (1, default: a
- *                 mesh refitted every frame stays on the tree walk where that is the faster of the two)
- *                 or at the first (2); scenes whose
- *                 lists would average more than 32 entries per texel, or exceed 256 entries per
- *                 triangle + 64 M, keep the tree walk (stats.list_entries = 0)
+ *                 lists are built from the scene's triangle records (0.65 ms at 1 M triangles): at the second
+ *                 launch after a build / refit / import, or at the first when that launch is large enough for
+ *                 the build to pay for itself at once -- 2^26 voxels or more and the estimate after the build's
+ *                 counting pass says so (1, default: a mesh refitted every frame takes whichever is faster), or
+ *                 always at the first (2); scenes whose lists would exceed 256 entries per triangle + 64 M or
+ *                 65,535 entries in one texel keep the tree walk (stats.list_entries = 0)
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
  *   plists 0|1|2    parity rule through row lists of the (y, z) plane: 1 (default) from a scene's second parity launch,
  *                 2 from the first, 0 = always walk the tree; plistres 0|16..4096: texels per side of their grid
