@@ -69,6 +69,7 @@ struct dxv_ctx {
         uint32_t lastZBlock = 1, lastZPeriod = 1;
         bool pending = false;            // a voxelize launch has not been checked by dxv_sync yet
         bool ready = false;              // status words, redo list, events and stream exist
+        uint64_t clearSig = 0;           // the partial launch whose memset this grid still carries (launch_shape, traverse.hip); 0 = none
         // launch fields of dxv_stats
         float voxelize_ms = 0.0f;
         uint32_t grid_dim = 0, z0 = 0, nz = 0, stack_entries = 0, redo_rays = 0, row_block = 0, list_entries = 0, list_res = 0;
@@ -489,6 +490,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
     memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
     p.grid = f.dGrid; p.texels = c->texels ? f.dTexels : nullptr; p.status = f.dStatus;
+    p.clearSig = &f.clearSig;
     p.redo = f.dRedo; p.redoCap = kRedoCap; p.redoParity = f.redoParity;
     p.N = f.grid_dim; p.z0 = f.z0; p.nz = f.nz; p.mode = f.lastMode;
     p.zBlock = f.lastZBlock; p.zPeriod = f.lastZPeriod;
@@ -565,6 +567,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         if (c->optRowBlock) rowBlock = c->optRowBlock;
         if (p.scene.plCells) rowBlock = 1;                             // row lists: one row per wave
         f.row_block = (uint32_t)rowBlock;
+        f.clearSig = 0;                                                // (the row kernel writes every voxel of the grid)
         DXV_HIP(c, launch_parity_rows(p, rowBlock, fs));
         f.lastRedoParity = -1;
     } else {
@@ -854,12 +857,14 @@ int voxelize_common(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nzLo
         (void)hipFree(f.dGrid); f.dGrid = nullptr; f.gridCap = 0;
         DXV_HIP(c, hipMalloc(&f.dGrid, align256(bytes)));
         f.gridCap = bytes;
+        f.clearSig = 0;
     }
     if (c->texels && bytes > f.texelCap) {
         DXV_HIP(c, hipStreamSynchronize(fs));
         (void)hipFree(f.dTexels); f.dTexels = nullptr; f.texelCap = 0;
         DXV_HIP(c, hipMalloc(&f.dTexels, align256(bytes * 4)));
         f.texelCap = bytes;
+        f.clearSig = 0;
     }
     f.gridBytes = bytes;
     f.grid_dim = N; f.z0 = z0; f.nz = nzLocal;
@@ -983,7 +988,12 @@ int dxv_render(dxv_ctx* c, const float eye[3], const float viewProj[16], const f
     return 0;
 }
 
-void* dxv_grid_device_ptr(dxv_ctx* c) { return c ? cur_frame(c).dGrid : nullptr; }
+void* dxv_grid_device_ptr(dxv_ctx* c)
+{
+    if (!c) return nullptr;
+    cur_frame(c).clearSig = 0;       // (the caller may write through the pointer: the next partial launch clears the grid again)
+    return cur_frame(c).dGrid;
+}
 size_t dxv_grid_bytes(const dxv_ctx* c) { return c ? c->frames[c->cur].gridBytes : 0; }
 
 int dxv_grid_download(dxv_ctx* c, uint8_t* host, size_t bytes)

@@ -78,6 +78,7 @@ struct VoxelizeParams {
     uint32_t subbox;        // 1: launch only bricks the root early-out cannot clear (default)
     uint32_t wide;          // 1: reference rule walks the wide nodes (default when the stack bound allows)
     uint32_t lists;         // 1: reference rule reads the direction-space lists of p.scene (no tree walk)
+    uint64_t* clearSig;     // host word of the frame (or NULL): signature of the partial launch whose memset the grid still carries -- the same launch again skips the memset
     uint32_t ablate;        // timing-only builds of the lists kernel (wrong grids; tools/ablate.py), 0 = the real kernel
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);

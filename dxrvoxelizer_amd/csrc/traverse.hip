@@ -535,11 +535,25 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
         b1[0] = tbx; b1[1] = tby; b1[2] = tbz;
     }
     const bool partial = !live || b0[0] || b0[1] || b0[2] || b1[0] != tbx || b1[1] != tby || b1[2] != tbz;
-    if (partial) {
+    // The memset of a partial launch (the whole grid: 134 MB, 35 us at 512^3) is still good when the frame's last writer was
+    // the same partial launch -- same grid, slab, partition, brick box, rule and buffers: the kernel only ever writes inside
+    // the box.  The frame's signature word says so; every other writer of the grid resets it (full launches here, the row
+    // kernel and reallocations in dxv_api.hip).
+    uint64_t sig = 0;
+    if (partial && live) {
+        auto mix = [&](uint64_t v) { sig = (sig ^ v) * 0x9E3779B97F4A7C15ull; sig ^= sig >> 29; };
+        mix(p.N); mix(p.nz); mix(p.z0); mix(p.zBlock); mix(p.zPeriod); mix((uint64_t)p.mode);
+        for (int a = 0; a < 3; ++a) { mix(b0[a]); mix(b1[a]); }
+        mix((uint64_t)B::x | ((uint64_t)B::y << 16) | ((uint64_t)B::z << 32));
+        mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels));
+        sig |= 1ull;                                                    // never 0 (= no valid memset)
+    }
+    if (partial && !(p.clearSig && sig && *p.clearSig == sig)) {
         hipError_t e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s);
         if (e != hipSuccess) return e;
         if (p.texels && (e = hipMemsetAsync(p.texels, 0, (size_t)p.N * p.N * p.nz * 4, s)) != hipSuccess) return e;
     }
+    if (p.clearSig) *p.clearSig = sig;                                  // (0 after a full launch or an all-empty grid)
     if (!live) return hipSuccess;
     const uint32_t nbx = b1[0] - b0[0], nby = b1[1] - b0[1], nbz = b1[2] - b0[2];
     p.nbx = nbx; p.nby = nby; p.nbz = nbz;

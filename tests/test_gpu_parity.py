@@ -98,12 +98,15 @@ def test_refit_variants_identical(dxv, request, mesh):
         for v in vs:
             v.InitFromArrays(vb, ib)
         want = vs[0].debug(DBG_NODES)
-        for v in vs[1:]:
-            assert np.array_equal(v.debug(DBG_NODES), want)
+        for refit, v in enumerate(vs[1:], 1):
+            got = v.debug(DBG_NODES)
+            assert np.array_equal(got, want), (mesh, "refit", refit, "differs from refit 0 in", int((got != want).sum()), "words, first rows",
+                                               np.argwhere((got != want).any(1))[:4].ravel().tolist())
             assert v.stats()["tree_height"] == vs[0].stats()["tree_height"]
-        for _ in range(3):                   # rebuilds are deterministic
+        for k in range(3):                   # rebuilds are deterministic
             vs[1].InitFromArrays(vb, ib)
-            assert np.array_equal(vs[1].debug(DBG_NODES), want)
+            got = vs[1].debug(DBG_NODES)
+            assert np.array_equal(got, want), (mesh, "rebuild", k, "differs in", int((got != want).sum()), "words")
     for v in vs:
         v.close()
 
