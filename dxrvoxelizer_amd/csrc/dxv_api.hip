@@ -169,7 +169,11 @@ int frame_prepare(dxv_ctx* c, uint32_t i)
     if (!f.ev1) DXV_HIP(c, hipEventCreate(&f.ev1));
     if (!f.dStatus) DXV_HIP(c, hipMalloc(&f.dStatus, 256));
     if (!f.dRedo) DXV_HIP(c, hipMalloc(&f.dRedo, sizeof(uint64_t) * kRedoCap));
-    DXV_HIP(c, hipMemset(f.dStatus, 0, 256));
+    // on the frame's own stream, and finished before anything reads the words: the streams are non-blocking, a memset on the
+    // null stream is not ordered with them (a fresh context whose status words landed on recycled memory could read
+    // 0x7ff out of them -- seen twice in some fifty runs of the GPU suite)
+    DXV_HIP(c, hipMemsetAsync(f.dStatus, 0, 256, frame_stream(c, i)));
+    DXV_HIP(c, hipStreamSynchronize(frame_stream(c, i)));
     f.ready = true;
     return 0;
 }
