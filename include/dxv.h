@@ -148,7 +148,9 @@ DXV_API int dxv_voxelize_interleaved_async(dxv_ctx* ctx, uint32_t grid_dim, int 
                                            uint32_t world, uint32_t zblock);
 
 /* Result access.  The grid stays resident on the device (the reference never reads it back,
- * it is consumed by the ray-cast pass on the GPU); download is for callers that want it. */
+ * it is consumed by the ray-cast pass on the GPU); download is for callers that want it.
+ * dxv_grid_device_ptr: the selected frame's grid after dxv_sync; the caller may also write through it (the library then
+ * clears the grid again before its next launch into that frame instead of relying on what it wrote there last). */
 DXV_API void* dxv_grid_device_ptr(dxv_ctx* ctx);
 DXV_API size_t dxv_grid_bytes(const dxv_ctx* ctx);
 DXV_API int dxv_grid_download(dxv_ctx* ctx, uint8_t* host, size_t bytes);
