@@ -948,3 +948,46 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
         assert np.array_equal(v.Grid(), want), (n_tris, L, N)
     assert served >= 4
     v.close()
+
+
+@pytest.mark.gpu
+def test_kept_memset_of_partial_launches(dxv, orc):
+    """A partial launch clears the whole grid and writes only the bricks around the scene's root box; the same launch again
+    relies on that memset still being there.  Every other writer of the frame's grid must make the next partial launch
+    clear it again: the row kernel of the parity rule (an open mesh -- a quad facing the rays -- leaves ones far outside the
+    box), a launch with another slab or grid size, the texel image switched on, a caller writing through
+    dxv_grid_device_ptr; and each frame keeps its own account."""
+    import ctypes as C
+    vb = np.array([[0.2, -0.3, -0.3, 1, 0, 0], [0.2, 0.3, -0.3, 1, 0, 0], [0.2, 0.3, 0.3, 1, 0, 0], [0.2, -0.3, 0.3, 1, 0, 0],
+                   [-1, -1, -1, 0, 0, 1], [1, 1, 1, 0, 0, 1]], np.float32)          # (two unreferenced vertices pin the bound)
+    ib = np.array([0, 1, 2, 0, 2, 3], np.uint32)
+    N = 256
+    s = orc.Scene(vb, ib)
+    ref, par = s.voxelize(N, mode=0), s.voxelize(N, mode=1)
+    assert int((par & (1 - ref))[:, :, : N // 2 - 8].sum()) > 100000          # parity ones far to the left of the quad's box
+    v = dxv.Voxelizer(0)
+    v.InitFromArrays(vb, ib)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    for lists in (2, 0):
+        v.set_option("lists", lists)
+        for frame in (0, 2):
+            v.SetFrame(frame)
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref)          # (the memset is skipped here)
+            v.Voxelize(N, dxv.MODE_PARITY); assert np.array_equal(v.Grid(), par)
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref), "stale parity voxels outside the box"
+            v.Voxelize(N, 0, 100, 40); assert np.array_equal(v.Grid(), ref[100:140])
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
+            v.Voxelize(128); assert np.array_equal(v.Grid(), s.voxelize(128))
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
+            v.Sync()
+            assert hip.hipMemset(C.c_void_p(v.grid_device_ptr()), 1, N ** 3) == 0 and hip.hipDeviceSynchronize() == 0
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref), "the caller's bytes outside the box"
+        v.SetFrame(0)
+        v.EnableTexels(True)
+        v.Voxelize(N)
+        assert np.array_equal(v.Grid(), ref) and np.array_equal(v.Texels(), s.voxelize(N, texels=True)[1])
+        v.EnableTexels(False)
+        v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
+    v.close()
