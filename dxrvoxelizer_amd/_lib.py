@@ -25,7 +25,7 @@ class Stats(C.Structure):
                 ("grid_dim", C.c_uint32), ("z0", C.c_uint32), ("nz", C.c_uint32),
                 ("stack_entries", C.c_uint32), ("render_ms", C.c_float), ("redo_rays", C.c_uint32),
                 ("row_block", C.c_uint32), ("tri_extent", C.c_float), ("list_entries", C.c_uint32), ("list_res", C.c_uint32),
-                ("list_ms", C.c_float)]
+                ("list_ms", C.c_float), ("plan_bricks", C.c_uint32), ("plan_waves", C.c_uint32), ("plan_ms", C.c_float)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("bound", "reserved")}
@@ -57,6 +57,7 @@ SYMBOLS = {
     "dxv_set_frame": (C.c_int, [C.c_void_p, C.c_uint32]),
     "dxv_sync_all": (C.c_int, [C.c_void_p]),
     "dxv_grid_device_ptr": (C.c_void_p, [C.c_void_p]),
+    "dxv_grid_device_ptr_ro": (C.c_void_p, [C.c_void_p]),
     "dxv_grid_bytes": (C.c_size_t, [C.c_void_p]),
     "dxv_grid_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dxv_grid_packed_bytes": (C.c_size_t, [C.c_void_p]),

@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 using namespace dxv;
 
@@ -71,9 +73,13 @@ struct dxv_ctx {
         bool lastCanFail = true;         // ... and it can report something (a walk's column can run out; the lists have no column)
         bool ready = false;              // status words, redo list, events and stream exist
         uint64_t clearSig = 0;           // the partial launch whose memset this grid still carries (launch_shape, traverse.hip); 0 = none
+        bool ptrExposed = false;         // dxv_grid_device_ptr handed this grid out for writing: the caller may write through the pointer at any
+                                         // time, so no memset is ever kept for it again (until the grid is reallocated)
         // launch fields of dxv_stats
         float voxelize_ms = 0.0f;
         uint32_t grid_dim = 0, z0 = 0, nz = 0, stack_entries = 0, redo_rays = 0, row_block = 0, list_entries = 0, list_res = 0;
+        uint32_t plan_bricks = 0, plan_waves = 0;
+        float plan_ms = 0.0f;
     };
     Frame frames[DXV_FRAME_COUNT];
     uint32_t cur = 0;                    // dxv_set_frame
@@ -96,6 +102,23 @@ struct dxv_ctx {
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
     uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
+    // dispatch plans of the lists kernel (traverse.hip: live bricks only, regions heaviest first, dealt to the XCDs by cost):
+    // one per partition launched against the current lists, built at the partition's second launch (option plan = 1) so
+    // that a mesh refitted every frame never pays for one
+    struct Plan {
+        bool used = false, valid = false;
+        uint64_t epoch = 0;              // listEpoch of the lists it was probed against
+        uint32_t N = 0, nz = 0, z0 = 0, zBlock = 0, zPeriod = 0;
+        uint32_t* dPlan = nullptr;
+        size_t cap = 0;
+        uint32_t count = 0, live = 0, bricks = 0, seen = 0;
+        uint64_t id = 0, lastUse = 0;
+        float ms = 0.0f;
+    };
+    static constexpr int kPlans = 8;
+    Plan plans[kPlans];
+    uint64_t listEpoch = 0, planClock = 0, planIds = 0;
+    int optPlan = 1;                 // 0 = no plans (brick box + Morton order), 1 = from a partition's second launch, 2 = from the first
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
     uint32_t* dPlCells = nullptr;
@@ -410,6 +433,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     c->listRes = R;
     c->listState = 1;
     c->listOpt = c->optListRes;
+    ++c->listEpoch;                                       // (dispatch plans probed against older lists are stale)
     return 0;
 }
 
@@ -486,6 +510,91 @@ int build_plists(dxv_ctx* c, hipStream_t stream)
     return done(1);
 }
 
+// The dispatch plan of this launch's partition against the current lists, or NULL (not yet worth one / none wanted / no
+// memory: the launch then takes the brick box in Morton order).  Builds it when due: one probe launch over the partition, a
+// few KB to the host, the regions placed by cost (LPT over the eight XCDs, heaviest first), one fill launch; synchronous on
+// the launching stream, once per (lists, partition).
+dxv_ctx::Plan* plan_for(dxv_ctx* c, const VoxelizeParams& p, hipStream_t stream, int& err)
+{
+    using Plan = dxv_ctx::Plan;
+    err = 0;
+    if (!c->optPlan) return nullptr;
+    Plan* pl = nullptr;
+    for (Plan& q : c->plans)
+        if (q.used && q.epoch == c->listEpoch && q.N == p.N && q.nz == p.nz && q.z0 == p.z0 && q.zBlock == p.zBlock && q.zPeriod == p.zPeriod) { pl = &q; break; }
+    if (!pl) {
+        pl = &c->plans[0];
+        for (Plan& q : c->plans) {
+            if (!q.used) { pl = &q; break; }
+            if (q.lastUse < pl->lastUse) pl = &q;
+        }
+        pl->used = true; pl->valid = false; pl->seen = 0;
+        pl->epoch = c->listEpoch; pl->N = p.N; pl->nz = p.nz; pl->z0 = p.z0; pl->zBlock = p.zBlock; pl->zPeriod = p.zPeriod;
+    }
+    pl->lastUse = ++c->planClock;
+    ++pl->seen;
+    if (pl->valid) return pl;
+    if (c->optPlan == 1 && pl->seen < 2) return nullptr;
+    // build
+    VoxelizeParams q = p;
+    const uint32_t nb = plan_layout(q), nr = plan_regions(nb);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    uint32_t* scratch = nullptr;
+    auto done = [&](hipError_t e, const char* what) -> Plan* {
+        if (t0) (void)hipEventDestroy(t0);
+        if (t1) (void)hipEventDestroy(t1);
+        (void)hipFree(scratch);
+        if (e == hipSuccess) return pl;
+        pl->valid = false;
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); pl->seen = 0; return nullptr; }   // no plan: the plain launch still works
+        err = fail(c, "dispatch plan: %s failed: %s", what, hipGetErrorString(e));
+        return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&scratch, sizeof(uint32_t) * ((size_t)nb + 4 * (size_t)nr))) != hipSuccess) return done(e, "hipMalloc");
+    uint32_t *cost = scratch, *regionCost = scratch + nb, *regionLive = regionCost + nr, *regionDst = regionLive + nr;
+    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, stream);
+    if ((e = plan_probe(p, cost, regionCost, regionLive, stream)) != hipSuccess) return done(e, "plan_probe");
+    std::vector<uint32_t> host(2 * (size_t)nr), dst(2 * (size_t)nr, 0u);
+    if ((e = hipMemcpyAsync(host.data(), regionCost, sizeof(uint32_t) * 2 * (size_t)nr, hipMemcpyDeviceToHost, stream)) != hipSuccess) return done(e, "hipMemcpyAsync");
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e, "hipStreamSynchronize");
+    std::vector<uint32_t> order;
+    order.reserve(nr);
+    for (uint32_t r = 0; r < nr; ++r) if (host[nr + r]) order.push_back(r);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return host[a] > host[b]; });
+    uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t len[8] = {0, 0, 0, 0, 0, 0, 0, 0}, live = 0;
+    for (uint32_t r : order) {
+        int x = 0;
+        for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+        dst[2 * r] = (uint32_t)x; dst[2 * r + 1] = len[x];
+        len[x] += host[nr + r]; load[x] += host[r];
+        live += host[nr + r];
+    }
+    uint32_t longest = 0;
+    for (int k = 0; k < 8; ++k) if (len[k] > longest) longest = len[k];
+    const uint32_t words = 8u * longest;
+    if ((size_t)words > pl->cap) {
+        // (another frame may still be running the plan this slot held before)
+        for (uint32_t i = 0; i < DXV_FRAME_COUNT; ++i)
+            if (c->frames[i].ready && (e = hipStreamSynchronize(frame_stream(c, i))) != hipSuccess) return done(e, "hipStreamSynchronize");
+        (void)hipFree(pl->dPlan); pl->dPlan = nullptr; pl->cap = 0;
+        if ((e = hipMalloc(&pl->dPlan, sizeof(uint32_t) * (size_t)(words ? words : 8u))) != hipSuccess) return done(e, "hipMalloc");
+        pl->cap = words ? words : 8u;
+    }
+    if (words) {
+        if ((e = hipMemcpyAsync(regionDst, dst.data(), sizeof(uint32_t) * 2 * (size_t)nr, hipMemcpyHostToDevice, stream)) != hipSuccess) return done(e, "hipMemcpyAsync");
+        if ((e = plan_fill(p, cost, regionDst, pl->dPlan, words, stream)) != hipSuccess) return done(e, "plan_fill");
+    }
+    if (t1) (void)hipEventRecord(t1, stream);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e, "hipStreamSynchronize");
+    pl->ms = t0 && t1 ? elapsed(t0, t1) : 0.0f;
+    pl->count = words; pl->live = live; pl->bricks = nb;
+    pl->id = ++c->planIds;
+    pl->valid = true;
+    return done(hipSuccess, "");
+}
+
 int launch_now(dxv_ctx* c, uint32_t frame)
 {
     Frame& f = c->frames[frame];
@@ -507,6 +616,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
     p.subbox = (uint32_t)c->optSubbox;
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     int st = c->optStack ? c->optStack : c->stackNow;
+    dxv_ctx::Plan* plan = nullptr;
     f.list_entries = 0; f.list_res = 0;
     // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
@@ -532,8 +642,15 @@ int launch_now(dxv_ctx* c, uint32_t frame)
             st = 16;                                                // no stack: the column is the queue of selected triangles (8 items of two words)
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
             f.list_entries = c->listEntries; f.list_res = c->listRes;
+            if (c->optBrick == 4 && !c->optAblate) {
+                int perr = 0;
+                plan = plan_for(c, p, fs, perr);
+                if (perr) return 1;
+            }
         }
     }
+    f.plan_bricks = plan ? plan->live : 0u; f.plan_waves = plan ? plan->count : 0u; f.plan_ms = plan ? plan->ms : 0.0f;
+    if (f.ptrExposed) p.clearSig = nullptr;                            // the caller may have written into the grid: clear it every time
     f.stack_entries = (uint32_t)st;
     f.lastCanFail = true;
     if (p.mode == DXV_MODE_PARITY && c->optRows && !c->optRowBlock) {
@@ -578,7 +695,10 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         DXV_HIP(c, launch_parity_rows(p, rowBlock, fs));
         f.lastRedoParity = -1;
     } else {
-        DXV_HIP(c, launch_voxelize(p, c->optBrick, st, fs));
+        if (plan) {
+            p.plan = plan->dPlan; p.planCount = plan->count;
+            DXV_HIP(c, launch_voxelize_planned(p, plan->id, fs));
+        } else DXV_HIP(c, launch_voxelize(p, c->optBrick, st, fs));
         if (p.lists) f.lastRedoParity = -1;                        // no column to run out of, nothing to redo
         else {
             DXV_HIP(c, launch_voxelize_redo(p, fs));
@@ -636,6 +756,7 @@ void dxv_destroy(dxv_ctx* c)
         if (f.ownStream) (void)hipStreamDestroy(f.ownStream);
     }
     free_scratch(c);
+    for (auto& pl : c->plans) (void)hipFree(pl.dPlan);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene);
     (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dPlCells); (void)hipFree(c->dPlEntries); (void)hipFree(c->dPlScratch); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
     (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
@@ -868,6 +989,7 @@ int voxelize_common(dxv_ctx* c, uint32_t N, int mode, uint32_t z0, uint32_t nzLo
         DXV_HIP(c, hipMalloc(&f.dGrid, align256(bytes)));
         f.gridCap = bytes;
         f.clearSig = 0;
+        f.ptrExposed = false;                                           // (pointers handed out before are dead)
     }
     if (c->texels && bytes > f.texelCap) {
         DXV_HIP(c, hipStreamSynchronize(fs));
@@ -1001,9 +1123,13 @@ int dxv_render(dxv_ctx* c, const float eye[3], const float viewProj[16], const f
 void* dxv_grid_device_ptr(dxv_ctx* c)
 {
     if (!c) return nullptr;
-    cur_frame(c).clearSig = 0;       // (the caller may write through the pointer: the next partial launch clears the grid again)
+    // the caller may write through the pointer now or at any later time (it stays valid until the grid is reallocated): from
+    // here on every launch into this frame clears the grid itself instead of trusting what it wrote there last
+    cur_frame(c).clearSig = 0;
+    cur_frame(c).ptrExposed = true;
     return cur_frame(c).dGrid;
 }
+const void* dxv_grid_device_ptr_ro(const dxv_ctx* c) { return c ? c->frames[c->cur].dGrid : nullptr; }
 size_t dxv_grid_bytes(const dxv_ctx* c) { return c ? c->frames[c->cur].gridBytes : 0; }
 
 int dxv_grid_download(dxv_ctx* c, uint8_t* host, size_t bytes)
@@ -1198,6 +1324,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     c->haveScene = true;
     if (withLists && (c->optListRes == 0 || (uint32_t)c->optListRes == listRes)) {   // (an explicit listres of another size: built here as asked)
         c->listEntries = listCount; c->listRes = listRes; c->listState = 1; c->listOpt = c->optListRes; c->listMs = 0.0f;
+        ++c->listEpoch;
     }
     c->stackNow = stack_round_up((int)(h.treeHeight + 3 < (uint32_t)c->optStack0 ? h.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_tris = h.numTris; c->stats.num_verts = h.numVerts; c->stats.num_nodes = h.numNodes;
@@ -1215,6 +1342,7 @@ int dxv_get_stats(const dxv_ctx* c, dxv_stats* out)
     out->voxelize_ms = f.voxelize_ms; out->grid_dim = f.grid_dim; out->z0 = f.z0; out->nz = f.nz;
     out->stack_entries = f.stack_entries; out->redo_rays = f.redo_rays; out->row_block = f.row_block;
     out->list_entries = f.list_entries; out->list_res = f.list_res; out->list_ms = f.lastMode == DXV_MODE_PARITY ? c->plMs : c->listMs;
+    out->plan_bricks = f.plan_bricks; out->plan_waves = f.plan_waves; out->plan_ms = f.plan_ms;
     return 0;
 }
 
@@ -1245,6 +1373,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "lists")) {
         if (value < 0 || value > 2) return fail(c, "option lists: %lld not in {0,1,2}", (long long)value);
         c->optLists = (int)value;
+    } else if (!strcmp(key, "plan")) {
+        if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
+        c->optPlan = (int)value;
     } else if (!strcmp(key, "plistres")) {
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option plistres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
         if (c->optPlistRes != (int)value) { if (sync_frames(c)) return 1; c->plState = 0; }     // the next parity launch rebuilds the row lists

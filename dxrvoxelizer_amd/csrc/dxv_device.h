@@ -80,8 +80,17 @@ struct VoxelizeParams {
     uint32_t lists;         // 1: reference rule reads the direction-space lists of p.scene (no tree walk)
     uint64_t* clearSig;     // host word of the frame (or NULL): signature of the partial launch whose memset the grid still carries -- the same launch again skips the memset
     uint32_t ablate;        // timing-only builds of the lists kernel (wrong grids; tools/ablate.py), 0 = the real kernel
+    const uint32_t* plan;   // dispatch plan of the lists kernel (traverse.hip): planCount words, one brick (or ~0) per workgroup
+    uint32_t planCount;
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
+// dispatch plan of the lists kernel with 4 x 4 x 4 bricks (traverse.hip): probe = per-brick cost (0 = no live ray) in the
+// partition's Morton order + cost and live bricks per region of 512; fill = the plan from the host's region placement
+uint32_t plan_layout(VoxelizeParams& p);           // fills the brick-order fields for the whole partition, returns its bricks
+uint32_t plan_regions(uint32_t bricks);
+hipError_t plan_probe(const VoxelizeParams& p, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s);
+hipError_t plan_fill(const VoxelizeParams& p, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s);
+hipError_t launch_voxelize_planned(const VoxelizeParams& p, uint64_t planId, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack
 int stack_round_up(int want);
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s);   // parity mode: one walk per row run (1) or per 2 x 2 rows (2)

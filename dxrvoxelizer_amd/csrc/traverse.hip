@@ -34,12 +34,41 @@ __device__ __forceinline__ uint32_t compact1by2(uint32_t x)
     return x;
 }
 
+// Brick at position `lin` of the launch order: Morton inside 2^m-brick super-blocks (m = p.mortonBits, the largest power
+// of two dividing all three brick counts), super-blocks linear; offset by the launch's brick box.
+__device__ __forceinline__ void brick_of_lin(const VoxelizeParams& p, uint32_t lin, uint32_t& bx, uint32_t& by, uint32_t& bz)
+{
+    const uint32_t m = p.mortonBits;
+    const uint32_t low = lin & ((1u << (3u * m)) - 1u), high = lin >> (3u * m);
+    bx = compact1by2(low); by = compact1by2(low >> 1); bz = compact1by2(low >> 2);
+    if (p.superX == 1u && p.superY == 1u) bz |= high << m;      // usual case (cubic power-of-two grid): no divisions
+    else {
+        bx |= (high % p.superX) << m;
+        by |= ((high / p.superX) % p.superY) << m;
+        bz |= (high / (p.superX * p.superY)) << m;
+    }
+    bx += p.bx0; by += p.by0; bz += p.bz0;
+}
+
 // WALK: 0 = leaves tested as met, 1 = postponed-leaf walk, 2 = the same over the wide nodes (MODE 0)
-template <class B, int STACK, int MODE, bool TEXELS, int WALK, int ABL = 0>
+// PLAN: the workgroup's brick comes from the launch's dispatch plan (k_plan_probe / k_plan_fill below): p.plan[blockIdx.x] =
+// bx | by << 10 | bz << 20, or ~0 for a slot that pads the shorter XCD sequences.
+template <class B, int STACK, int MODE, bool TEXELS, int WALK, int ABL = 0, bool PLAN = false>
 __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs (lists: the bound is 6, the kernel needs 62 and runs 8)
 {
     __shared__ int32_t stack[STACK * B::threads];
     const uint32_t N = p.N;
+    uint32_t bx, by, bz;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (PLAN) {
+        uint32_t w;                                                     // through the scalar cache: one word per wave
+        const uint32_t* slot = p.plan + blockIdx.x;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
+        if (w == 0xffffffffu) return;
+        bx = w & 1023u; by = (w >> 10) & 1023u; bz = w >> 20;
+    } else
+#endif
+    {
     const uint32_t nb = p.nbx * p.nby * p.nbz;
     // XCD-aware remap: workgroups b and b + 8 share an XCD.  Bricks are numbered along a Morton
     // curve (below); runs of 2^regionBits consecutive bricks (compact regions) are dealt round-robin
@@ -49,19 +78,9 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
     const uint32_t j = blockIdx.x >> 3;
     const uint32_t lin = ((((j >> rb) << 3) | (blockIdx.x & 7u)) << rb) | (j & ((1u << rb) - 1u));
     if (lin >= nb) return;
-    // brick order: Morton inside 2^m-brick super-blocks (m = p.mortonBits, the largest power of two
-    // dividing all three brick counts), super-blocks linear.  Consecutive workgroups of an XCD then
-    // cover a compact region and reuse the same part of the tree in L1/L2.
-    const uint32_t m = p.mortonBits;
-    const uint32_t low = lin & ((1u << (3u * m)) - 1u), high = lin >> (3u * m);
-    uint32_t bx = compact1by2(low), by = compact1by2(low >> 1), bz = compact1by2(low >> 2);
-    if (p.superX == 1u && p.superY == 1u) bz |= high << m;      // usual case (cubic power-of-two grid): no divisions
-    else {
-        bx |= (high % p.superX) << m;
-        by |= ((high / p.superX) % p.superY) << m;
-        bz |= (high / (p.superX * p.superY)) << m;
+    // Consecutive workgroups of an XCD cover a compact region and reuse the same part of the tree in L1/L2.
+    brick_of_lin(p, lin, bx, by, bz);
     }
-    bx += p.bx0; by += p.by0; bz += p.bz0;
     const uint32_t tid = threadIdx.x;
     const uint32_t ix = bx * B::x + tid % B::x;
     const uint32_t iy = by * B::y + (tid / B::x) % B::y;
@@ -88,6 +107,107 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
         else atomicOr(p.status, 1u);
     }
     p.grid[id] = occ;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dispatch plan of the lists kernel (4 x 4 x 4 bricks): WHICH bricks a launch runs and in WHAT order.
+//  * which: a ray that starts beyond the last entry of its texel (or whose texel is empty, or whose origin has left the
+//    root box) is a miss after one load -- on torus-1M four launched waves in ten held no other ray.  k_plan_probe makes
+//    exactly that decision (same functions, same floats as trace_reference_dm's first step) for every voxel of the
+//    partition once; bricks without a single live ray are not launched, their voxels are zero by the launch's memset;
+//  * in what order: regions of 512 consecutive bricks of the Morton order (8 x 8 x 8 bricks) are the unit; a region's cost
+//    is estimated from the list lengths of its live rays; the host deals the regions to the eight XCDs heaviest first
+//    onto the least loaded one (LPT), so that every XCD ends on its cheapest regions and the launch's tail -- what does
+//    not shrink when the grid is cut into eight ranks' shares -- is made of short waves.
+// The plan depends on the lists and on the partition (N, slab or block-cyclic set), not on the frame: dxv_api.hip keeps a
+// few per context and builds one when the same partition is launched a second time against the same lists.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kPlanRegionBits = 9u, kPlanRegion = 1u << kPlanRegionBits;
+
+__global__ __launch_bounds__(64) void k_plan_probe(VoxelizeParams p, uint32_t nb, uint32_t* __restrict__ cost,
+                                                   uint32_t* __restrict__ regionCost, uint32_t* __restrict__ regionLive)
+{
+    const uint32_t lin = blockIdx.x;
+    if (lin >= nb) return;
+    uint32_t bx, by, bz;
+    brick_of_lin(p, lin, bx, by, bz);
+    const uint32_t tid = threadIdx.x, N = p.N;
+    const uint32_t ix = bx * 4u + (tid & 3u), iy = by * 4u + ((tid >> 2) & 3u), lz = bz * 4u + (tid >> 4);
+    uint32_t c = 0;
+    if (ix < N && iy < N && lz < p.nz) {
+        const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
+        float ox, oy, oz;
+        ray_origin(N, ix, iy, iz, ox, oy, oz);
+        if (!origin_leaves_root(ox, oy, oz, p.scene.rootLo, p.scene.rootHi)) {
+            const DirMapView dm{static_cast<const DirCell*>(p.scene.dmCells), static_cast<const DirEntry*>(p.scene.dmEntries), p.scene.dmR};
+            uint32_t face, ti, tj, cx, cy;
+            float u, v, rho;
+            dm_ray_point(ox, oy, oz, face, u, v, rho);
+            dm_local(u, dm.R, ti, cx); dm_local(v, dm.R, tj, cy);
+            const DirCell cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
+            const float near = rho * 0.999f;                            // (trace_reference_dm: i = hi when the far radius of the texel's last entry < near)
+            if (cell.count != 0u && !(half_bits_to_float(cell.r1max) < near)) c = 8u + (cell.count < 120u ? cell.count : 120u);
+        }
+    }
+    for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
+    if (tid == 0u) {
+        cost[lin] = c;
+        if (c) { atomicAdd(regionCost + (lin >> kPlanRegionBits), c); atomicAdd(regionLive + (lin >> kPlanRegionBits), 1u); }
+    }
+}
+
+// regionDst[2 r] = XCD of region r, regionDst[2 r + 1] = position of its first live brick in that XCD's sequence
+__global__ __launch_bounds__(kPlanRegion) void k_plan_fill(VoxelizeParams p, uint32_t nb, const uint32_t* __restrict__ cost,
+                                                           const uint32_t* __restrict__ regionDst, uint32_t* __restrict__ plan)
+{
+    __shared__ uint32_t waveCount[kPlanRegion / 64u];
+    const uint32_t lin = blockIdx.x * kPlanRegion + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool live = lin < nb && cost[lin] != 0u;
+    const unsigned long long m = __ballot(live);
+    if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    if (!live) return;
+    uint32_t rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    for (uint32_t k = 0; k < w; ++k) rank += waveCount[k];
+    uint32_t bx, by, bz;
+    brick_of_lin(p, lin, bx, by, bz);
+    plan[(size_t)(regionDst[2u * blockIdx.x + 1u] + rank) * 8u + regionDst[2u * blockIdx.x]] = bx | (by << 10) | (bz << 20);
+}
+
+// the brick order of the whole partition (no brick box): what k_plan_probe, k_plan_fill and the host agree on
+uint32_t plan_layout(VoxelizeParams& p)
+{
+    const uint32_t nbx = (p.N + 3u) / 4u, nby = nbx, nbz = (p.nz + 3u) / 4u;
+    p.nbx = nbx; p.nby = nby; p.nbz = nbz;
+    p.bx0 = p.by0 = p.bz0 = 0;
+    uint32_t m = 0;
+    while (m < 10 && !((nbx >> m) & 1u) && !((nby >> m) & 1u) && !((nbz >> m) & 1u)) ++m;
+    p.mortonBits = m;
+    p.superX = nbx >> m;
+    p.superY = nby >> m;
+    return nbx * nby * nbz;
+}
+uint32_t plan_regions(uint32_t nb) { return (nb + kPlanRegion - 1u) / kPlanRegion; }
+
+hipError_t plan_probe(const VoxelizeParams& pin, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s)
+{
+    VoxelizeParams p = pin;
+    const uint32_t nb = plan_layout(p), nr = plan_regions(nb);
+    hipError_t e = hipMemsetAsync(regionCost, 0, sizeof(uint32_t) * nr, s);
+    if (e == hipSuccess) e = hipMemsetAsync(regionLive, 0, sizeof(uint32_t) * nr, s);
+    if (e != hipSuccess) return e;
+    k_plan_probe<<<dim3(nb), dim3(64), 0, s>>>(p, nb, cost, regionCost, regionLive);
+    return hipGetLastError();
+}
+
+hipError_t plan_fill(const VoxelizeParams& pin, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s)
+{
+    VoxelizeParams p = pin;
+    const uint32_t nb = plan_layout(p), nr = plan_regions(nb);
+    hipError_t e = hipMemsetAsync(plan, 0xff, sizeof(uint32_t) * (size_t)planWords, s);
+    if (e != hipSuccess) return e;
+    k_plan_fill<<<dim3(nr), dim3(kPlanRegion), 0, s>>>(p, nb, cost, regionDst, plan);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -642,6 +762,28 @@ hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEnt
     case 7: return launch_stack<Brick7>(p, stackEntries, s);
     default: return hipErrorInvalidValue;
     }
+}
+
+// Launch through a dispatch plan (above): the plan's bricks only, everything else is zero by the memset -- which the frame's
+// grid keeps while the same plan is launched into it again (the kernel writes the same set of bricks every time).
+hipError_t launch_voxelize_planned(const VoxelizeParams& p, uint64_t planId, hipStream_t s)
+{
+    uint64_t sig = 0;
+    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 0x9E3779B97F4A7C15ull; sig ^= sig >> 29; };
+    mix(0x706c616eull); mix(planId); mix(p.N); mix(p.nz); mix(p.z0); mix(p.zBlock); mix(p.zPeriod);
+    mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels));
+    sig |= 1ull;
+    if (!(p.clearSig && *p.clearSig == sig)) {
+        hipError_t e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s);
+        if (e != hipSuccess) return e;
+        if (p.texels && (e = hipMemsetAsync(p.texels, 0, (size_t)p.N * p.N * p.nz * 4, s)) != hipSuccess) return e;
+    }
+    if (p.clearSig) *p.clearSig = sig;
+    if (!p.planCount) return hipSuccess;                                // no live brick at all
+    const dim3 g(p.planCount), b(64);
+    if (p.texels) k_voxelize<Brick4, 16, 0, true, 4, 0, true><<<g, b, 0, s>>>(p);
+    else k_voxelize<Brick4, 16, 0, false, 4, 0, true><<<g, b, 0, s>>>(p);
+    return hipGetLastError();
 }
 
 // Solid-voxel count: 16 B per lane streaming reduction, one atomic per workgroup.

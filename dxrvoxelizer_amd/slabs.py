@@ -93,7 +93,7 @@ def device_grid_tensor(vox, device):
     """The context's device-resident grid of the last Voxelize as a torch uint8 tensor (no copy)."""
     import torch
 
-    return torch.as_tensor(_DeviceBuffer(vox.grid_device_ptr(), vox.grid_bytes()), device=device)
+    return torch.as_tensor(_DeviceBuffer(vox.grid_device_ptr(writable=False), vox.grid_bytes()), device=device)
 
 
 def allgather_grid(vox, dist, N, world, zblock, device):

@@ -171,8 +171,13 @@ class Voxelizer:
         self._check(self._lib.dxv_grid_count(self._ctx, C.byref(v)))
         return v.value
 
-    def grid_device_ptr(self):
-        return self._lib.dxv_grid_device_ptr(self._ctx)
+    def grid_device_ptr(self, writable=True):
+        """Device pointer of the selected frame's grid.  writable=True (dxv_grid_device_ptr) tells the library that the caller
+        may write through it at any later time: the frame's launches then clear the grid every time.  writable=False
+        (dxv_grid_device_ptr_ro) is for consumers that only read."""
+        if writable:
+            return self._lib.dxv_grid_device_ptr(self._ctx)
+        return self._lib.dxv_grid_device_ptr_ro(self._ctx)
 
     def grid_bytes(self):
         return self._lib.dxv_grid_bytes(self._ctx)

@@ -61,6 +61,9 @@ typedef struct dxv_stats {
     uint32_t list_entries;   /* reference rule: entries of the direction-space lists in use, 0 = tree walk */
     uint32_t list_res;       /* ... texels per cube-map face side                                   */
     float list_ms;           /* ... time of their build (first launch after a build / refit / import) */
+    uint32_t plan_bricks;    /* reference rule through a dispatch plan: bricks of 4^3 voxels with a live ray (0 = no plan) */
+    uint32_t plan_waves;     /* ... workgroups launched (the eight XCD sequences padded to the longest)               */
+    float plan_ms;           /* ... time of the plan's build (probe + placement + fill), once per (lists, partition)  */
 } dxv_stats;
 
 /* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that
@@ -149,9 +152,15 @@ DXV_API int dxv_voxelize_interleaved_async(dxv_ctx* ctx, uint32_t grid_dim, int 
 
 /* Result access.  The grid stays resident on the device (the reference never reads it back,
  * it is consumed by the ray-cast pass on the GPU); download is for callers that want it.
- * dxv_grid_device_ptr: the selected frame's grid after dxv_sync; the caller may also write through it (the library then
- * clears the grid again before its next launch into that frame instead of relying on what it wrote there last). */
+ * dxv_grid_device_ptr: the selected frame's grid after dxv_sync; the caller may also write through it, now or later
+ * (see dxv_grid_device_ptr_ro below for what that costs). */
 DXV_API void* dxv_grid_device_ptr(dxv_ctx* ctx);
+/* The same pointer for READING only (the consumer of the reference's grid SRV, Content/Voxelizer.cpp:371-399).
+ * dxv_grid_device_ptr marks the frame as written to by the caller for as long as that pointer lives (until the grid is
+ * reallocated by a larger launch): every later launch into the frame then clears the whole grid first instead of keeping
+ * the zeros of its own last launch -- a caller who caches the pointer and writes through it later is safe.  This accessor
+ * leaves the frame alone. */
+DXV_API const void* dxv_grid_device_ptr_ro(const dxv_ctx* ctx);
 DXV_API size_t dxv_grid_bytes(const dxv_ctx* ctx);
 DXV_API int dxv_grid_download(dxv_ctx* ctx, uint8_t* host, size_t bytes);
 /* The same grid as one BIT per voxel, packed on the device before it crosses PCIe (8x fewer
@@ -213,6 +222,9 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
  *   plists 0|1|2    parity rule through row lists of the (y, z) plane: 1 (default) from a scene's second parity launch,
  *                 2 from the first, 0 = always walk the tree; plistres 0|16..4096: texels per side of their grid
+ *   plan   0|1|2  lists kernel: launch only the 4^3-voxel bricks that hold a live ray, 512-brick regions heaviest first and
+ *                 dealt to the XCDs by estimated cost (1, default: from the second launch of a partition against the same
+ *                 lists; 2: from the first; 0: brick box around the scene in Morton order)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);

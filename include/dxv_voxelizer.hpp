@@ -114,7 +114,7 @@ public:
 		bits.resize(dxv_grid_packed_bytes(m_ctx));
 		return dxv_grid_download_packed(m_ctx, bits.data(), bits.size()) == 0;
 	}
-	const void* DeviceGrid() const { return m_ctx ? dxv_grid_device_ptr(m_ctx) : nullptr; }
+	const void* DeviceGrid() const { return m_ctx ? dxv_grid_device_ptr_ro(m_ctx) : nullptr; }
 	bool CountSolid(uint64_t& solid) { return m_ctx && dxv_grid_count(m_ctx, &solid) == 0; }
 
 	bool GetStats(dxv_stats& s) const { return m_ctx && dxv_get_stats(m_ctx, &s) == 0; }

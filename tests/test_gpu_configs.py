@@ -99,6 +99,16 @@ def test_config_grid_equals_oracle_fixture(dxv, configs, key):
                 assert st["list_entries"] == 0
             check_whole(v.Grid(), configs[key], f"{key} lists={lists}")
             assert v.CountSolid() == configs[key]["solid"]
+            if mode == 0 and lists == 2 and st["list_entries"] > 0:
+                # the same launch through a dispatch plan (live bricks only, regions by cost), twice: the second one keeps
+                # the first one's memset
+                v.set_option("plan", 2)
+                for again in range(2):
+                    v.Voxelize(N, mode)
+                    sp = v.stats()
+                    assert 0 < sp["plan_bricks"] <= (N // 4) ** 3 and sp["plan_waves"] >= sp["plan_bricks"]
+                    check_whole(v.Grid(), configs[key], f"{key} plan, launch {again}")
+                v.set_option("plan", 0)
     finally:
         v.close()
 
@@ -126,6 +136,18 @@ def test_config4_dragon9_1024_slabs_and_block_cyclic(dxv, configs):
             for r in range(W):
                 v.VoxelizeInterleaved(N, r, W, blk)
                 assert sha(v.Grid()) == want["cyclic8x8_sha256"][r], f"block-cyclic rank {r} lists={lists}"
+            if lists == 2:
+                # every rank's share through its dispatch plan (what bench.py --gpus 8 runs), and two slabs
+                v.set_option("plan", 2)
+                for r in range(W):
+                    v.VoxelizeInterleaved(N, r, W, blk)
+                    assert v.stats()["plan_bricks"] > 0
+                    assert sha(v.Grid()) == want["cyclic8x8_sha256"][r], f"block-cyclic rank {r} through a plan"
+                for r in (0, 3):
+                    z0, nz = slab_range(N, r, W)
+                    v.Voxelize(N, 0, z0, nz)
+                    assert sha(v.Grid()) == want["slabs8_sha256"][r], f"slab {r} through a plan"
+                v.set_option("plan", 0)
     finally:
         v.close()
 
@@ -143,6 +165,12 @@ def test_config5_soup10m_512(dxv, configs):
             v.set_option("lists", lists)
             v.Voxelize(512)
             check_whole(v.Grid(), configs[key], f"{key} lists={lists}")
+        v.set_option("lists", 2)
+        v.set_option("plan", 2)
+        v.Voxelize(512)
+        if v.stats()["list_entries"]:
+            assert v.stats()["plan_bricks"] > 0
+        check_whole(v.Grid(), configs[key], f"{key} plan")
     finally:
         v.close()
         _cache.clear()

@@ -982,12 +982,100 @@ def test_kept_memset_of_partial_launches(dxv, orc):
             v.Voxelize(128); assert np.array_equal(v.Grid(), s.voxelize(128))
             v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
             v.Sync()
-            assert hip.hipMemset(C.c_void_p(v.grid_device_ptr()), 1, N ** 3) == 0 and hip.hipDeviceSynchronize() == 0
+            ptr = v.grid_device_ptr()
+            assert hip.hipMemset(C.c_void_p(ptr), 1, N ** 3) == 0 and hip.hipDeviceSynchronize() == 0
             v.Voxelize(N); assert np.array_equal(v.Grid(), ref), "the caller's bytes outside the box"
+            # a caller who KEEPS the pointer and writes through it later, without fetching it again (the pointer stays
+            # valid while the grid is not reallocated): the frame never trusts its own memset again
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
+            assert hip.hipMemset(C.c_void_p(ptr), 1, N ** 3) == 0 and hip.hipDeviceSynchronize() == 0
+            v.Voxelize(N); assert np.array_equal(v.Grid(), ref), "bytes written through a cached pointer survived"
+            assert v.grid_device_ptr(writable=False) == ptr
         v.SetFrame(0)
         v.EnableTexels(True)
         v.Voxelize(N)
         assert np.array_equal(v.Grid(), ref) and np.array_equal(v.Texels(), s.voxelize(N, texels=True)[1])
         v.EnableTexels(False)
         v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
+    v.close()
+
+
+@pytest.mark.gpu
+def test_dispatch_plan_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon):
+    """Lists kernel through a dispatch plan (option plan: only bricks with a live ray are launched, 512-brick regions
+    heaviest first, dealt to the XCDs by cost; everything else is the launch's memset): same grid as the plain launch and
+    the oracle -- whole grids, grids that are no multiple of the brick or the region, slabs, block-cyclic ranks, texels,
+    frames in flight, a refit (new lists: a new plan), the automatic policy (second launch of a partition), and the
+    caller writing into the grid between two planned launches."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 2)
+    for (vb, ib, _), sizes in ((bunny, (64, 50, 100, 256)), (dragon, (66, 128))):
+        s = orc.Scene(vb, ib)
+        v.InitFromArrays(vb, ib)
+        for N in sizes:
+            want = s.voxelize(N)
+            v.set_option("plan", 0)
+            v.Voxelize(N)
+            assert np.array_equal(v.Grid(), want) and v.stats()["plan_bricks"] == 0
+            v.set_option("plan", 2)
+            for again in range(3):
+                v.Voxelize(N)
+                st = v.stats()
+                assert st["plan_bricks"] > 0 and st["plan_waves"] % 8 == 0 and st["plan_waves"] >= st["plan_bricks"]
+                assert np.array_equal(v.Grid(), want), (N, again)
+            assert hip.hipMemset(C.c_void_p(v.grid_device_ptr()), 1, N ** 3) == 0 and hip.hipDeviceSynchronize() == 0
+            v.Voxelize(N)
+            assert np.array_equal(v.Grid(), want), "the caller's bytes in bricks the plan does not launch"
+            if N % 16 == 0:
+                for z0, nz in ((0, N // 2), (N // 4, 10), (N - 6, 6)):
+                    v.Voxelize(N, 0, z0, nz)
+                    assert np.array_equal(v.Grid(), want[z0:z0 + nz]), (N, z0, nz)
+                for world, zb in ((2, 4), (4, 2)):
+                    for r in range(world):
+                        v.VoxelizeInterleaved(N, r, world, zb)
+                        zs = [z for z in range(N) if (z // zb) % world == r]
+                        assert np.array_equal(v.Grid(), want[zs]), (N, world, zb, r)
+    # texels, frames in flight (one plan serves all frames; every frame's grid needs its own memset)
+    vb, ib, _ = bunny
+    s = orc.Scene(vb, ib)
+    N = 128
+    want, wtex = s.voxelize(N, texels=True)
+    v.InitFromArrays(vb, ib)
+    v.EnableTexels(True)
+    v.Voxelize(N)
+    assert np.array_equal(v.Grid(), want) and np.array_equal(v.Texels(), wtex)
+    v.EnableTexels(False)
+    for f in range(v.FrameCount):
+        v.Voxelize(N, 0, sync=False, frameIndex=f)
+    v.SyncAll()
+    for f in range(v.FrameCount):
+        v.SetFrame(f)
+        assert v.stats()["plan_bricks"] > 0 and np.array_equal(v.Grid(), want), f
+    v.SetFrame(0)
+    # automatic policy: the first launch of a partition against new lists takes the brick box, the second builds the plan
+    v.set_option("plan", 1)
+    lo, hi = vb[:, :3].min(0), vb[:, :3].max(0)
+    pins = np.zeros((2, 6), np.float32)
+    pins[0, :3], pins[1, :3] = (lo + hi) / 2 - 1.25 * (hi - lo).max() / 2, (lo + hi) / 2 + 1.25 * (hi - lo).max() / 2
+    vb0 = np.concatenate([vb, pins]).astype(np.float32)                 # (unreferenced vertices pin the bound through the refit)
+    v.InitFromArrays(vb0, ib)
+    v.Voxelize(N); v.Voxelize(N)
+    assert v.stats()["plan_bricks"] > 0
+    vb1 = vb0.copy()
+    vb1[:-2, 0] = (vb1[:-2, 0] - (lo[0] + hi[0]) / 2) * np.float32(0.8) + (lo[0] + hi[0]) / 2
+    v.UpdateVertices(vb1)                                               # refit: new lists at the next launch, the old plan is stale
+    w2 = orc.Scene(vb1, ib).voxelize(N)
+    seen = []
+    for k in range(3):
+        v.Voxelize(N)
+        seen.append(v.stats()["plan_bricks"] > 0)
+        assert np.array_equal(v.Grid(), w2), k
+    assert seen == [False, True, True]
+    g_auto = v.Grid()
+    v.set_option("plan", 0)
+    v.Voxelize(N)
+    assert np.array_equal(v.Grid(), g_auto)
     v.close()
