@@ -54,7 +54,7 @@ def algorithmic_bytes(N, nz, T, V):
     return N * N * nz * 1 + (2 * T - 1) * 32 + T * 12 + V * 24
 
 
-def cpu_baseline(vb, ib, N, mode, budget_s=15.0):
+def cpu_baseline(vb, ib, N, mode, budget_s=15.0):  # (N > 1: a shorter sample, the other ranks wait for rank 0)
     """The oracle's scalar BVH voxelizer ('port': the reference has no CPU path) on a bounded
     sample of the same workload: evenly spaced Z slices, all host cores (OpenMP over rows)."""
     from oracle import orc
@@ -213,20 +213,23 @@ def main():
     if interleave:
         nz = N // world
 
-    def timed_region(frames, steps, warmup):
+    def timed_region(frames, steps, warmup, n=None):
         """`steps` steps with `frames` voxelizations in flight (frames of the one context, taking the steps in turn),
-        barrier + synchronize on both sides; (wall seconds, mean kernel ms).  A rank's share of the grid is a short
-        launch whose tail -- its last long rays running alone -- does not shrink with it; the reference hides the same
-        thing by keeping FrameCount = 3 grids in flight (Content/Voxelizer.h:24)."""
+        barrier + synchronize on both sides; (wall seconds, mean kernel ms, per-step ms).  A rank's share of the grid is a
+        short launch whose tail -- its last long rays running alone -- does not shrink with it; the reference hides the same
+        thing by keeping FrameCount = 3 grids in flight (Content/Voxelizer.h:24).  n: grid size (default: the headline's)."""
         turn = [0]
+        n = N if n is None else n
+        inter = (world > 1 or args.interleave) and n % (zblock * world) == 0
+        z0n, nzn = slab_range(n, rank, world)
 
         def step():
             f = turn[0] % frames
             turn[0] += 1
-            if interleave:
-                vox.VoxelizeInterleaved(N, rank, world, zblock, mode, sync=False, frameIndex=f)
-            elif nz:
-                vox.Voxelize(N, mode, z0, nz, sync=False, frameIndex=f)
+            if inter:
+                vox.VoxelizeInterleaved(n, rank, world, zblock, mode, sync=False, frameIndex=f)
+            elif nzn:
+                vox.Voxelize(n, mode, z0n, nzn, sync=False, frameIndex=f)
 
         for _ in range(max(warmup, frames)):     # every frame launches at least once before the clock starts
             step()
@@ -234,19 +237,24 @@ def main():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if frames == 1 else 2)]
         t0 = time.perf_counter()
-        ev0.record(stream)
-        for _ in range(steps):
+        evs[0].record(stream)
+        for k in range(steps):
             step()
-        ev1.record(stream)
+            if frames == 1:
+                evs[k + 1].record(stream)        # (the launches queue back to back on this stream: event k+1 - event k = step k on the device)
+        if frames != 1:
+            evs[1].record(stream)
         torch.cuda.synchronize()
-        if use_dist:
+        dt = time.perf_counter() - t0            # this rank's K steps; the closing barrier (tens of us of RCCL) is not part of any
+        if use_dist:                             # rank's work: the maximum over ranks is taken by reduce_max below
             dist.barrier()
-        dt = time.perf_counter() - t0
         vox.SyncAll()                            # deferred kernel status (stack overflow) is an error
+        per_step = []
         if frames == 1:
-            k_ms = ev0.elapsed_time(ev1) / max(steps, 1)         # avg launch duration on the kernel's stream
+            per_step = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
+            k_ms = evs[0].elapsed_time(evs[steps]) / max(steps, 1)   # avg launch duration on the kernel's stream
         else:                                    # overlapping launches: the library's own events around each frame's last launch
             ks = []
             for f in range(frames):
@@ -254,7 +262,7 @@ def main():
                 ks.append(vox.stats()["voxelize_ms"])
             k_ms = float(np.mean(ks))
         vox.SetFrame(0)
-        return dt, k_ms
+        return dt, k_ms, per_step
 
     def reduce_max(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -262,10 +270,24 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(x):
+        """x of every rank, in rank order"""
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if not use_dist:
+            return [float(x)]
+        out = torch.empty(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(out, t)
+        return [float(v) for v in out.tolist()]
+
+    def stats_ms(xs):
+        return {"median": float(np.median(xs)), "min": float(np.min(xs)), "max": float(np.max(xs))} if len(xs) else None
+
     frames = max(1, min(args.frames, vox.FrameCount))
-    dt, kernel_ms = timed_region(frames, args.steps, args.warmup)
+    dt, kernel_ms, per_step = timed_region(frames, args.steps, args.warmup)
     dt_max = reduce_max(dt)
-    kmax = reduce_max(kernel_ms)
+    rank_kernel_ms = gather(kernel_ms)           # every rank's mean launch duration: an imbalance of the partition shows here
+    rank_wall_ms = gather(dt / max(args.steps, 1) * 1e3)
+    kmax = max(rank_kernel_ms)
     st_run = vox.stats()                         # of the timed rule (the extras below overwrite the launch fields)
     solid = vox.CountSolid() if nz else 0
     tot = torch.tensor([float(solid)], dtype=torch.float64, device="cuda")
@@ -276,7 +298,7 @@ def main():
     if not args.no_extras:
         # the same steps with two voxelizations in flight per GPU, at every N (like-for-like ratios across N)
         other = 2 if frames == 1 else 1
-        dt2, k2 = timed_region(other, args.steps, 2)
+        dt2, k2, _ = timed_region(other, args.steps, 2)
         dt2 = reduce_max(dt2)
         extras[f"frames_in_flight_{other}"] = {"value": (N ** 3) * args.steps / dt2 / 1e6, "unit": "Mvoxels/s",
                                                "ms_per_step": dt2 / args.steps * 1e3, "kernel_ms": reduce_max(k2)}
@@ -327,6 +349,22 @@ def main():
                 extras["bunny16"] = {"workload": f"{blabel}, {N}^3, reference predicate", "ms": lm, "mvoxels_s": N ** 3 / lm / 1e3,
                                      "tree_walk_ms": tm, "tree_walk_mvoxels_s": N ** 3 / tm / 1e3}
 
+    if not args.no_extras and mode == dxv.MODE_REFERENCE and args.mesh == "torus1m":
+        # BASELINE config 4 beside the headline at every N: dragon x9 at 1024^3, the same partition -- a rank's share is
+        # eight times the headline's, so the launch tail weighs an eighth as much in the scaling it shows
+        n4, k4 = 1024, max(5, min(args.steps, 10))
+        if rank == 0:
+            vb4, ib4, label4 = make_mesh("dragon9")
+            vox.InitFromArrays(vb4, ib4)
+        if use_dist:
+            broadcast_scene(vox, dist, torch.device("cuda", local_rank))
+        dt4, k4ms, step4 = timed_region(1, k4, 3, n=n4)
+        rk4 = gather(k4ms)
+        dt4 = reduce_max(dt4)
+        extras["config4_dragon9_1024"] = {"workload": "dragon x9 (900,000 triangles), 1024^3, reference predicate, same partition",
+                                          "value": (n4 ** 3) * k4 / dt4 / 1e6, "unit": "Mvoxels/s", "steps": k4,
+                                          "ms_per_step": dt4 / k4 * 1e3, "rank_kernel_ms": rk4, "step_ms": stats_ms(step4)}
+
     if rank == 0:
         value = (N ** 3) * args.steps / dt_max / 1e6
         bytes_launch = algorithmic_bytes(N, nz, T, V)
@@ -336,7 +374,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = f"{args.mesh}/{N}/{args.mode}/gpus{world}"
+                key = f"{args.mesh}/{N}/{args.mode}/gpus{world}"    # (N > 1: one rank's launch, like `achieved`)
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -359,7 +397,12 @@ def main():
                        "build_ms": st0["build_ms"], "build_stages_ms": {k: st0[k] for k in
                                                                        ("prep_ms", "sort_ms", "hierarchy_ms", "refit_ms")},
                        "upload_ms": st0["upload_ms"], "scene_broadcast_ms": bcast_ms,
-                       "kernel_ms_max_over_ranks": kmax, **extras},
+                       "kernel_ms_max_over_ranks": kmax, "rank_kernel_ms": rank_kernel_ms, "rank_ms_per_step": rank_wall_ms,
+                       "rank_imbalance": max(rank_kernel_ms) / (sum(rank_kernel_ms) / len(rank_kernel_ms)) if min(rank_kernel_ms) > 0 else None,
+                       "step_ms_rank0": stats_ms(per_step),
+                       "dispatch_plan": ({"live_bricks": st_run["plan_bricks"], "workgroups": st_run["plan_waves"], "build_ms": st_run["plan_ms"]}
+                                         if st_run.get("plan_bricks") else None),
+                       **extras},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
@@ -368,8 +411,8 @@ def main():
                                  "is not bound by bandwidth: compulsory HBM bytes are a few per cent of what 8 TB/s moves in its "
                                  "run time (DESIGN.md section 4 names the measured limiter)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode)
+        if not args.no_cpu_baseline:                      # (N > 1: a shorter sample; the other ranks wait in the barrier below)
+            out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode, budget_s=15.0 if world == 1 else 6.0)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -1,6 +1,6 @@
 """Build libdxv.so (HIP kernels + C-ABI) in-tree for gfx950.
 
-    python -m dxrvoxelizer_amd.build [--force] [--save-temps]
+    python -m dxrvoxelizer_amd.build [--force] [--save-temps] [--ablate]
 
 hipcc cross-compiles without a GPU; the resulting dxrvoxelizer_amd/libdxv.so travels with the
 repository snapshot to the GPU box.
@@ -37,8 +37,9 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def _compile(src, extra):
-    obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+def _compile(src, extra, objdir=None):
+    objdir = objdir or OBJDIR
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     cmd = [hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
     if src.endswith(".cpp"):
         cmd = [c for c in cmd if not c.startswith("--offload-arch") and not c.startswith("-fhip")]
@@ -49,29 +50,33 @@ def _compile(src, extra):
     if r.returncode:
         raise RuntimeError("compile failed: %s\n%s%s" % (" ".join(cmd), r.stdout, r.stderr))
     if src.endswith(".hip"):
-        with open(os.path.join(OBJDIR, os.path.splitext(src)[0] + ".usage"), "w") as fh:
+        with open(os.path.join(objdir, os.path.splitext(src)[0] + ".usage"), "w") as fh:
             fh.write(r.stderr)
         return obj, "\n".join(l for l in r.stderr.splitlines() if "remark:" not in l)
     return obj, r.stderr
 
 
-def build(force=False, save_temps=False, verbose=False):
+def build(force=False, save_temps=False, verbose=False, ablate=False):
+    """ablate=True: a second library, libdxv_ablate.so, with the timing-only variants of the lists kernel (-DDXV_ABLATE:
+    option `ablate`, wrong grids by design) for tools/ablate.py; the product library never contains them."""
+    lib = os.path.join(HERE, "libdxv_ablate.so") if ablate else LIB
+    objdir = OBJDIR + ("_ablate" if ablate else "")
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] + [__file__]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
-        return LIB
-    os.makedirs(OBJDIR, exist_ok=True)
-    extra = ["-save-temps=obj"] if save_temps else []
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
+        return lib
+    os.makedirs(objdir, exist_ok=True)
+    extra = (["-save-temps=obj"] if save_temps else []) + (["-DDXV_ABLATE"] if ablate else [])
     with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
-        results = list(ex.map(lambda s: _compile(s, extra), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, extra, objdir), SOURCES))
     for _, err in results:
         if verbose and err.strip():
             print(err, file=sys.stderr)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for o, _ in results]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + [o for o, _ in results]
     # cwd = the ignored build directory: the offload bundler drops its temp files where it runs
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJDIR)
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=objdir)
     if r.returncode:
         raise RuntimeError("link failed: %s\n%s%s" % (" ".join(cmd), r.stdout, r.stderr))
-    return LIB
+    return lib
 
 
 def kernel_resources(src="traverse"):
@@ -96,4 +101,4 @@ def kernel_resources(src="traverse"):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True, ablate="--ablate" in sys.argv))

@@ -42,6 +42,8 @@ struct dxv_ctx {
     size_t sceneBytes = 0;
     SceneHeader hdr{};
     bool haveScene = false;
+    bool haveHierarchy = false;      // dxv_build ran for the resident mesh: keys, links and parent words are in place for dxv_refit
+                                     // (stays true when a refit fails on bad vertices: the next good update refits again)
 
     // build scratch
     uint64_t* dKeys = nullptr;
@@ -119,6 +121,7 @@ struct dxv_ctx {
     Plan plans[kPlans];
     uint64_t listEpoch = 0, planClock = 0, planIds = 0;
     int optPlan = 1;                 // 0 = no plans (brick box + Morton order), 1 = from a partition's second launch, 2 = from the first
+    int optPlanOrder = 1;            // order of the regions inside a plan (plan_for)
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
     uint32_t* dPlCells = nullptr;
@@ -561,16 +564,48 @@ dxv_ctx::Plan* plan_for(dxv_ctx* c, const VoxelizeParams& p, hipStream_t stream,
     std::vector<uint32_t> order;
     order.reserve(nr);
     for (uint32_t r = 0; r < nr; ++r) if (host[nr + r]) order.push_back(r);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return host[a] > host[b]; });
     uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t len[8] = {0, 0, 0, 0, 0, 0, 0, 0}, live = 0;
-    for (uint32_t r : order) {
-        int x = 0;
-        for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
-        dst[2 * r] = (uint32_t)x; dst[2 * r + 1] = len[x];
-        len[x] += host[nr + r]; load[x] += host[r];
-        live += host[nr + r];
+    for (uint32_t r : order) live += host[nr + r];
+    std::vector<uint32_t> seq[8];                                       // regions of every XCD in launch order
+    auto lpt = [&](const std::vector<uint32_t>& rs) {                   // each region onto the XCD with the least cost so far
+        for (uint32_t r : rs) {
+            int x = 0;
+            for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
+            seq[x].push_back(r);
+            load[x] += host[r];
+        }
+    };
+    const int mode = c->optPlanOrder;
+    if (mode == 0) {                                                    // Morton order, dealt round-robin (the plain launch minus its dead bricks)
+        for (size_t k = 0; k < order.size(); ++k) seq[k & 7].push_back(order[k]);
+    } else if (mode == 1) {                                             // heaviest first
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return host[a] > host[b]; });
+        lpt(order);
+    } else {
+        // balanced by cost, every XCD in Morton order; mode 3: the regions that are cheapest per live brick -- two rounds of
+        // wave slots' worth per XCD -- go last, dearest of them first, so that the launch drains through short waves
+        std::vector<uint32_t> body = order, tail;
+        if (mode == 3) {
+            std::stable_sort(body.begin(), body.end(), [&](uint32_t a, uint32_t b) {
+                return (uint64_t)host[a] * host[nr + b] < (uint64_t)host[b] * host[nr + a]; });    // cost per live brick, ascending
+            uint32_t pool = 0;
+            size_t cut = 0;
+            while (cut < body.size() && pool < 8u * 2048u && cut < body.size() / 3) pool += host[nr + body[cut++]];
+            tail.assign(body.begin(), body.begin() + cut);
+            body.erase(body.begin(), body.begin() + cut);
+            std::reverse(tail.begin(), tail.end());
+        }
+        std::stable_sort(body.begin(), body.end(), [&](uint32_t a, uint32_t b) { return host[a] > host[b]; });
+        lpt(body);
+        for (auto& q : seq) std::sort(q.begin(), q.end());
+        size_t mark[8];
+        for (int k = 0; k < 8; ++k) mark[k] = seq[k].size();
+        lpt(tail);                                                      // (appended behind the body, in the order given)
+        (void)mark;
     }
+    for (int x = 0; x < 8; ++x)
+        for (uint32_t r : seq[x]) { dst[2 * r] = (uint32_t)x; dst[2 * r + 1] = len[x]; len[x] += host[nr + r]; }
     uint32_t longest = 0;
     for (int k = 0; k < 8; ++k) if (len[k] > longest) longest = len[k];
     const uint32_t words = 8u * longest;
@@ -821,7 +856,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -874,6 +909,7 @@ int finish_build(dxv_ctx* c, const char* who)
     DXV_HIP(c, hipMemcpyAsync(rootInfo, c->dRootInfo, sizeof(rootInfo), hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     if (rootInfo[7] != 1) return fail(c, "%s: did not complete", who);
+    if (rootInfo[11]) return fail(c, "%s: %u triangle(s) have a non-finite vertex position (NaN / Inf in the vertex buffer)", who, rootInfo[11]);
     memcpy(c->hdr.rootLo, &rootInfo[0], 12);
     memcpy(c->hdr.rootHi, &rootInfo[3], 12);
     c->hdr.treeHeight = rootInfo[6];
@@ -924,7 +960,7 @@ int dxv_update_vertices_device(dxv_ctx* c, const void* dvb, uint32_t V)
 int dxv_refit(dxv_ctx* c)
 {
     if (!c) return 1;
-    if (!c->haveMesh || !c->haveScene || c->scratchT != c->T || !c->T)
+    if (!c->haveMesh || !c->haveHierarchy || c->scratchT != c->T || !c->T)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
@@ -949,7 +985,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -960,6 +996,7 @@ int dxv_build(dxv_ctx* c)
     if (c->optRefit != 1) b.pyramid = nullptr;
     DXV_HIP(c, lbvh_build(b, c->optRefit, c->stream, c->ev));
     if (finish_build(c, "dxv_build")) return 1;
+    c->haveHierarchy = true;
     c->stats.prep_ms = elapsed(c->ev[0], c->ev[1]);
     c->stats.sort_ms = elapsed(c->ev[1], c->ev[2]);
     c->stats.hierarchy_ms = elapsed(c->ev[2], c->ev[3]);
@@ -1293,7 +1330,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     // triangle count over the old, smaller buffers.
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
-    c->dVb = nullptr; c->dIb = nullptr; c->haveMesh = false;
+    c->dVb = nullptr; c->dIb = nullptr; c->haveMesh = false; c->haveHierarchy = false;
     free_scratch(c);
     if (alloc_scene(c, h.numTris, h.numVerts, h.hasWide != 0)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dScene, src, want.totalBytes, hipMemcpyDeviceToDevice, c->stream));
@@ -1376,6 +1413,10 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "plan")) {
         if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
         c->optPlan = (int)value;
+    } else if (!strcmp(key, "planorder")) {
+        if (value < 0 || value > 3) return fail(c, "option planorder: %lld not in {0,1,2,3}", (long long)value);
+        if (c->optPlanOrder != (int)value) { if (sync_frames(c)) return 1; for (auto& pl : c->plans) pl.used = pl.valid = false; }
+        c->optPlanOrder = (int)value;
     } else if (!strcmp(key, "plistres")) {
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option plistres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
         if (c->optPlistRes != (int)value) { if (sync_frames(c)) return 1; c->plState = 0; }     // the next parity launch rebuilds the row lists
@@ -1388,8 +1429,14 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
         if (c->optListRes != (int)value && sync_frames(c)) return 1;     // the next launch rebuilds the lists: nothing may still read them
         c->optListRes = (int)value;
     } else if (!strcmp(key, "ablate")) {
+#if defined(DXV_ABLATE)
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8}", (long long)value);
         c->optAblate = (int)value;
+#else
+        // the timing-only variants of the lists kernel write wrong grids by design: they exist only in the library that
+        // tools/ablate.py builds for itself (python -m dxrvoxelizer_amd.build --ablate -> libdxv_ablate.so)
+        if (value != 0) return fail(c, "option ablate: this library was built without the ablation kernels (-DDXV_ABLATE)");
+#endif
     } else if (!strcmp(key, "skipempty")) {
         if (value != 0 && value != 1) return fail(c, "option skipempty: %lld not in {0,1}", (long long)value);
         c->optSkipEmpty = (int)value;

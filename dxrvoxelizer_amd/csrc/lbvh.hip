@@ -66,7 +66,8 @@ __global__ __launch_bounds__(kThreads) void k_tri_keys(const float* __restrict__
 
 __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
                                                          uint32_t T, Bound4 bnd, const uint64_t* __restrict__ keys,
-                                                         TriPos* __restrict__ triPos, TriNrm* __restrict__ triNrm)
+                                                         TriPos* __restrict__ triPos, TriNrm* __restrict__ triNrm,
+                                                         uint32_t* __restrict__ rootInfo)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T) return;
@@ -74,6 +75,11 @@ __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict
     F4 a, b, c;
     uint32_t idx[3];
     gather_tri(vb, ib, k, bnd, a, b, c, idx);
+    // vertices that came from a device buffer (dxv_update_vertices_device) were never seen by the host: a NaN / Inf position
+    // inside an otherwise finite mesh would not show in the root box.  rootInfo[11] counts such triangles (x - x is 0 for
+    // every finite x); dxv_build / dxv_refit fail on a non-zero count.
+    const float probe = ((a.x - a.x) + (a.y - a.y) + (a.z - a.z)) + ((b.x - b.x) + (b.y - b.y) + (b.z - b.z)) + ((c.x - c.x) + (c.y - c.y) + (c.z - c.z));
+    if (!(probe == 0.0f)) atomicAdd(rootInfo + 11, 1u);
     a.w = __builtin_bit_cast(float, k);
     TriPos tp; tp.v0 = a; tp.v1 = b; tp.v2 = c;
     TriNrm tn;
@@ -304,7 +310,7 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
         if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;
     }
     (void)hipEventRecord(ev[2], s);
-    k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm);
+    k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo);
     if (T > 1) k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents, b.flags2);
     (void)hipEventRecord(ev[3], s);
     if (b.pyramid && refitMode == 1 && T > 1) e = refit_pyramid(b, true, s);
@@ -510,8 +516,9 @@ hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight,
     for (int a = 0; a < 4; ++a) bnd.c[a] = b.bound[a];
     hipError_t e;
     if ((e = hipMemsetAsync(b.rootInfo, 0, 8 * sizeof(uint32_t), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(b.rootInfo + 11, 0, sizeof(uint32_t), s)) != hipSuccess) return e;      // (words 8..10: the build's triangle extent stays)
     (void)hipEventRecord(ev[0], s);
-    k_tri_gather<<<blocks_for(b.T), kThreads, 0, s>>>(b.vb, b.ib, b.T, bnd, b.keys, b.triPos, b.triNrm);
+    k_tri_gather<<<blocks_for(b.T), kThreads, 0, s>>>(b.vb, b.ib, b.T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo);
     if (b.pyramid && refitMode != 0 && b.T > 1) e = refit_pyramid(b, false, s);
     else e = refit_stage(b, refitMode, s, treeHeight);
     if (e != hipSuccess) return e;

@@ -695,6 +695,7 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
         // direction-space lists: no stack, the column is the queue of selected triangles (8 entries; 16 for deep scenes,
         // where a ray meets many candidates before its first flush)
         if constexpr (STACK == 8 || STACK == 16) {
+#if defined(DXV_ABLATE)                                                  // (only in the library tools/ablate.py builds for itself: libdxv_ablate.so)
             if constexpr (B::threads == 64 && B::x == 4 && STACK == 16) {    // timing-only ablations of the default shape (tools/ablate.py)
                 switch (p.ablate) {
                 case 0: break;
@@ -706,6 +707,7 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
                 default: return hipErrorInvalidValue;
                 }
             }
+#endif
             if (p.texels) k_voxelize<B, STACK, 0, true, 4><<<g, b, 0, s>>>(p);
             else k_voxelize<B, STACK, 0, false, 4><<<g, b, 0, s>>>(p);
         } else return hipErrorInvalidValue;

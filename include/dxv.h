@@ -108,8 +108,15 @@ DXV_API int dxv_build(dxv_ctx* ctx);
 DXV_API int dxv_update_vertices(dxv_ctx* ctx, const float* vb, uint32_t num_verts);
 /* The same from a DEVICE buffer (6 floats per vertex, on this context's GPU): the reference's vertex buffer is a GPU
  * resource (createVB, Content/Voxelizer.cpp:115-126), and a mesh animated on the GPU -- skinning, simulation -- never
- * passes through the host.  A device-to-device copy on the context's stream; the caller's buffer may be reused as soon as
- * the call returns only if it was written on that stream, else after dxv_sync_all. */
+ * passes through the host.  A device-to-device copy ENQUEUED on the context's stream (dxv_set_stream), nothing else:
+ *  - ordering before the copy is the caller's: whatever wrote device_vb must be complete, or ordered before this stream (same
+ *    stream, or an event the stream waits on), when the call is made -- a producer kernel still running on another stream
+ *    would be read half-written;
+ *  - the caller's buffer may be reused as soon as the call returns only if it is written on that same stream, else after
+ *    dxv_sync_all;
+ *  - positions are not inspected on the host (dxv_set_mesh refuses non-finite ones there): the following dxv_refit counts
+ *    triangles with a NaN / Inf vertex while it gathers them and fails if there are any (the hierarchy stays: the next
+ *    good update refits again). */
 DXV_API int dxv_update_vertices_device(dxv_ctx* ctx, const void* device_vb, uint32_t num_verts);
 DXV_API int dxv_refit(dxv_ctx* ctx);
 

@@ -868,6 +868,17 @@ def test_update_vertices_from_a_device_buffer(dxv, orc, bunny):
         v.UpdateVerticesDevice(d.data_ptr(), len(moved) - 1)
     with pytest.raises(dxv.DxvError):
         v.UpdateVerticesDevice(0, len(moved))
+    # one NaN inside an otherwise finite mesh (the root box would not show it): the refit counts it and fails; the next good
+    # update recovers
+    bad = moved.copy()
+    bad[ib[30], 1] = np.nan
+    dbad = torch.from_numpy(bad).cuda()
+    torch.cuda.synchronize()
+    with pytest.raises(dxv.DxvError, match="non-finite"):
+        v.UpdateVerticesDevice(dbad.data_ptr(), len(bad))
+    v.UpdateVerticesDevice(d.data_ptr(), len(moved))
+    v.Voxelize(64)
+    assert np.array_equal(a, v.Grid())
     v.close(); w.close()
 
 

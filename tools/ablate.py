@@ -10,7 +10,11 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+# the ablation kernels are not in the product library: this tool loads libdxv_ablate.so (python -m dxrvoxelizer_amd.build
+# --ablate, cross-compiled in the build container; it travels to the GPU box with the snapshot)
+os.environ.setdefault("DXV_LIBRARY", os.path.abspath(os.path.join(ROOT, "dxrvoxelizer_amd", "libdxv_ablate.so")))
 import dxrvoxelizer_amd as dxv  # noqa: E402
 from bench import make_mesh  # noqa: E402
 
@@ -24,6 +28,7 @@ def main():
     a = ap.parse_args()
     v = dxv.Voxelizer(0)
     v.set_option("lists", 2)
+    v.set_option("plan", 0)                      # (the ablations are variants of the plain launch)
     for mesh in a.meshes.split(","):
         vb, ib, _ = make_mesh(mesh)
         v.InitFromArrays(vb, ib)
