@@ -73,7 +73,8 @@ SYMBOLS = {
     "dxv_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "dxv_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "dxv_debug_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
-    "dxv_debug_list_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "dxv_debug_list_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "dxv_debug_class_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
 }
 
 

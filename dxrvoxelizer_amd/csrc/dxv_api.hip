@@ -121,7 +121,7 @@ struct dxv_ctx {
     Plan plans[kPlans];
     uint64_t listEpoch = 0, planClock = 0, planIds = 0;
     int optPlan = 1;                 // 0 = no plans (brick box + Morton order), 1 = from a partition's second launch, 2 = from the first
-    int optPlanOrder = 1;            // order of the regions inside a plan (plan_for)
+    int optPlanOrder = 3;            // order of the regions inside a plan (plan_for): 3 = balanced by cost, Morton order, cheapest regions last
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
     uint32_t* dPlCells = nullptr;
@@ -1350,6 +1350,15 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         const uint8_t* in = static_cast<const uint8_t*>(src);
         DXV_HIP(c, hipMemcpyAsync(c->dListCells, in + b.offCells, b.cellBytes, hipMemcpyDeviceToDevice, c->stream));
         if (b.entryBytes) DXV_HIP(c, hipMemcpyAsync(c->dListEntries, in + b.offEntries, b.entryBytes, hipMemcpyDeviceToDevice, c->stream));
+        // The kernel indexes the entries with what the cells say and the triangle records with what the entries say: a blob
+        // whose header is consistent but whose payload is not (cut short, corrupted, another version's) must not get that far.
+        uint32_t bad[2] = {0, 0};
+        DXV_HIP(c, dirmap_validate(c->dListCells, h.listRes, c->dListEntries, h.listCount, h.numTris, c->dRootInfo, c->stream));
+        DXV_HIP(c, hipMemcpyAsync(bad, c->dRootInfo, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+        if (bad[0] || bad[1])
+            return fail(c, "dxv_scene_import: the list section is inconsistent (%u texels point outside the %u entries, %u entries name a triangle >= %u)",
+                        bad[0], h.listCount, bad[1], h.numTris);
     }
     const uint32_t listRes = h.listRes, listCount = h.listCount;
     h.offListCells = h.offListEntries = 0; h.listRes = h.listCount = 0; h.totalBytes = want.totalBytes;   // the resident header describes the resident scene
@@ -1463,11 +1472,12 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     return 0;
 }
 
-int dxv_debug_list_check(dxv_ctx* c, uint32_t N, uint64_t out[34])
+int dxv_debug_list_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, uint64_t out[34])
 {
     if (!c || !out) return 1;
     if (!c->haveScene) return fail(c, "dxv_debug_list_check: no scene");
     if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_debug_list_check: grid_dim must be even and in [2, 2048], got %u", N);
+    if (nz == 0 || z0 >= N || nz > N - z0) return fail(c, "dxv_debug_list_check: slab [%u, %u+%u) outside the grid (N=%u)", z0, z0, nz, N);
     if (c->hdr.treeHeight + 1 > 64) return fail(c, "dxv_debug_list_check: tree too deep for the checker's stack");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
@@ -1483,13 +1493,39 @@ int dxv_debug_list_check(dxv_ctx* c, uint32_t N, uint64_t out[34])
     memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
     memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
     p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
-    p.N = N;
+    p.N = N; p.z0 = z0; p.nz = nz;
     hipError_t e = hipMemsetAsync(dOut, 0, 34 * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) e = launch_list_check(p, dOut, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, 34 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(dOut);
     if (e != hipSuccess) return fail(c, "dxv_debug_list_check failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int dxv_debug_class_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, uint64_t out[34])
+{
+    if (!c || !out) return 1;
+    if (!c->haveScene) return fail(c, "dxv_debug_class_check: no scene");
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_debug_class_check: grid_dim must be even and in [2, 2048], got %u", N);
+    if (nz == 0 || z0 >= N || nz > N - z0) return fail(c, "dxv_debug_class_check: slab [%u, %u+%u) outside the grid (N=%u)", z0, z0, nz, N);
+    if (c->hdr.treeHeight + 1 > 64) return fail(c, "dxv_debug_class_check: tree too deep for the checker's stack");
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
+    if (ensure_nodes(c, c->stream)) return 1;
+    unsigned long long* dOut = nullptr;
+    DXV_HIP(c, hipMalloc(&dOut, 34 * sizeof(unsigned long long)));
+    VoxelizeParams p{};
+    p.scene.nodes = scene_nodes32(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
+    memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
+    memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
+    p.N = N; p.z0 = z0; p.nz = nz;
+    hipError_t e = hipMemsetAsync(dOut, 0, 34 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = launch_class_check(p, dOut, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, 34 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(c, "dxv_debug_class_check failed: %s", hipGetErrorString(e));
     return 0;
 }
 

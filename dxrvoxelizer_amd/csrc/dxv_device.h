@@ -50,6 +50,10 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
                        uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longest,
                        hipStream_t s);
 
+// consistency of a list section that arrived in a blob (dxv_scene_import): out[0] = cells whose range leaves the entries,
+// out[1] = entries whose triangle slot is >= T
+hipError_t dirmap_validate(const DirCell* cells, uint32_t R, const DirEntry* entries, uint32_t n, uint32_t T, uint32_t* out, hipStream_t s);
+
 hipError_t parity_lists_total(const TriPos* triPos, uint32_t T, uint32_t R, unsigned long long* total, hipStream_t s);
 hipError_t parity_lists_fill(const TriPos* triPos, uint32_t T, uint32_t R, uint32_t* counts, uint32_t* offsets, uint32_t* sums, uint32_t* cells,
                              uint32_t* entries, hipStream_t s);
@@ -94,7 +98,8 @@ hipError_t launch_voxelize_planned(const VoxelizeParams& p, uint64_t planId, hip
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack
 int stack_round_up(int want);
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s);   // parity mode: one walk per row run (1) or per 2 x 2 rows (2)
-hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);   // test hook: superset claim of the lists
+hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);   // test hook: superset claim of the lists (slices [p.z0, p.z0 + p.nz))
+hipError_t launch_class_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);  // test hook: per-triangle class of the normal test against the predicate
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
 hipError_t launch_pack_bits(const uint8_t* grid, size_t n, uint8_t* packed, hipStream_t s);
 int num_brick_shapes();

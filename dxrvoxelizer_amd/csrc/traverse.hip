@@ -226,8 +226,8 @@ __global__ __launch_bounds__(64) void k_list_check(VoxelizeParams p, unsigned lo
     const uint32_t N = p.N, nbx = (N + 3u) / 4u;
     const uint32_t b = blockIdx.x, bx = b % nbx, by = (b / nbx) % nbx, bz = b / (nbx * nbx);
     const uint32_t lane = threadIdx.x;
-    const uint32_t ix = bx * 4u + (lane & 3u), iy = by * 4u + ((lane >> 2) & 3u), iz = bz * 4u + (lane >> 4);
-    if (ix >= N || iy >= N || iz >= N) return;
+    const uint32_t ix = bx * 4u + (lane & 3u), iy = by * 4u + ((lane >> 2) & 3u), lz = bz * 4u + (lane >> 4), iz = p.z0 + lz;
+    if (ix >= N || iy >= N || lz >= p.nz) return;
     const SceneView& sc = p.scene;
     Ray r;
     ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void k_list_check(VoxelizeParams p, unsigned lo
     const DirCell cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
     const DirRayLocal loc = dm_ray_local(cx, cy);
     const float near = rho * 0.999f;
-    const size_t id = ((size_t)iz * N + iy) * N + ix;
+    const size_t id = ((size_t)lz * N + iy) * N + ix;
     auto leaf = [&](int32_t l) {
         const TriPos tp = load_tri(sc.triPos, l);
         float lo[3], hi[3], tn, t, b1, b2;
@@ -287,8 +287,54 @@ __global__ __launch_bounds__(64) void k_list_check(VoxelizeParams p, unsigned lo
 
 hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s)
 {
-    const uint32_t nb = (p.N + 3u) / 4u;
-    k_list_check<<<dim3(nb * nb * nb), dim3(64), 0, s>>>(p, out);
+    const uint32_t nb = (p.N + 3u) / 4u, nbz = (p.nz + 3u) / 4u;
+    k_list_check<<<dim3(nb * nb * nbz), dim3(64), 0, s>>>(p, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Test hook (dxv_debug_class_check): the per-triangle class of the normal test (normal_class, dxv_math.h: "every ray of the
+// rule that can hit this triangle gets the same answer from the predicate"), checked against the predicate itself for
+// every closest hit of a grid.  The closest hit comes from the plain LBVH walk (no lists, no shortcut); when its triangle
+// carries a class, the canonical predicate (hlsl:137-138: interpolated normal, normalize, dot > 0.12) is evaluated as for
+// an unclassified triangle and must agree.  out[0] hits on classified triangles, out[1] disagreements, out[2] all hits,
+// out[3 + 2 k], out[4 + 2 k]: voxel id and triangle slot of the first 15 disagreements.  Not a product path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_class_check(VoxelizeParams p, unsigned long long* out)
+{
+    __shared__ int32_t stack[64 * 64];
+    const uint32_t N = p.N, nbx = (N + 3u) / 4u;
+    const uint32_t b = blockIdx.x, bx = b % nbx, by = (b / nbx) % nbx, bz = b / (nbx * nbx);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ix = bx * 4u + (lane & 3u), iy = by * 4u + ((lane >> 2) & 3u), lz = bz * 4u + (lane >> 4), iz = p.z0 + lz;
+    if (ix >= N || iy >= N || lz >= p.nz) return;
+    const SceneView& sc = p.scene;
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return;
+    finish_ray_reference(r);
+    const StridedStack stk{stack + lane, 64};
+    Hit best;
+    if (!trace_reference(r, sc.nodes, sc.triPos, stk, 64, best)) { atomicAdd(out + 1, 1ull); return; }     // (cannot happen: 64 >= any tree height)
+    if (best.k == 0xffffffffu) return;
+    atomicAdd(out + 2, 1ull);
+    const TriPos tp = load_tri(sc.triPos, best.leaf);
+    const uint32_t cls = __builtin_bit_cast(uint32_t, tp.v1.w) >> kClassShift;
+    if (cls == 0u) return;
+    atomicAdd(out, 1ull);
+    const TriNrm tn = sc.triNrm[best.leaf];
+    float nx, ny, nz;
+    const bool in = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz);
+    if (in != (cls == kClassIn)) {
+        const unsigned long long slot = atomicAdd(out + 1, 1ull);
+        if (slot < 15ull) { out[3 + 2 * slot] = ((unsigned long long)lz * N + iy) * N + ix; out[4 + 2 * slot] = (unsigned long long)(uint32_t)best.leaf; }
+    }
+}
+
+hipError_t launch_class_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s)
+{
+    const uint32_t nb = (p.N + 3u) / 4u, nbz = (p.nz + 3u) / 4u;
+    k_class_check<<<dim3(nb * nb * nbz), dim3(64), 0, s>>>(p, out);
     return hipGetLastError();
 }
 

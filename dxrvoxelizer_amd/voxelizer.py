@@ -207,12 +207,23 @@ class Voxelizer:
     def scene_import(self, device_ptr, nbytes):
         self._check(self._lib.dxv_scene_import(self._ctx, C.c_void_p(device_ptr), nbytes))
 
-    def list_check(self, gridDim):
-        """(accepted (ray, triangle) pairs, violations, [(voxel id, triangle slot), ...]) of dxv_debug_list_check."""
+    def list_check(self, gridDim, z0=0, nz=None):
+        """(accepted (ray, triangle) pairs, violations, [(voxel id, triangle slot), ...]) of dxv_debug_list_check over slices
+        [z0, z0 + nz) (default: the whole grid)."""
         out = np.zeros(34, np.uint64)
-        self._check(self._lib.dxv_debug_list_check(self._ctx, int(gridDim), out.ctypes.data_as(C.c_void_p)))
+        nz = gridDim - z0 if nz is None else nz
+        self._check(self._lib.dxv_debug_list_check(self._ctx, int(gridDim), int(z0), int(nz), out.ctypes.data_as(C.c_void_p)))
         nv = int(min(out[1], 16))
         return int(out[0]), int(out[1]), [(int(out[2 + 2 * k]), int(out[3 + 2 * k])) for k in range(nv)]
+
+    def class_check(self, gridDim, z0=0, nz=None):
+        """(hits on classified triangles, disagreements with the predicate, all hits, [(voxel id, triangle slot), ...]) of
+        dxv_debug_class_check."""
+        out = np.zeros(34, np.uint64)
+        nz = gridDim - z0 if nz is None else nz
+        self._check(self._lib.dxv_debug_class_check(self._ctx, int(gridDim), int(z0), int(nz), out.ctypes.data_as(C.c_void_p)))
+        nv = int(min(out[1], 15))
+        return int(out[0]), int(out[1]), int(out[2]), [(int(out[3 + 2 * k]), int(out[4 + 2 * k])) for k in range(nv)]
 
     def debug(self, what):
         st = self.stats()

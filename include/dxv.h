@@ -236,11 +236,19 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
 
-/* Test hook: the superset claim of the direction-space lists, checked for every voxel of a grid_dim^3 grid on the device:
+/* Test hook: the superset claim of the direction-space lists, checked for every voxel of slices [z0, z0 + nz) of a grid_dim^3
+ * grid on the device:
  * every triangle the canonical triangle step accepts for a ray (found by an LBVH walk without distance culling) must be
  * selectable from that ray's texel list.  out[0] = accepted (ray, triangle) pairs, out[1] = violations (must be 0),
  * out[2 + 2k], out[3 + 2k] = voxel id and triangle slot of the first 16 violations.  Builds the lists if needed. */
-DXV_API int dxv_debug_list_check(dxv_ctx* ctx, uint32_t grid_dim, uint64_t out[34]);
+DXV_API int dxv_debug_list_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, uint32_t nz, uint64_t out[34]);
+
+/* Test hook: the per-triangle class of the normal test (most hits of the reference rule are answered from two bits of the hit
+ * triangle's record instead of its interpolated normal) against the predicate itself: for every voxel of
+ * slices [z0, z0 + nz) of a grid_dim^3 grid the closest hit is found by the plain LBVH walk, and when its triangle carries a
+ * class the canonical predicate (hlsl:137-138) is evaluated and compared.  out[0] = hits on classified triangles, out[1] =
+ * disagreements (must be 0), out[2] = all hits, out[3 + 2k], out[4 + 2k] = voxel id and triangle slot of the first 15. */
+DXV_API int dxv_debug_class_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, uint32_t nz, uint64_t out[34]);
 
 /* Test hook: copy an internal device array to the host (enum above). */
 DXV_API int dxv_debug_download(dxv_ctx* ctx, int what, void* host, size_t bytes);

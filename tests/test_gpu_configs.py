@@ -174,3 +174,30 @@ def test_config5_soup10m_512(dxv, configs):
     finally:
         v.close()
         _cache.clear()
+
+
+# The two exactness claims that rest on margin arguments, checked exhaustively at the scale of the configurations: (i) every
+# triangle the canonical step accepts for a ray can be selected from that ray's texel list (dxv_debug_list_check: LBVH walk
+# without distance culling against the lists' integer tests, radial cut and early stop), (ii) a triangle's class of the
+# normal test agrees with the predicate for every closest hit on it (dxv_debug_class_check: plain LBVH walk + hlsl:137-138).
+@pytest.mark.parametrize("name,N,z0,nz", [("dragon9", 512, 0, 512), ("torus1m", 512, 0, 512), ("bunny16", 512, 0, 512),
+                                          ("dragon9", 1024, 384, 128), ("soup1m", 256, 0, 256)])
+def test_lists_and_classes_checked_exhaustively_at_config_scale(dxv, configs, name, N, z0, nz):
+    v = dxv.Voxelizer(0)
+    try:
+        key = f"{name}/{N}/reference"
+        init(v, configs, key)
+        v.set_option("lists", 2)
+        v.Voxelize(64)                                         # (builds the lists the product would use for this scene)
+        if v.stats()["list_entries"]:
+            accepted, violations, first = v.list_check(N, z0, nz)
+            assert accepted > 0 and violations == 0, (key, accepted, violations, first)
+        classified, wrong, hits, first = v.class_check(N, z0, nz)
+        assert hits > 0 and wrong == 0, (key, classified, wrong, first)
+        if name != "soup1m":
+            assert classified > hits // 2, "most hits of a surface mesh land on classified triangles"
+        whole = configs[key]
+        if (z0, nz) == (0, N):
+            assert hits >= whole["solid"]                      # every solid voxel is a hit
+    finally:
+        v.close()

@@ -369,6 +369,19 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     assert sa["list_entries"] == sb["list_entries"] > 0 and sa["list_res"] == sb["list_res"] and sb["list_ms"] == 0.0
     assert np.array_equal(a.Grid(), want) and np.array_equal(b.Grid(), want)
     assert np.array_equal(a.debug(DBG_LIST_CELLS), b.debug(DBG_LIST_CELLS)) and np.array_equal(a.debug(DBG_LIST_ENTRIES), b.debug(DBG_LIST_ENTRIES))
+    # a blob whose header is consistent but whose list payload is not (a texel pointing outside the entries, an entry naming
+    # a triangle the scene does not have) is refused instead of being indexed by the kernel
+    hdr = blob3[:512].cpu().numpy().view(np.uint64)
+    off_cells, off_entries = int(hdr[15]), int(hdr[16])      # SceneHeader: offListCells, offListEntries (dxv_types.h)
+    cells_np = blob3[off_cells:off_cells + 16 * 6 * sb["list_res"] ** 2].cpu().numpy().view(np.uint32).reshape(-1, 4)
+    k = int(np.flatnonzero(cells_np[:, 1] & 0xffff)[0])     # a non-empty texel
+    for off, word, value in ((off_cells + 16 * k, 0, 0x7fffff00), (off_entries, 3, 0x03ffffff)):
+        bad = blob3.clone()
+        bad[off:off + 16].view(torch.int32)[word] = value
+        torch.cuda.synchronize()
+        with pytest.raises(dxv.DxvError, match="inconsistent"):
+            b.scene_import(bad.data_ptr(), n3)
+    b.scene_import(blob3.data_ptr(), n3)                      # (and the good blob again)
     with pytest.raises(dxv.DxvError):
         b.scene_import(blob3.data_ptr(), n3 - 256)         # truncated blob
     b.set_option("listres", 64)                           # an importer that wants another map builds its own
