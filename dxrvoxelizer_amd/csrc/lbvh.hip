@@ -439,11 +439,14 @@ __device__ __forceinline__ Box6 range_box(const TriPos* __restrict__ triPos, uin
     return b;
 }
 
+// nodes32 != NULL: the half-float traversal copy of the node as well, from the registers that hold its exact boxes (the copy
+// kernel would read the 64-byte node back: 640 MB at 10 M triangles)
 template <bool DEPTH>
 __global__ __launch_bounds__(kThreads) void k_refit_ranges(const TriPos* __restrict__ triPos, uint32_t T, uint32_t P,
                                                            const Box6* __restrict__ pyr, const uint32_t* __restrict__ rangeEnd,
                                                            Node* __restrict__ nodes, const uint32_t* __restrict__ depthLeaf,
-                                                           const uint32_t* __restrict__ depthNode, const uint32_t* __restrict__ pyrD)
+                                                           const uint32_t* __restrict__ depthNode, const uint32_t* __restrict__ pyrD,
+                                                           Node32* __restrict__ nodes32)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T - 1) return;
@@ -461,6 +464,48 @@ __global__ __launch_bounds__(kThreads) void k_refit_ranges(const TriPos* __restr
         nodes[i].h0 = deep0 - below;
         nodes[i].h1 = deep1 - below;
     }
+    if (nodes32) {
+        Node n;                                          // (compress_node reads boxes and links only)
+        n.lo0x = b0.lo[0]; n.lo0y = b0.lo[1]; n.lo0z = b0.lo[2]; n.hi0x = b0.hi[0]; n.hi0y = b0.hi[1]; n.hi0z = b0.hi[2];
+        n.lo1x = b1.lo[0]; n.lo1y = b1.lo[1]; n.lo1z = b1.lo[2]; n.hi1x = b1.hi[0]; n.hi1y = b1.hi[1]; n.hi1z = b1.hi[2];
+        n.c0 = c0; n.c1 = nodes[i].c1; n.h0 = n.h1 = 0;
+        nodes32[i] = compress_node(n);
+    }
+}
+
+// K6 from the half-float copy: the four-box node of binary node i is a re-arrangement of half planes that nodes32 already
+// holds -- its own for a leaf child, the child's two boxes for an internal child -- so this pass reads 32-byte nodes (its own
+// and up to two children's) instead of 64-byte ones and converts nothing.  Same words as widen_node (tests).
+__global__ __launch_bounds__(kThreads) void k_widen_from32(const Node32* __restrict__ nodes32, uint32_t n, Node64* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const Node32 me = nodes32[i];
+    Node64 w;
+    int slot = 0;
+    auto emit = [&](const Node32& src, int child, int32_t link) {        // Node32.b: [axis * 4 + {lo0, lo1, hi0, hi1}]
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            w.b[a * 8 + slot] = src.b[a * 4 + child];
+            w.b[a * 8 + 4 + slot] = src.b[a * 4 + 2 + child];
+        }
+        w.c[slot++] = link;
+    };
+    const int32_t link[2] = {me.c0, me.c1};
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        if (link[side] >= 0) {
+            const Node32 m = nodes32[link[side]];
+            emit(m, 0, m.c0);
+            emit(m, 1, m.c1);
+        } else emit(me, side, link[side]);
+    }
+    for (; slot < 4; ++slot) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { w.b[a * 8 + slot] = 0x7c00u; w.b[a * 8 + 4 + slot] = 0xfc00u; }   // [+inf, -inf]
+        w.c[slot] = kNoChild;
+    }
+    out[i] = w;
 }
 
 uint32_t pyramid_slots(uint32_t T)            // entries (24 B box + 4 B depth each) of the pyramid scratch for T leaves
@@ -483,16 +528,16 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
         k_depths<<<blocks_for(T), kThreads, 0, s>>>(b.parents, T, depthLeaf, depthNode);
         k_pyramid_low<true><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, depthLeaf, pyrD);
         if (P > kPyrLeaves) k_pyramid_high<true><<<1, 1024, 0, s>>>(P, pyr, pyrD);
-        k_refit_ranges<true><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, depthLeaf, depthNode, pyrD);
+        k_refit_ranges<true><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, depthLeaf, depthNode, pyrD,
+                                                                    b.deferCopies ? nullptr : b.nodes32);
     } else {
         k_pyramid_low<false><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, nullptr, nullptr);
         if (P > kPyrLeaves) k_pyramid_high<false><<<1, 1024, 0, s>>>(P, pyr, nullptr);
-        k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr);
+        k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr,
+                                                                     b.deferCopies ? nullptr : b.nodes32);
     }
-    if (!b.deferCopies) {
-        if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
-        else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
-    }
+    // (the half-float copy came out of k_refit_ranges' registers; the four-box copy is a re-arrangement of it)
+    if (!b.deferCopies && b.nodes64) k_widen_from32<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes32, numNodes, b.nodes64);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
     return hipGetLastError();
 }
@@ -502,8 +547,8 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
 hipError_t lbvh_traversal_copies(const BuildBuffers& b, hipStream_t s)
 {
     const uint32_t numNodes = b.T > 1 ? b.T - 1 : 1;
-    if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
-    else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    if (b.nodes64) k_widen_from32<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes32, numNodes, b.nodes64);
     return hipGetLastError();
 }
 

@@ -45,6 +45,8 @@ def lib():
         L.i64_destroy.argtypes = [C.c_void_p]
         L.i64_voxelize.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
         L.i64_probe.argtypes = [C.c_void_p] + [C.c_uint32] * 5 + [np.ctypeslib.ndpointer(np.float64, flags="C")]
+        L.i64_voxels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_void_p] * 6
+        L.i64_parity_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p, C.c_double, C.c_void_p, C.c_void_p]
         _L = L
     return _L
 
@@ -66,6 +68,22 @@ class Indep:
         occ, t, k, d, t2 = np.zeros(n, np.uint8), np.zeros(n), np.zeros(n, np.uint32), np.zeros(n), np.zeros(n)
         lib().i64_voxelize(self.h, N, *[a.ctypes.data_as(C.c_void_p) for a in (occ, t, k, d, t2)])
         return occ.reshape(N, N, N), t.reshape(N, N, N), k.reshape(N, N, N), d.reshape(N, N, N), t2.reshape(N, N, N)
+
+    def voxels(self, N, ids):
+        """the same for a list of voxel ids ((iz * N + iy) * N + ix): samples of grids too large to trace whole"""
+        ids = np.ascontiguousarray(ids, np.uint64)
+        n = len(ids)
+        occ, t, k, d, t2 = np.zeros(n, np.uint8), np.zeros(n), np.zeros(n, np.uint32), np.zeros(n), np.zeros(n)
+        lib().i64_voxels(self.h, N, n, ids.ctypes.data_as(C.c_void_p), *[a.ctypes.data_as(C.c_void_p) for a in (occ, t, k, d, t2)])
+        return occ, t, k, d, t2
+
+    def parity_rows(self, N, rows, eps=EPS_LEN):
+        """+X crossing parity of whole grid rows, rows = [(iy, iz), ...]: (occ [nrows, N], near [nrows, N]); near = the count
+        hinges on a crossing within eps of a triangle edge or of the voxel centre (the fill rule's business)"""
+        rows = np.ascontiguousarray(rows, np.uint32).reshape(-1, 2)
+        occ, near = np.zeros((len(rows), N), np.uint8), np.zeros((len(rows), N), np.uint8)
+        lib().i64_parity_rows(self.h, N, len(rows), rows.reshape(-1), float(eps), occ.ctypes.data_as(C.c_void_p), near.ctypes.data_as(C.c_void_p))
+        return occ, near
 
     def probe(self, N, ix, iy, iz, k):
         out = np.zeros(6)
@@ -133,7 +151,92 @@ def compare(name, N=64, golden=None):
     return rec
 
 
+def load_mesh(name):
+    """the three assets (committed loader output) and the synthetic meshes of BASELINE.md section 4, as the fixtures make them"""
+    gold = lambda n: np.load(os.path.join(ROOT, "tests", "golden", "meshes", n + ".npz"))
+    if name in ("bunny", "dragon", "turingbowl"):
+        d = gold(name)
+        return d["vb"], d["ib"]
+    from dxrvoxelizer_amd import meshes                      # (pure numpy generators; no library, no GPU)
+    if name == "dragon9":
+        d = gold("dragon")
+        return meshes.trisect(d["vb"], d["ib"])
+    if name == "bunny16":
+        b = gold("bunny")
+        return meshes.midpoint_subdivide(b["vb"], b["ib"], 2)
+    if name == "torus1m":
+        return meshes.torus()
+    if name == "soup1m":
+        return meshes.soup(1_000_000)
+    raise KeyError(name)
+
+
+def compare_sampled(name, N, n, seed=1):
+    """Reference rule on `n` random voxels of an N^3 grid (grids too large to trace whole with every triangle tested for
+    every ray): half of the sample uniform over the grid, half from the shell of voxels within two voxels of a change of
+    the oracle's grid along x -- where surfaces are."""
+    vb, ib = load_mesh(name)
+    scene = orc.Scene(vb, ib)
+    ind = Indep(vb, ib, scene.bound)
+    rng = np.random.default_rng(seed)
+    zs = np.sort(rng.choice(N, size=min(N, 24), replace=False)).astype(np.uint32)
+    slices = orc.voxelize_slices(scene, N, zs)                                   # the oracle's grid on a few slices (BVH tracer)
+    edge = np.zeros_like(slices, bool)
+    chg = slices[:, :, 1:] != slices[:, :, :-1]
+    for sh in range(-2, 3):
+        lo, hi = max(0, -sh), min(N - 1, N - 1 - sh)
+        edge[:, :, lo + max(sh, 0):hi + max(sh, 0) + 0][:, :, : hi - lo] |= chg[:, :, lo:hi]
+    near_ids = np.argwhere(edge)
+    pick = near_ids[rng.choice(len(near_ids), size=min(n // 2, len(near_ids)), replace=False)]
+    ids_a = (zs[pick[:, 0]].astype(np.uint64) * N + pick[:, 1].astype(np.uint64)) * N + pick[:, 2].astype(np.uint64)
+    ids_b = rng.integers(0, N ** 3, size=n - len(ids_a), dtype=np.uint64)
+    ids = np.unique(np.concatenate([ids_a, ids_b]))
+    occ, t, k, dot, _ = ind.voxels(N, ids)
+    rec = {"N": N, "rule": "reference", "sampled_voxels": int(len(ids)), "near_surface": int(len(ids_a)), "seed": seed, "differ": 0, "voxels": []}
+    solid32 = 0
+    for j, vid in enumerate(ids):
+        ix, iy, iz = int(vid % N), int((vid // N) % N), int(vid // (N * N))
+        occ32 = scene.voxel(N, ix, iy, iz)[0]                                   # the oracle (BVH tracer) at this voxel
+        solid32 += occ32
+        if occ32 == occ[j]:
+            continue
+        label, detail = classify(ind, scene, N, ix, iy, iz, (int(occ[j]), float(t[j]), int(k[j]), float(dot[j])))
+        rec["voxels"].append({"ix": ix, "iy": iy, "iz": iz, "oracle": int(occ32), "fp64": int(occ[j]), "class": label})
+        if label == "unexplained":
+            rec["voxels"][-1]["detail"] = json.loads(json.dumps(detail, default=str))
+    rec["differ"] = len(rec["voxels"])
+    rec["solid_oracle"], rec["solid_fp64"] = int(solid32), int(occ.sum())
+    rec["classes"] = {c: sum(1 for v in rec["voxels"] if v["class"] == c) for c in ("tie", "edge", "threshold", "origin", "unexplained")}
+    return rec
+
+
+def compare_parity(name, N, nslices=None, seed=1):
+    """Parity rule: the oracle's grid against the independent float64 crossing count, whole grid rows (every voxel of the
+    chosen slices; nslices = None: the whole grid).  A voxel whose count hinges on a crossing within EPS_LEN of a triangle
+    edge or of the voxel centre is the fill rule's business (class "edge" when the two differ there); every other voxel
+    must agree."""
+    vb, ib = load_mesh(name)
+    scene = orc.Scene(vb, ib)
+    ind = Indep(vb, ib, scene.bound)
+    rng = np.random.default_rng(seed)
+    zs = np.arange(N, dtype=np.uint32) if nslices is None else np.sort(rng.choice(N, size=nslices, replace=False)).astype(np.uint32)
+    want = orc.voxelize_slices(scene, N, zs, mode=orc.MODE_PARITY)               # [len(zs), N, N] (iy, ix)
+    rows = np.array([(iy, iz) for iz in zs for iy in range(N)], np.uint32)
+    occ, near = ind.parity_rows(N, rows)
+    occ, near = occ.reshape(len(zs), N, N), near.reshape(len(zs), N, N)
+    diff = occ != want
+    rec = {"N": N, "rule": "parity", "slices": [int(z) for z in zs] if nslices is not None else "all", "voxels_compared": int(occ.size),
+           "solid_oracle": int(want.sum()), "solid_fp64": int(occ.sum()), "near_edge_voxels": int(near.sum()), "differ": int(diff.sum()),
+           "classes": {"edge": int((diff & (near != 0)).sum()), "unexplained": int((diff & (near == 0)).sum())}, "voxels": []}
+    for sz, iy, ix in np.argwhere(diff)[:64]:
+        rec["voxels"].append({"ix": int(ix), "iy": int(iy), "iz": int(zs[sz]), "oracle": int(want[sz, iy, ix]), "fp64": int(occ[sz, iy, ix]),
+                              "class": "edge" if near[sz, iy, ix] else "unexplained"})
+    return rec
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        return main_wide()
     names = sys.argv[1:] or ["turingbowl", "bunny", "dragon"]
     path = os.path.join(ROOT, "tests", "golden", "anchor.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
@@ -147,6 +250,34 @@ def main():
         rec["plain_vs_canonical_differ"] = int((plain != golden).sum())
         out[name] = rec
         print(name, {k: v for k, v in rec.items() if k != "voxels"}, flush=True)
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1, sort_keys=True)
+
+
+def main_wide():
+    """Round 3: the anchor beyond 64^3 of the three assets -- their 128^3 grids whole, samples of the BASELINE configurations,
+    and the parity rule.  ~10 minutes of CPU; writes tests/golden/anchor_wide.json."""
+    import time
+    path = os.path.join(ROOT, "tests", "golden", "anchor_wide.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    jobs = [(f"{n}/128/reference", lambda n=n: compare(n, 128)) for n in ("turingbowl", "bunny", "dragon")]
+    jobs += [("dragon9/512/reference/sample", lambda: compare_sampled("dragon9", 512, 12000)),
+             ("torus1m/512/reference/sample", lambda: compare_sampled("torus1m", 512, 12000)),
+             ("soup1m/256/reference/sample", lambda: compare_sampled("soup1m", 256, 12000)),
+             ("bunny16/512/reference/sample", lambda: compare_sampled("bunny16", 512, 8000))]
+    jobs += [(f"{n}/64/parity", lambda n=n: compare_parity(n, 64)) for n in ("bunny", "dragon")]
+    jobs += [(f"{n}/128/parity", lambda n=n: compare_parity(n, 128)) for n in ("bunny", "dragon")]
+    jobs += [("torus1m/512/parity/slices", lambda: compare_parity("torus1m", 512, 6)),
+             ("dragon9/512/parity/slices", lambda: compare_parity("dragon9", 512, 6))]
+    only = sys.argv[2:]
+    for key, job in jobs:
+        if only and not any(o in key for o in only):
+            continue
+        t0 = time.time()
+        rec = job()
+        rec["seconds"] = round(time.time() - t0, 1)
+        out[key] = rec
+        print(key, {k: v for k, v in rec.items() if k not in ("voxels", "slices")}, flush=True)
         with open(path, "w") as fh:
             json.dump(out, fh, indent=1, sort_keys=True)
 

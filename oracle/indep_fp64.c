@@ -142,3 +142,118 @@ API double i64_tri_size(const scene64* s, uint32_t k)
     const double c = sqrt(cx * cx + cy * cy + cz * cz);
     return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
+
+/* The same for a list of voxels (ids in hlsl:64-67 order): what i64_voxelize computes, for samples of grids that are too
+ * large to trace whole with every triangle tested for every ray (1 M triangles at 512^3). */
+API void i64_voxels(const scene64* s, uint32_t N, uint32_t n, const uint64_t* ids, uint8_t* occ, double* tbest, uint32_t* kbest,
+                    double* dotbest, double* tsecond)
+{
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t j = 0; j < (int64_t)n; ++j) {
+        const uint64_t id = ids[j];
+        const uint32_t ix = (uint32_t)(id % N), iy = (uint32_t)((id / N) % N), iz = (uint32_t)(id / ((uint64_t)N * N));
+        double o[3], d[3];
+        ray_of(N, ix, iy, iz, o, d);
+        double t1 = INFINITY, t2 = INFINITY, B1 = 0, B2 = 0;
+        uint32_t k1 = UINT32_MAX;
+        for (uint32_t k = 0; k < s->T; ++k) {
+            double t, b1, b2;
+            if (!plane_hit(s, k, o, d, &t, &b1, &b2)) continue;
+            if (b1 < 0.0 || b2 < 0.0 || b1 + b2 > 1.0 || !(t > 0.0 && t < 10000.0)) continue;
+            if (t < t1) { t2 = t1; t1 = t; k1 = k; B1 = b1; B2 = b2; }
+            else if (t < t2) t2 = t;
+        }
+        double dn = 0.0;
+        if (k1 != UINT32_MAX) dn = dot_normal(s, k1, B1, B2, d);
+        occ[j] = (k1 != UINT32_MAX && dn > 0.12) ? 1 : 0;
+        tbest[j] = t1; kbest[j] = k1; dotbest[j] = dn; tsecond[j] = t2;
+    }
+}
+
+/* The second occupancy rule (north_star's "axis-aligned ray, hit count"; no reference counterpart): occ = parity of the
+ * number of triangles the +X ray from the voxel centre crosses.  Independent statement: float64, every triangle against
+ * every grid row's line (all voxels of a row share it), a crossing counts when the point lies STRICTLY inside the triangle
+ * and strictly right of the voxel centre -- no fill rule, no box, no hierarchy.  Where a line passes within `eps` of an
+ * edge (or a voxel centre within eps of a crossing) the count is a matter of the fill rule: those voxels are flagged
+ * (near = 1) instead of judged.  rows: nrows pairs (iy, iz); occ / near: nrows x N. */
+API void i64_parity_rows(const scene64* s, uint32_t N, uint32_t nrows, const uint32_t* rows, double eps, uint8_t* occ, uint8_t* near)
+{
+#pragma omp parallel
+    {
+        double* xs = (double*)malloc(sizeof(double) * 4096);
+        uint8_t* fl = (uint8_t*)malloc(4096);
+        size_t cap = 4096;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t r = 0; r < (int64_t)nrows; ++r) {
+            const uint32_t iy = rows[2 * r], iz = rows[2 * r + 1];
+            double o[3], d[3] = {1.0, 0.0, 0.0}, dummy[3];
+            ray_of(N, 0, iy, iz, o, dummy);
+            o[0] = -4.0;                                       /* far left of the scene: t = x + 4 */
+            size_t m = 0;
+            for (uint32_t k = 0; k < s->T; ++k) {
+                double t, b1, b2;
+                if (!plane_hit(s, k, o, d, &t, &b1, &b2)) {
+                    /* line parallel to the plane: it may run inside the triangle's plane -- flag the whole row's stretch if the
+                     * line lies within eps of the plane and overlaps the triangle's extent in y and z */
+                    const double nx = s->e1y[k] * s->e2z[k] - s->e1z[k] * s->e2y[k], ny = s->e1z[k] * s->e2x[k] - s->e1x[k] * s->e2z[k],
+                                 nz = s->e1x[k] * s->e2y[k] - s->e1y[k] * s->e2x[k];
+                    const double nn = sqrt(nx * nx + ny * ny + nz * nz);
+                    if (nn > 0.0) {
+                        const double dist = fabs((o[1] - s->ay[k]) * ny + (o[2] - s->az[k]) * nz + (o[0] - s->ax[k]) * nx) / nn;
+                        if (dist <= eps) {
+                            if (m == cap) { cap *= 2; xs = (double*)realloc(xs, sizeof(double) * cap); fl = (uint8_t*)realloc(fl, cap); }
+                            xs[m] = INFINITY; fl[m] = 2; ++m;    /* (flags every voxel of the row: rare, conservative) */
+                        }
+                    }
+                    continue;
+                }
+                const double b0 = 1.0 - b1 - b2;
+                /* distances of the crossing point to the three edges: barycentric x altitude = b x (2 area / |edge|) */
+                const double cx = s->e1y[k] * s->e2z[k] - s->e1z[k] * s->e2y[k], cy = s->e1z[k] * s->e2x[k] - s->e1x[k] * s->e2z[k],
+                             cz = s->e1x[k] * s->e2y[k] - s->e1y[k] * s->e2x[k];
+                const double area2 = sqrt(cx * cx + cy * cy + cz * cz);
+                const double l1 = sqrt(s->e1x[k] * s->e1x[k] + s->e1y[k] * s->e1y[k] + s->e1z[k] * s->e1z[k]);
+                const double l2 = sqrt(s->e2x[k] * s->e2x[k] + s->e2y[k] * s->e2y[k] + s->e2z[k] * s->e2z[k]);
+                const double ex = s->e2x[k] - s->e1x[k], ey = s->e2y[k] - s->e1y[k], ez = s->e2z[k] - s->e1z[k];
+                const double l0 = sqrt(ex * ex + ey * ey + ez * ez);
+                /* b0 is the weight of vertex 0: distance to the edge opposite vertex 0 (length l0); b1: edge v0-v2 (l2); b2: edge v0-v1 (l1) */
+                const double d0 = l0 > 0.0 ? b0 * area2 / l0 : 0.0, d1 = l2 > 0.0 ? b1 * area2 / l2 : 0.0, d2 = l1 > 0.0 ? b2 * area2 / l1 : 0.0;
+                double dm = d0 < d1 ? d0 : d1;
+                dm = dm < d2 ? dm : d2;
+                if (dm < -eps) continue;                       /* clearly outside */
+                if (m == cap) { cap *= 2; xs = (double*)realloc(xs, sizeof(double) * cap); fl = (uint8_t*)realloc(fl, cap); }
+                xs[m] = t - 4.0;
+                /* 0: clearly inside; within eps of an edge (either side): 1 when the triangle faces -X, 3 when it faces +X */
+                fl[m] = dm <= eps ? (cx < 0.0 ? 1 : 3) : 0;
+                ++m;
+            }
+            /* Near-edge crossings in pairs: a line through the shared edge of exactly two triangles crosses the surface once
+             * when both face the same way along X (one crossing: keep one of them as a clear crossing) and not at all, or
+             * twice, when they face opposite ways (a fold seen edge-on: parity unchanged, drop both).  Anything else near an
+             * edge -- a mesh boundary, a vertex with its fan of triangles -- stays flagged. */
+            for (size_t a = 0; a < m; ++a) {
+                if (fl[a] != 1 && fl[a] != 3) continue;
+                size_t mate = m, others = 0;
+                for (size_t b = 0; b < m; ++b)
+                    if (b != a && (fl[b] == 1 || fl[b] == 3 || fl[b] == 4) && fabs(xs[b] - xs[a]) <= 2.0 * eps) { ++others; mate = b; }
+                if (others != 1 || fl[mate] == 4) continue;
+                if (fl[a] == fl[mate]) { fl[a] = 0; fl[mate] = 5; }     /* one clear crossing; 5 = dropped */
+                else { fl[a] = 5; fl[mate] = 5; }
+            }
+            for (uint32_t ix = 0; ix < N; ++ix) {
+                const double ox = (ix + 0.5) / N * 2.0 - 1.0;
+                uint32_t c = 0;
+                uint8_t nr = 0;
+                for (size_t j = 0; j < m; ++j) {
+                    if (fl[j] == 2) { nr = 1; continue; }
+                    if (fabs(xs[j] - ox) <= eps) nr = 1;               /* the voxel centre lies on the surface (t > 0 is at rounding level) */
+                    if (fl[j] == 5) continue;
+                    if (xs[j] > ox) { if (fl[j]) nr = 1; else ++c; }
+                }
+                occ[(size_t)r * N + ix] = (uint8_t)(c & 1u);
+                near[(size_t)r * N + ix] = nr;
+            }
+        }
+        free(xs); free(fl);
+    }
+}
