@@ -100,6 +100,8 @@ struct dxv_ctx {
     int optLists = 1;                // reference rule through the lists (-40...-60 % against the tree walk, profiles/r01/final/ab_lists.jsonl):
                                      // 1 = from a scene's second launch on (from the first when that launch is large: build_lists), 2 = from the first, 0 = tree walk
     int optListRes = 0;              // texels per face side; 0 = by triangle count (list_resolution)
+    uint32_t listResFloor = 0;       // automatic resolution: not below this (512 once the scene has been launched at 1024^3 or beyond:
+    bool listFloorTried = false;     // a texel should stay about two voxels wide -- dragon x9 at 1024^3: 2.82 -> 2.48 ms)
     float listMs = 0.0f;
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
@@ -134,7 +136,7 @@ struct dxv_ctx {
     int optPlists = 1;               // 1 = from a scene's second parity launch, 2 = from the first, 0 = tree walk
     uint32_t parityLaunchesOfScene = 0;
     float plMs = 0.0f;
-    bool nodesStale = false;         // a refit left nodes32 / nodes64 behind (ensure_nodes brings them up to date before anything reads them)
+    bool nodesStale = false;         // a build / refit left the four-box copy (nodes64) behind (ensure_nodes brings it up to date before anything reads it)
     int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
     size_t emptyCap = 0;
@@ -321,18 +323,20 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
 {
     const uint32_t T = c->hdr.numTris;
     uint32_t R = list_resolution(c);
+    if (!c->optListRes && c->listResFloor > R) R = c->listResFloor;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, stream);
     const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
     // scratch in two allocations (an allocation costs ~0.1 ms, as much as a pass): per-(triangle, face)
     // arrays now, the key buffers once the number of entries is known
-    // (kept with the context up to 1 GiB each: an allocation costs ~0.1 ms, as much as a pass of the build)
+    // (kept with the context up to 16 GiB each: an allocation costs ~0.1 ms, as much as a pass of the build -- and hundreds of ms
+    // for the gigabytes of a 10 M-triangle scene)
     uint8_t *scratchA = nullptr, *scratchB = nullptr;
     auto scratch = [&](uint8_t*& keep, size_t& cap, size_t bytes, uint8_t*& out) -> hipError_t {
         if (bytes <= cap) { out = keep; return hipSuccess; }
         (void)hipFree(keep); keep = nullptr; cap = 0;
         const hipError_t err = hipMalloc(&out, bytes);
-        if (err == hipSuccess && bytes <= (1ull << 30)) { keep = out; cap = bytes; }
+        if (err == hipSuccess && bytes <= (16ull << 30)) { keep = out; cap = bytes; }    // (kept: a multi-GB hipMalloc is 0.1 - 0.3 s, ten builds' worth)
         return err;
     };
     auto release = [&]() {
@@ -663,6 +667,15 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         if (sync_frames(c)) return 1;
         if (build_lists(c, fs, voxels)) return 1;
     }
+    // A scene that has lists on the 256 map and is now launched (again) at 1024^3 or beyond: once, the 512 map instead -- the
+    // map that suits a grid keeps a texel about two voxels wide (measured: 128^3 -> R 128, 256^3 and 512^3 -> 256, 1024^3 -> 512;
+    // profiles/r03/ab_listres_vs_grid.jsonl).  Deep scenes fall back to their coarse map inside build_lists.
+    if (p.mode == DXV_MODE_REFERENCE && c->optLists && !c->optListRes && c->listState == 1 && c->listRes < 512u && p.N >= 1024u &&
+        !c->listFloorTried && c->launchesOfScene > 0 && c->hdr.numTris >= 20000u) {
+        if (sync_frames(c)) return 1;
+        c->listResFloor = 512u; c->listFloorTried = true;
+        if (build_lists(c, fs)) return 1;
+    }
     const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists &&
                            (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0);
     if (p.mode == DXV_MODE_REFERENCE) ++c->launchesOfScene;
@@ -856,7 +869,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -964,14 +977,15 @@ int dxv_refit(dxv_ctx* c)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0;
+    c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0;
     if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
     fill_build_buffers(c, b);
     if (c->optRefit != 1) b.pyramid = nullptr;
-    // the walks' copies of the hierarchy (0.12 ms of the refit's 0.25 at 1 M triangles) wait until a walk needs them: the
-    // next launch of a refitted mesh usually goes through the lists, which are built from the triangle records alone
-    b.deferCopies = c->optLists != 0;
+    // the wide walks' four-box copy of the hierarchy waits until a walk needs it: the next launch of a refitted mesh usually
+    // goes through the lists, which are built from the triangle records alone (the half-float copy comes out of the box
+    // merge's registers and is always current)
+    b.deferCopies = c->optLists != 0 && c->hdr.hasWide;
     DXV_HIP(c, lbvh_refit(b, c->optRefit, c->hdr.treeHeight, c->stream, c->ev + 3));
     c->nodesStale = b.deferCopies;
     if (finish_build(c, "dxv_refit")) return 1;
@@ -985,7 +999,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -994,7 +1008,9 @@ int dxv_build(dxv_ctx* c)
     BuildBuffers b{};
     fill_build_buffers(c, b);
     if (c->optRefit != 1) b.pyramid = nullptr;
+    b.deferCopies = c->optLists != 0 && c->hdr.hasWide;                // (as in dxv_refit: 0.6 ms of a 10 M-triangle build that most scenes never need)
     DXV_HIP(c, lbvh_build(b, c->optRefit, c->stream, c->ev));
+    c->nodesStale = b.deferCopies;
     if (finish_build(c, "dxv_build")) return 1;
     c->haveHierarchy = true;
     c->stats.prep_ms = elapsed(c->ev[0], c->ev[1]);
@@ -1324,7 +1340,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         (withLists && (h.offListCells != b.offCells || h.offListEntries != b.offEntries)) || (!withLists && (h.offListCells || h.offListEntries || h.listCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
     // triangle count over the old, smaller buffers.

@@ -32,14 +32,14 @@ struct BuildBuffers {
     Node64* nodes64;        // max(T-1,1), wide traversal copy
     TriPos* triPos;         // T
     TriNrm* triNrm;         // T
-    bool deferCopies;       // refit only: leave nodes32 / nodes64 stale (lbvh_traversal_copies brings them up to date when a walk needs them)
+    bool deferCopies;       // leave the four-box copy (nodes64) stale: lbvh_traversal_copies brings it up to date when a walk needs it (nodes32 always is)
 };
 struct BuildTimes { float prep, sort, hierarchy, refit; };
 // refitMode: 0 = one pass, bottom-up with per-node arrival counters; 1 = level-synchronous sweeps
 hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEvent_t ev[5]);
 uint32_t pyramid_slots(uint32_t T);
 hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight, hipStream_t s, hipEvent_t ev[2]);
-hipError_t lbvh_traversal_copies(const BuildBuffers& b, hipStream_t s);   // nodes -> nodes32 (+ nodes64): the copies the tree walks read
+hipError_t lbvh_traversal_copies(const BuildBuffers& b, hipStream_t s);   // nodes32 -> nodes64: the four-box copy the wide tree walks read
 
 // dirmap.hip -- direction-space lists of the reference rule (dxv_dirmap.h)
 struct DirEntry;

@@ -7,8 +7,10 @@
 //   K2b k_tri_gather   per Morton slot: write the 48-B position and normal records
 //   K3  k_hierarchy    Karras 2012, one thread per internal node, parent links
 //   K4  k_refit_*      bottom-up box merge; a node stores the boxes of BOTH children
-//   K5  k_compress_nodes  32-B traversal copy of every node (outward-rounded half-float boxes)
-//   K6  k_widen_nodes  64-B wide traversal copy: up to four boxes per node (reference rule)
+//   K5  32-B traversal copy of every node (outward-rounded half-float boxes): written by k_refit_ranges from the registers
+//       that hold the exact boxes (k_compress_nodes for the sweep / atomic variants of K4)
+//   K6  k_widen_from32  64-B wide traversal copy: up to four boxes per node (reference rule), re-arranged from the
+//       32-B copies of the node and its children; made when a wide walk first needs it
 //
 // All kernels are HBM-streaming integer/float work: one thread per element, 16-B accesses where
 // the layout allows, no LDS needed outside the sort.
@@ -220,17 +222,6 @@ __global__ __launch_bounds__(kThreads) void k_compress_nodes(const Node* __restr
     if (i < n) out[i] = compress_node(nodes[i]);
 }
 
-// K6: wide traversal copy (dxv_types.h Node64): every binary node with its internal children
-// replaced by their children.  A pure gather from the refitted nodes, so a refit only re-runs it.
-__global__ __launch_bounds__(kThreads) void k_widen_nodes(const Node* __restrict__ nodes, uint32_t n, Node32* __restrict__ out32,
-                                                          Node64* __restrict__ out)
-{
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    out32[i] = compress_node(nodes[i]);         // K5 in the same pass when both copies are wanted
-    out[i] = widen_node(nodes, (int32_t)i);
-}
-
 // rootInfo: lo[3], hi[3] (float bits), height of the root, 1
 __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict__ rootInfo,
                             const uint32_t* __restrict__ rootReady)
@@ -283,10 +274,8 @@ static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t 
             rootReadyFlag = ready;
         }
     }
-    if (!b.deferCopies) {
-        if (b.nodes64) k_widen_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32, b.nodes64);
-        else k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
-    }
+    k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
+    if (!b.deferCopies && b.nodes64) k_widen_from32<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes32, numNodes, b.nodes64);
     k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, rootReadyFlag);
     return hipGetLastError();
 }
@@ -528,13 +517,11 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
         k_depths<<<blocks_for(T), kThreads, 0, s>>>(b.parents, T, depthLeaf, depthNode);
         k_pyramid_low<true><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, depthLeaf, pyrD);
         if (P > kPyrLeaves) k_pyramid_high<true><<<1, 1024, 0, s>>>(P, pyr, pyrD);
-        k_refit_ranges<true><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, depthLeaf, depthNode, pyrD,
-                                                                    b.deferCopies ? nullptr : b.nodes32);
+        k_refit_ranges<true><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, depthLeaf, depthNode, pyrD, b.nodes32);
     } else {
         k_pyramid_low<false><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, nullptr, nullptr);
         if (P > kPyrLeaves) k_pyramid_high<false><<<1, 1024, 0, s>>>(P, pyr, nullptr);
-        k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr,
-                                                                     b.deferCopies ? nullptr : b.nodes32);
+        k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr, b.nodes32);
     }
     // (the half-float copy came out of k_refit_ranges' registers; the four-box copy is a re-arrangement of it)
     if (!b.deferCopies && b.nodes64) k_widen_from32<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes32, numNodes, b.nodes64);
@@ -542,12 +529,11 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
     return hipGetLastError();
 }
 
-// The copies of the hierarchy the tree walks read (half-float boxes; four-box nodes), from the exact nodes: what a refit
-// with deferCopies left undone -- a scene whose next launch goes through the direction-space lists never needs them.
+// The four-box copy of the hierarchy (what the wide tree walks read) from the half-float one: what a build or refit with
+// deferCopies left undone -- a scene whose launches go through the direction-space lists never needs it.
 hipError_t lbvh_traversal_copies(const BuildBuffers& b, hipStream_t s)
 {
     const uint32_t numNodes = b.T > 1 ? b.T - 1 : 1;
-    k_compress_nodes<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes, numNodes, b.nodes32);
     if (b.nodes64) k_widen_from32<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes32, numNodes, b.nodes64);
     return hipGetLastError();
 }

@@ -73,3 +73,20 @@ def test_header_is_plain_c(tmp_path):
                            "-o", str(tmp_path / "use.o")])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "voxelize_obj.cpp")])
+
+
+def test_cpp_multi_gpu_host_compiles_and_links(tmp_path, dxvlib):
+    """include/dxv_multi.hpp (one context per device, scene broadcast through the RCCL C API, slab / block-cyclic Voxelize, no
+    Python) must compile as plain C++17 against the HIP and RCCL headers and link with libdxv.so + libamdhip64 + librccl;
+    it runs in the -m gpu suite (tests/test_gpu_parity.py::test_cpp_multi_gpu_host)."""
+    import subprocess
+    rocm = "/opt/rocm"
+    if not os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")):
+        pytest.skip("no RCCL headers on this machine")
+    exe = tmp_path / "multi_gpu"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "multi_gpu.cpp"), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "dxrvoxelizer_amd"), "-l:libdxv.so", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dxrvoxelizer_amd"), "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr          # (no arguments: usage, no GPU touched)

@@ -137,6 +137,8 @@ def test_config4_dragon9_1024_slabs_and_block_cyclic(dxv, configs):
                 v.VoxelizeInterleaved(N, r, W, blk)
                 assert sha(v.Grid()) == want["cyclic8x8_sha256"][r], f"block-cyclic rank {r} lists={lists}"
             if lists == 2:
+                # (launched at 1024^3 more than once: the lists have moved to the 512 map, a texel stays ~2 voxels wide)
+                assert v.stats()["list_res"] == 512
                 # every rank's share through its dispatch plan (what bench.py --gpus 8 runs), and two slabs
                 v.set_option("plan", 2)
                 for r in range(W):

@@ -548,6 +548,35 @@ def test_cpp_voxelizer_mirror(orc, tmp_path):
     assert np.array_equal(g, want) and int(r.stdout.strip()) == int(want.sum())
 
 
+def test_cpp_multi_gpu_host(orc, bunny, grids_json, tmp_path):
+    """The multi-GPU host in C++ (include/dxv_multi.hpp): device-set constructor, rank-0 build, ncclBroadcast of the scene blob
+    through the RCCL C API, block-cyclic and slab Voxelize, reassembly -- no Python in the path.  Runs with the devices this
+    box has (one here: the same code path as N) and must reproduce the oracle's bunny grid at 128^3."""
+    vb, ib, _ = bunny
+    mesh = tmp_path / "bunny.bin"
+    with open(mesh, "wb") as fh:
+        fh.write(np.array([len(vb), len(ib) // 3], np.uint32).tobytes())
+        fh.write(np.ascontiguousarray(vb, np.float32).tobytes())
+        fh.write(np.ascontiguousarray(ib, np.uint32).tobytes())
+    rocm = "/opt/rocm"
+    exe = tmp_path / "multi_gpu"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "multi_gpu.cpp"), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "dxrvoxelizer_amd"), "-l:libdxv.so", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dxrvoxelizer_amd"), "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    out = tmp_path / "grid.bin"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([str(exe), str(mesh), "128", str(out)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    solid, ndev, blob = (int(x) for x in r.stdout.split())
+    want = grids_json["bunny/128/reference"]
+    assert solid == want["solid"] and ndev >= 1 and blob > 0
+    g = np.fromfile(out, np.uint8).reshape(128, 128, 128)
+    assert sha(g) == want["sha256"]
+    assert np.array_equal(g, orc.Scene(vb, ib).voxelize(128))
+
+
 # ---------------------------------------------------------------------------------------------
 # full size (BASELINE.json: 1 M-triangle mesh at 512^3)
 # ---------------------------------------------------------------------------------------------
