@@ -239,6 +239,7 @@ __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict
 }
 
 static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStream_t s);
+__global__ void k_widen_from32(const Node32* __restrict__ nodes32, uint32_t n, Node64* __restrict__ out);    // (below, with the pyramid refit)
 
 // K4 + K5 + root info over an existing hierarchy (links and parent words in place).
 static hipError_t refit_stage(const BuildBuffers& b, int refitMode, hipStream_t s, uint32_t knownHeight = 0)
