@@ -54,6 +54,12 @@ def algorithmic_bytes(N, nz, T, V):
     return N * N * nz * 1 + (2 * T - 1) * 32 + T * 12 + V * 24
 
 
+def build_bytes(T, passes=4):
+    """SURVEY.md section 8(d), B_build: three positions per triangle read, one 64-bit key written, `passes` radix passes of
+    8 B read + 8 B written per key, every 32-byte node written once, two child boxes read per internal node."""
+    return T * 36 + T * 8 + passes * 16 * T + (2 * T - 1) * 32 + (T - 1) * 64
+
+
 def cpu_baseline(vb, ib, N, mode, budget_s=15.0):  # (N > 1: a shorter sample, the other ranks wait for rank 0)
     """The oracle's scalar BVH voxelizer ('port': the reference has no CPU path) on a bounded
     sample of the same workload: evenly spaced Z slices, all host cores (OpenMP over rows)."""
@@ -194,6 +200,8 @@ def main():
     if rank == 0:
         vb, ib, label = make_mesh(args.mesh)
         vox.InitFromArrays(vb, ib)               # upload + LBVH build (not part of a step)
+        cold_build_ms = vox.stats()["build_ms"]  # (the first build of a process pays for code loading and allocations)
+        vox.InitFromArrays(vb, ib)               # ... the same again: the figure config.build_roofline is made from
     if use_dist:
         torch.cuda.synchronize()
         dist.barrier()
@@ -394,8 +402,13 @@ def main():
                        "candidates": ({"structure": "direction-space lists", "texels_per_face_side": st_run["list_res"],
                                        "entries": st_run["list_entries"], "build_ms": st_run["list_ms"]}
                                       if st_run.get("list_entries") else {"structure": "LBVH walk"}),
-                       "build_ms": st0["build_ms"], "build_stages_ms": {k: st0[k] for k in
-                                                                       ("prep_ms", "sort_ms", "hierarchy_ms", "refit_ms")},
+                       "build_ms": st0["build_ms"], "build_ms_first_in_process": cold_build_ms,
+                       "build_stages_ms": {k: st0[k] for k in ("prep_ms", "sort_ms", "hierarchy_ms", "refit_ms")},
+                       "build_roofline": {"bound": "hbm", "bytes": build_bytes(T), "ms": st0["build_ms"],
+                                          "achieved": build_bytes(T) / (st0["build_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "frac": build_bytes(T) / (st0["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                          "note": "LBVH build of this mesh (keys, 4-pass radix sort, hierarchy, boxes, half-float node copy), "
+                                                  "B_build of SURVEY.md 8(d); the 10 M-triangle build of config 5: profiles/r03/build_soup10m.jsonl"},
                        "upload_ms": st0["upload_ms"], "scene_broadcast_ms": bcast_ms,
                        "kernel_ms_max_over_ranks": kmax, "rank_kernel_ms": rank_kernel_ms, "rank_ms_per_step": rank_wall_ms,
                        "rank_imbalance": max(rank_kernel_ms) / (sum(rank_kernel_ms) / len(rank_kernel_ms)) if min(rank_kernel_ms) > 0 else None,

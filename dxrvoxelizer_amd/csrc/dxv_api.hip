@@ -416,7 +416,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     }
     if ((size_t)n > c->listEntryCap) {
         (void)hipFree(c->dListEntries); c->dListEntries = nullptr; c->listEntryCap = 0;
-        if ((e = hipMalloc(&c->dListEntries, ((size_t)n + 1) * sizeof(DirEntry))) != hipSuccess) return bail(e, "hipMalloc");
+        if ((e = hipMalloc(&c->dListEntries, ((size_t)n + 4) * sizeof(DirEntry))) != hipSuccess) return bail(e, "hipMalloc");   // (+ spare ones: a scan round loads four)
         c->listEntryCap = n;
     }
     const size_t keyBytes = align256(((size_t)n + 1) * 8);
@@ -1360,7 +1360,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         }
         if ((size_t)h.listCount > c->listEntryCap) {
             (void)hipFree(c->dListEntries); c->dListEntries = nullptr; c->listEntryCap = 0;
-            DXV_HIP(c, hipMalloc(&c->dListEntries, ((size_t)h.listCount + 1) * sizeof(DirEntry)));
+            DXV_HIP(c, hipMalloc(&c->dListEntries, ((size_t)h.listCount + 4) * sizeof(DirEntry)));
             c->listEntryCap = h.listCount;
         }
         const uint8_t* in = static_cast<const uint8_t*>(src);

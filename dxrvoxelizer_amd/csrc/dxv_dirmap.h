@@ -521,29 +521,34 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
     bestDet = 1.0f;                                                     // divisor of the closest hit's barycentrics (the caller's finish_hit)
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
     DirRayLocal loc = dm_ray_local(cx, cy);
-    uint32_t rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);   // radial cut: r1 >= near, r0 not beyond the closest hit so far
+    float bound = (rho + best.t) * 1.001f + 1e-4f;                      // how far out an entry may start and still matter: behind the closest hit so far
+    uint32_t rc = dm_radial_word(near, bound);                          // radial cut: r1 >= near, r0 not beyond `bound`
     for (;;) {
         // four entries per round, all four loads in flight before the first is looked at (two per round:
-        // +13 % on the 1 M-triangle scene, one: +40 %)
+        // +13 % on the 1 M-triangle scene, one: +40 %).  One address, four offsets: entries behind the end of the list are
+        // loaded and not looked at (the next texel's, or the three spare ones behind the last list).
         if (i < end) {
             const uint32_t last = end - 1u;
             // (the third and fourth load are skipped when no lane of the wave has that many entries left:
             // -5 % on the 1 M-triangle scene; voting on the second one as well: +7 %)
             const bool wide = wave_any(i + 2u <= last);
-            const DirEntry e0 = dm.entries[i], e1 = dm.entries[i + 1u < last ? i + 1u : last];
-            DirEntry e2 = e0, e3 = e0;
-            if (wide) { e2 = dm.entries[i + 2u < last ? i + 2u : last]; e3 = dm.entries[i + 3u < last ? i + 3u : last]; }
+            const DirEntry* p = dm.entries + i;
+            const DirEntry e0 = p[0], e1 = p[1];
+            DirEntry e2, e3;
+            if (wide) { e2 = p[2]; e3 = p[3]; }
             // The list is sorted by far radius and every entry knows (in 63rds of the texel's thickest entry) how far behind
             // its far radius the earliest start of any LATER entry lies: once that point is beyond the closest hit so far,
             // this entry and everything behind it start beyond the hit.  (Surface meshes have short lists and gain
             // little; in a deep soup a ray stops after the first few of hundreds of entries.)
-            if (dm_stop_radius(e0, step) > (rho + best.t) * 1.001f + 1e-4f) i = end;
+            if (dm_stop_radius(e0, step) > bound) i = end;
             else {
                 // (a queued item is two words: the triangle, and the entry's radial word for the second look below)
                 if (dm_local_pass(e0, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e0)); stk.put(2 * qn + 1, (int32_t)e0.rr); ++qn; }
                 if (i + 1u <= last && dm_local_pass(e1, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e1)); stk.put(2 * qn + 1, (int32_t)e1.rr); ++qn; }
-                if (i + 2u <= last && dm_local_pass(e2, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e2)); stk.put(2 * qn + 1, (int32_t)e2.rr); ++qn; }
-                if (i + 3u <= last && dm_local_pass(e3, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e3)); stk.put(2 * qn + 1, (int32_t)e3.rr); ++qn; }
+                if (wide) {
+                    if (i + 2u <= last && dm_local_pass(e2, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e2)); stk.put(2 * qn + 1, (int32_t)e2.rr); ++qn; }
+                    if (i + 3u <= last && dm_local_pass(e3, loc, rc)) { stk.put(2 * qn, (int32_t)dm_entry_tri(e3)); stk.put(2 * qn + 1, (int32_t)e3.rr); ++qn; }
+                }
                 i += 4u;
             }
         }
@@ -564,7 +569,8 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
                 if (!wave_any(k < qn)) break;
                 if (k < qn) {
                     leaf_reference_deferred(r, tris, stk.get(2 * k), best, bestDet);
-                    rc = dm_radial_word(near, (rho + best.t) * 1.001f + 1e-4f);
+                    bound = (rho + best.t) * 1.001f + 1e-4f;
+                    rc = dm_radial_word(near, bound);
                     ++k;
                 }
             }

@@ -139,7 +139,7 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
     std::sort(keys.begin(), keys.end());
     s->dmR = R;
     s->dmCells.assign((size_t)6 * R * R, DirCell{0, 0, 0, 0, 0, 0, 0});
-    s->dmEntries.resize(keys.size());
+    s->dmEntries.assign(keys.size() + 3, DirEntry{0, 0, 0, 0});          // (+ three spare ones: a scan round loads four)
     for (size_t i = 0; i < keys.size(); ++i) {
         const uint32_t cell = dm_key_cell(lay, keys[i]), t = dm_key_tri(lay, keys[i]);
         const DirRecord& rc = rec[(size_t)t * 6 + cell / (R * R)];
@@ -237,7 +237,7 @@ __attribute__((visibility("default"))) void hc_dirmap_get(void* p, void* cells, 
 {
     HcScene* s = static_cast<HcScene*>(p);
     memcpy(cells, s->dmCells.data(), s->dmCells.size() * sizeof(DirCell));
-    memcpy(entries, s->dmEntries.data(), s->dmEntries.size() * sizeof(DirEntry));
+    memcpy(entries, s->dmEntries.data(), (s->dmEntries.size() - 3) * sizeof(DirEntry));
 }
 
 __attribute__((visibility("default"))) void hc_scene_nodes32(void* p, void* out) { auto* s = static_cast<HcScene*>(p); memcpy(out, s->nodes32.data(), s->nodes32.size() * sizeof(Node32)); }

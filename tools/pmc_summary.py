@@ -8,6 +8,11 @@ import sys
 from collections import defaultdict
 
 
+def kind(name):
+    """k_voxelize launched through a dispatch plan (last template argument true) and over the brick box are different kernels"""
+    return "k_voxelize_plan" if name.rstrip().endswith("true>(dxv::VoxelizeParams)") or ", true>" in name.split("(")[0][-12:] else "k_voxelize"
+
+
 def main():
     d = sys.argv[1]
     per = defaultdict(lambda: defaultdict(list))
@@ -19,15 +24,15 @@ def main():
                 name = row["Kernel_Name"]
                 if "dxv::k_voxelize" not in name or "redo" in name:
                     continue
-                disp[row["Dispatch_Id"]][row["Counter_Name"]] = float(row["Counter_Value"])
-        for _, c in disp.items():
+                disp[(row["Dispatch_Id"], kind(name))][row["Counter_Name"]] = float(row["Counter_Value"])
+        for (_, kd), c in disp.items():
             for k, v in c.items():
-                per["k_voxelize"][k].append(v)
+                per[kd][k].append(v)
     for kt in glob.glob(os.path.join(d, "*", "*", "*_kernel_trace.csv")):
         with open(kt) as fh:
             for row in csv.DictReader(fh):
                 if "dxv::k_voxelize" in row["Kernel_Name"] and "redo" not in row["Kernel_Name"]:
-                    dur["k_voxelize"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+                    dur[kind(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
     out = {}
     for k, c in per.items():
         m = {n: sum(v) / len(v) for n, v in c.items()}
