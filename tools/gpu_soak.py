@@ -48,7 +48,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed)
     v = dxv.Voxelizer(0)
-    t0, cases, grids, checked = time.time(), 0, 0, 0
+    t0, cases, grids, checked, classes = time.time(), 0, 0, 0, 0
     while time.time() - t0 < budget:
         (vb, ib), label = random_mesh(rng)
         T = len(ib) // 3
@@ -71,25 +71,30 @@ def main():
                     "wide": int(rng.integers(0, 3)), "brick": int(rng.integers(0, 8)), "stack": int(rng.choice([0, 0, 12, 16, 32])),
                     "subbox": int(rng.integers(0, 2)), "morton": int(rng.integers(0, 2)),
                     "lists": int(rng.integers(0, 3)), "listres": int(rng.choice([0, 0, 16, 64, 512, 2048])),
-                    "plists": int(rng.integers(0, 3)), "plistres": int(rng.choice([0, 0, 16, 128, 1024]))}
+                    "plists": int(rng.integers(0, 3)), "plistres": int(rng.choice([0, 0, 16, 128, 1024])),
+                    "plan": int(rng.integers(0, 3)), "planorder": int(rng.integers(0, 4))}
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))
             v.SetFrame(int(rng.integers(0, 3)))               # any of the context's frames in flight
+            again = int(rng.choice([1, 1, 2, 3]))             # the same launch again: kept memsets, dispatch plans from the second launch on
             try:
                 if part == 0:
-                    v.Voxelize(N, mode)
+                    for _ in range(again):
+                        v.Voxelize(N, mode)
                     got, ref = v.Grid(), want
                 elif part == 1:
                     z0 = int(rng.integers(0, N)); nz = int(rng.integers(1, N - z0 + 1))
-                    v.Voxelize(N, mode, z0, nz)
+                    for _ in range(again):
+                        v.Voxelize(N, mode, z0, nz)
                     got, ref = v.Grid(), want[z0:z0 + nz]
                 else:
                     world = int(rng.choice([1, 2, 4])); zb = int(rng.choice([1, 2, 4, 8]))
                     if N % (world * zb):
                         continue
                     rank = int(rng.integers(0, world))
-                    v.VoxelizeInterleaved(N, rank, world, zb, mode)
+                    for _ in range(again):
+                        v.VoxelizeInterleaved(N, rank, world, zb, mode)
                     zs = np.concatenate([np.arange(b, b + zb) for b in range(rank * zb, N, world * zb)])
                     got, ref = v.Grid(), want[zs]
             except dxv.DxvError as e:
@@ -110,6 +115,12 @@ def main():
                                       "opts": opts, "seed": seed}))
                     sys.exit(1)
                 checked += accepted
+            if mode == 0 and T * N ** 3 < 2e9 and rng.integers(0, 3) == 0:
+                classified, wrong, hits, first = v.class_check(N)      # the per-triangle class of the normal test against the predicate
+                if wrong:
+                    print(json.dumps({"FAIL": label, "class_check": int(wrong), "first": [list(map(int, x)) for x in first[:4]], "T": T, "N": N, "seed": seed}))
+                    sys.exit(1)
+                classes += classified
             if part == 0 and rng.integers(0, 4) == 0:      # display pass: the empty-brick skip changes no pixel
                 eye, vp = camera.default_view_proj(96, 64, eye=tuple(float(x) for x in rng.uniform(-12, 12, 3) + np.array([0, 0, 14.0])))
                 v.set_option("skipempty", 1)
@@ -118,7 +129,7 @@ def main():
                 b = v.Render(eye, vp, 96, 64)
                 v.set_option("skipempty", 1)
                 assert np.array_equal(a, b), (label, N)
-    print(json.dumps({"soak": "ok", "seconds": round(time.time() - t0, 1), "meshes": cases, "grids": grids, "list_pairs_checked": int(checked), "seed": seed}))
+    print(json.dumps({"soak": "ok", "seconds": round(time.time() - t0, 1), "meshes": cases, "grids": grids, "list_pairs_checked": int(checked), "class_hits_checked": int(classes), "seed": seed}))
 
 
 if __name__ == "__main__":
