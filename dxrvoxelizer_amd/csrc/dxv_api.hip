@@ -634,7 +634,9 @@ dxv_ctx::Plan* plan_for(dxv_ctx* c, const VoxelizeParams& p, hipStream_t stream,
     return done(hipSuccess, "");
 }
 
-int launch_now(dxv_ctx* c, uint32_t frame)
+// relaunch: the same launch again with a deeper column (sync_frame, after a walk reported an overflow) -- possibly on behalf of
+// a caller that is about to replace the scene (sync_frames): it builds nothing, it takes the candidate structures that exist.
+int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
 {
     Frame& f = c->frames[frame];
     const hipStream_t fs = frame_stream(c, frame);
@@ -663,22 +665,22 @@ int launch_now(dxv_ctx* c, uint32_t frame)
     // (... unless the launch is large enough for the build to pay for itself at once: build_lists decides after its
     // counting pass -- 1 M triangles at 512^3: 0.65 ms of build + 1.0 ms against 2.7 ms through the tree)
     const uint64_t voxels = (uint64_t)p.N * p.N * p.nz;
-    if (p.mode == DXV_MODE_REFERENCE && c->optLists == 1 && c->launchesOfScene == 0 && c->listState == 0 && voxels >= (1ull << 26)) {
+    if (!relaunch && p.mode == DXV_MODE_REFERENCE && c->optLists == 1 && c->launchesOfScene == 0 && c->listState == 0 && voxels >= (1ull << 26)) {
         if (sync_frames(c)) return 1;
         if (build_lists(c, fs, voxels)) return 1;
     }
     // A scene that has lists on the 256 map and is now launched (again) at 1024^3 or beyond: once, the 512 map instead -- the
     // map that suits a grid keeps a texel about two voxels wide (measured: 128^3 -> R 128, 256^3 and 512^3 -> 256, 1024^3 -> 512;
     // profiles/r03/ab_listres_vs_grid.jsonl).  Deep scenes fall back to their coarse map inside build_lists.
-    if (p.mode == DXV_MODE_REFERENCE && c->optLists && !c->optListRes && c->listState == 1 && c->listRes < 512u && p.N >= 1024u &&
+    if (!relaunch && p.mode == DXV_MODE_REFERENCE && c->optLists && !c->optListRes && c->listState == 1 && c->listRes < 512u && p.N >= 1024u &&
         !c->listFloorTried && c->launchesOfScene > 0 && c->hdr.numTris >= 20000u) {
         if (sync_frames(c)) return 1;
         c->listResFloor = 512u; c->listFloorTried = true;
         if (build_lists(c, fs)) return 1;
     }
     const bool wantLists = p.mode == DXV_MODE_REFERENCE && c->optLists &&
-                           (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0);
-    if (p.mode == DXV_MODE_REFERENCE) ++c->launchesOfScene;
+                           (relaunch ? c->listState == 1 && c->listOpt == c->optListRes : (c->optLists == 2 || c->launchesOfScene > 0 || c->listState != 0));
+    if (p.mode == DXV_MODE_REFERENCE && !relaunch) ++c->launchesOfScene;
     if (wantLists) {
         if (c->listState == 0 || (c->listState != 0 && c->listOpt != c->optListRes)) {
             if (build_lists(c, fs)) return 1;
@@ -690,7 +692,7 @@ int launch_now(dxv_ctx* c, uint32_t frame)
             st = 16;                                                // no stack: the column is the queue of selected triangles (8 items of two words)
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
             f.list_entries = c->listEntries; f.list_res = c->listRes;
-            if (c->optBrick == 4 && !c->optAblate) {
+            if (c->optBrick == 4 && !c->optAblate && !relaunch) {
                 int perr = 0;
                 plan = plan_for(c, p, fs, perr);
                 if (perr) return 1;
@@ -710,8 +712,8 @@ int launch_now(dxv_ctx* c, uint32_t frame)
         // at 1024^3 1.7: 1.31 / 2.02; dragon x9 2.3: 1.26 / 1.49; dragon at 512^3 3.5: 0.16 / 0.36; bunny 5: 0.20 / 0.27;
         // dragon at 1024^3 7: 1.18 / 0.88; bunny 10: 1.36 / 0.98)
         const bool small = c->hdr.triExtent * 0.5f * (float)p.N <= 6.0f;
-        const bool want = c->optPlists && (c->optPlists == 2 || (small && (c->parityLaunchesOfScene > 0 || c->plState != 0)));
-        ++c->parityLaunchesOfScene;
+        const bool want = c->optPlists && (relaunch ? c->plState == 1 : (c->optPlists == 2 || (small && (c->parityLaunchesOfScene > 0 || c->plState != 0))));
+        if (!relaunch) ++c->parityLaunchesOfScene;
         if (want && c->plState == 0) {
             if (sync_frames(c)) return 1;
             if (build_plists(c, fs)) return 1;
@@ -1078,7 +1080,7 @@ int sync_frame(dxv_ctx* c, uint32_t i)
             // grow to the next instantiated depth (at most up to the depth that cannot overflow) and redo
             const int next = stack_round_up(c->stackNow + 1);
             c->stackNow = next < safe_stack(c, f.lastMode) ? next : safe_stack(c, f.lastMode);
-            if (launch_now(c, i)) return 1;
+            if (launch_now(c, i, true)) return 1;
             continue;
         }
         return fail(c, "voxelize kernel reported status 0x%x (traversal stack overflow: tree height %u, stack %u)",

@@ -261,10 +261,10 @@ def main_wide():
     path = os.path.join(ROOT, "tests", "golden", "anchor_wide.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
     jobs = [(f"{n}/128/reference", lambda n=n: compare(n, 128)) for n in ("turingbowl", "bunny", "dragon")]
-    jobs += [("dragon9/512/reference/sample", lambda: compare_sampled("dragon9", 512, 12000)),
-             ("torus1m/512/reference/sample", lambda: compare_sampled("torus1m", 512, 12000)),
-             ("soup1m/256/reference/sample", lambda: compare_sampled("soup1m", 256, 12000)),
-             ("bunny16/512/reference/sample", lambda: compare_sampled("bunny16", 512, 8000))]
+    jobs += [("dragon9/512/reference/sample", lambda: compare_sampled("dragon9", 512, 60000)),
+             ("torus1m/512/reference/sample", lambda: compare_sampled("torus1m", 512, 60000)),
+             ("soup1m/256/reference/sample", lambda: compare_sampled("soup1m", 256, 60000)),
+             ("bunny16/512/reference/sample", lambda: compare_sampled("bunny16", 512, 60000))]
     jobs += [(f"{n}/64/parity", lambda n=n: compare_parity(n, 64)) for n in ("bunny", "dragon")]
     jobs += [(f"{n}/128/parity", lambda n=n: compare_parity(n, 128)) for n in ("bunny", "dragon")]
     jobs += [("torus1m/512/parity/slices", lambda: compare_parity("torus1m", 512, 6)),

@@ -95,3 +95,60 @@ def test_kat_watertight_hit_in_front_of_its_own_box(orc, kat):
     assert L.orc_slab(o, d, lo, hi, C.byref(tn)) == 1                                               # the ray does pass the padded box
     assert (t.value, tn.value) == (np.float32(kat["t"]), np.float32(kat["tn"]))
     assert tn.value > t.value                                                                         # ... but enters it BEHIND t: rejected
+
+
+# ---------------------------------------------------------------------------------------------
+# Round 3: the anchor beyond 64^3 of the three assets (tests/golden/anchor_wide.json, written by `python oracle/anchor.py wide`,
+# half an hour of CPU): their 128^3 grids whole, samples of the BASELINE configurations, and the second rule.
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def anchor_wide():
+    with open(os.path.join(GOLD, "anchor_wide.json")) as fh:
+        return json.load(fh)
+
+
+def test_anchor_wide_committed_results(anchor_wide, grids_json):
+    """Nothing unexplained anywhere.  Reference rule: bunny and dragon agree with the float64 all-triangles tracer on every one
+    of the 2,097,152 voxels at 128^3, TuringBowl differs on 10 voxels, all of them hits within rounding of a triangle edge; on
+    the samples of the configurations (half of each sample drawn next to the surface) the two agree on every voxel.  Parity
+    rule: the independent float64 crossing count agrees with the oracle's fill rule on every voxel that is not within 4e-6 of
+    an edge or of a surface."""
+    for key, rec in anchor_wide.items():
+        assert rec["classes"]["unexplained"] == 0, key
+    for name in ("bunny", "dragon"):
+        rec = anchor_wide[f"{name}/128/reference"]
+        assert rec["differ"] == 0 and rec["solid_fp64"] == rec["solid_oracle"]
+    assert anchor_wide["bunny/128/reference"]["solid_oracle"] == grids_json["bunny/128/reference"]["solid"]
+    tb = anchor_wide["turingbowl/128/reference"]
+    assert tb["differ"] == tb["classes"]["edge"] == 10
+    for key in ("dragon9/512/reference/sample", "torus1m/512/reference/sample", "soup1m/256/reference/sample", "bunny16/512/reference/sample"):
+        rec = anchor_wide[key]
+        assert rec["sampled_voxels"] >= 8000 and rec["near_surface"] >= rec["sampled_voxels"] // 3
+        assert rec["differ"] == sum(rec["classes"].values())
+        assert 0 < rec["solid_oracle"] < rec["sampled_voxels"]
+    for key in ("bunny/64/parity", "dragon/64/parity", "bunny/128/parity", "dragon/128/parity", "torus1m/512/parity/slices", "dragon9/512/parity/slices"):
+        rec = anchor_wide[key]
+        assert rec["rule"] == "parity" and rec["classes"]["unexplained"] == 0
+        assert rec["differ"] <= rec["near_edge_voxels"] <= rec["voxels_compared"] // 1000
+    assert anchor_wide["bunny/64/parity"]["solid_oracle"] == grids_json["bunny/64/parity"]["solid"]
+
+
+def test_anchor_samples_rerun_small(orc):
+    """The same comparisons run now on small fresh samples of the metric's mesh (1,000,000 triangles, 512^3): 600 voxels of the
+    reference rule with every triangle tested for every ray in float64, and one whole slice of the parity rule."""
+    from oracle import anchor
+    rec = anchor.compare_sampled("torus1m", 512, 600, seed=20261003)
+    assert rec["classes"]["unexplained"] == 0 and rec["differ"] <= 2, rec["voxels"]
+    par = anchor.compare_parity("torus1m", 512, 1, seed=20261003)
+    assert par["classes"]["unexplained"] == 0 and par["voxels_compared"] == 512 * 512, par["voxels"]
+    assert par["solid_oracle"] > 0
+
+
+def test_parity_anchor_whole_bunny_64(orc, grids_json):
+    """The parity rule (no reference counterpart; north_star's hit-count mode) against an independent statement: float64
+    Moeller-Trumbore crossing count of every grid row's +X line, strict interior, shared-edge crossings paired by the
+    orientation of the two triangles -- every voxel of the bunny at 64^3."""
+    from oracle import anchor
+    rec = anchor.compare_parity("bunny", 64)
+    assert rec["classes"]["unexplained"] == 0 and rec["differ"] <= rec["near_edge_voxels"] <= 8
+    assert rec["solid_oracle"] == grids_json["bunny/64/parity"]["solid"]
