@@ -33,7 +33,19 @@ def make_mesh(name):
         vb, ib = meshes.torus()                       # exactly 1,000,000 triangles
         return vb, ib, "torus-1M (R=0.6, r=0.3, 1000x500 quads)"
     if name == "soup10m":
-        vb, ib = meshes.soup()
+        # (a minute of single-threaded generation: tools that build it again and again keep a copy in /tmp)
+        cache = os.path.join(os.environ.get("DXV_MESH_CACHE", "/tmp/dxv_mesh_cache"), "soup10m")
+        try:
+            vb, ib = np.load(cache + "_vb.npy"), np.load(cache + "_ib.npy")
+            if vb.shape != (30_000_000, 6) or ib.shape != (30_000_000,):
+                raise ValueError
+        except (OSError, ValueError):
+            vb, ib = meshes.soup()
+            try:
+                os.makedirs(os.path.dirname(cache), exist_ok=True)
+                np.save(cache + "_vb.npy", vb), np.save(cache + "_ib.npy", ib)
+            except OSError:
+                pass
         return vb, ib, "soup-10M (seed 0x5EED1234)"
     if name in ("bunny", "dragon"):
         d = np.load(os.path.join(ROOT, "tests", "golden", "meshes", name + ".npz"))

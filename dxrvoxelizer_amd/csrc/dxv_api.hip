@@ -123,6 +123,7 @@ struct dxv_ctx {
     Plan plans[kPlans];
     uint64_t listEpoch = 0, planClock = 0, planIds = 0;
     int optPlan = 1;                 // 0 = no plans (brick box + Morton order), 1 = from a partition's second launch, 2 = from the first
+    int optPlanRegion = 9;           // log2 bricks per region of a plan (6 .. 9)
     int optPlanOrder = 3;            // order of the regions inside a plan (plan_for): 3 = balanced by cost, Morton order, cheapest regions last
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
@@ -544,7 +545,8 @@ dxv_ctx::Plan* plan_for(dxv_ctx* c, const VoxelizeParams& p, hipStream_t stream,
     if (c->optPlan == 1 && pl->seen < 2) return nullptr;
     // build
     VoxelizeParams q = p;
-    const uint32_t nb = plan_layout(q), nr = plan_regions(nb);
+    const uint32_t rb = (uint32_t)c->optPlanRegion;
+    const uint32_t nb = plan_layout(q), nr = plan_regions(nb, rb);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     uint32_t* scratch = nullptr;
     auto done = [&](hipError_t e, const char* what) -> Plan* {
@@ -561,7 +563,7 @@ dxv_ctx::Plan* plan_for(dxv_ctx* c, const VoxelizeParams& p, hipStream_t stream,
     if ((e = hipMalloc(&scratch, sizeof(uint32_t) * ((size_t)nb + 4 * (size_t)nr))) != hipSuccess) return done(e, "hipMalloc");
     uint32_t *cost = scratch, *regionCost = scratch + nb, *regionLive = regionCost + nr, *regionDst = regionLive + nr;
     if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, stream);
-    if ((e = plan_probe(p, cost, regionCost, regionLive, stream)) != hipSuccess) return done(e, "plan_probe");
+    if ((e = plan_probe(p, rb, cost, regionCost, regionLive, stream)) != hipSuccess) return done(e, "plan_probe");
     std::vector<uint32_t> host(2 * (size_t)nr), dst(2 * (size_t)nr, 0u);
     if ((e = hipMemcpyAsync(host.data(), regionCost, sizeof(uint32_t) * 2 * (size_t)nr, hipMemcpyDeviceToHost, stream)) != hipSuccess) return done(e, "hipMemcpyAsync");
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e, "hipStreamSynchronize");
@@ -623,7 +625,7 @@ dxv_ctx::Plan* plan_for(dxv_ctx* c, const VoxelizeParams& p, hipStream_t stream,
     }
     if (words) {
         if ((e = hipMemcpyAsync(regionDst, dst.data(), sizeof(uint32_t) * 2 * (size_t)nr, hipMemcpyHostToDevice, stream)) != hipSuccess) return done(e, "hipMemcpyAsync");
-        if ((e = plan_fill(p, cost, regionDst, pl->dPlan, words, stream)) != hipSuccess) return done(e, "plan_fill");
+        if ((e = plan_fill(p, rb, cost, regionDst, pl->dPlan, words, stream)) != hipSuccess) return done(e, "plan_fill");
     }
     if (t1) (void)hipEventRecord(t1, stream);
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e, "hipStreamSynchronize");
@@ -1440,6 +1442,10 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "plan")) {
         if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
         c->optPlan = (int)value;
+    } else if (!strcmp(key, "planregion")) {
+        if (value < 6 || value > 9) return fail(c, "option planregion: %lld not in [6, 9]", (long long)value);
+        if (c->optPlanRegion != (int)value) { if (sync_frames(c)) return 1; for (auto& pl : c->plans) pl.used = pl.valid = false; }
+        c->optPlanRegion = (int)value;
     } else if (!strcmp(key, "planorder")) {
         if (value < 0 || value > 3) return fail(c, "option planorder: %lld not in {0,1,2,3}", (long long)value);
         if (c->optPlanOrder != (int)value) { if (sync_frames(c)) return 1; for (auto& pl : c->plans) pl.used = pl.valid = false; }

@@ -91,9 +91,9 @@ hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEnt
 // dispatch plan of the lists kernel with 4 x 4 x 4 bricks (traverse.hip): probe = per-brick cost (0 = no live ray) in the
 // partition's Morton order + cost and live bricks per region of 512; fill = the plan from the host's region placement
 uint32_t plan_layout(VoxelizeParams& p);           // fills the brick-order fields for the whole partition, returns its bricks
-uint32_t plan_regions(uint32_t bricks);
-hipError_t plan_probe(const VoxelizeParams& p, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s);
-hipError_t plan_fill(const VoxelizeParams& p, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s);
+uint32_t plan_regions(uint32_t bricks, uint32_t regionBits);           // regions of 2^regionBits consecutive bricks, 6 <= regionBits <= 9
+hipError_t plan_probe(const VoxelizeParams& p, uint32_t regionBits, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s);
+hipError_t plan_fill(const VoxelizeParams& p, uint32_t regionBits, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s);
 hipError_t launch_voxelize_planned(const VoxelizeParams& p, uint64_t planId, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack
 int stack_round_up(int want);

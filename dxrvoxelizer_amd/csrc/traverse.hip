@@ -122,9 +122,9 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 // The plan depends on the lists and on the partition (N, slab or block-cyclic set), not on the frame: dxv_api.hip keeps a
 // few per context and builds one when the same partition is launched a second time against the same lists.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kPlanRegionBits = 9u, kPlanRegion = 1u << kPlanRegionBits;
+constexpr uint32_t kPlanRegionBitsMax = 9u;                            // regions of 2^rb consecutive bricks, rb <= 9 (one workgroup of k_plan_fill each)
 
-__global__ __launch_bounds__(64) void k_plan_probe(VoxelizeParams p, uint32_t nb, uint32_t* __restrict__ cost,
+__global__ __launch_bounds__(64) void k_plan_probe(VoxelizeParams p, uint32_t nb, uint32_t rb, uint32_t* __restrict__ cost,
                                                    uint32_t* __restrict__ regionCost, uint32_t* __restrict__ regionLive)
 {
     const uint32_t lin = blockIdx.x;
@@ -152,16 +152,16 @@ __global__ __launch_bounds__(64) void k_plan_probe(VoxelizeParams p, uint32_t nb
     for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
     if (tid == 0u) {
         cost[lin] = c;
-        if (c) { atomicAdd(regionCost + (lin >> kPlanRegionBits), c); atomicAdd(regionLive + (lin >> kPlanRegionBits), 1u); }
+        if (c) { atomicAdd(regionCost + (lin >> rb), c); atomicAdd(regionLive + (lin >> rb), 1u); }
     }
 }
 
 // regionDst[2 r] = XCD of region r, regionDst[2 r + 1] = position of its first live brick in that XCD's sequence
-__global__ __launch_bounds__(kPlanRegion) void k_plan_fill(VoxelizeParams p, uint32_t nb, const uint32_t* __restrict__ cost,
-                                                           const uint32_t* __restrict__ regionDst, uint32_t* __restrict__ plan)
+__global__ __launch_bounds__(1u << kPlanRegionBitsMax) void k_plan_fill(VoxelizeParams p, uint32_t nb, const uint32_t* __restrict__ cost,
+                                                                        const uint32_t* __restrict__ regionDst, uint32_t* __restrict__ plan)
 {
-    __shared__ uint32_t waveCount[kPlanRegion / 64u];
-    const uint32_t lin = blockIdx.x * kPlanRegion + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    __shared__ uint32_t waveCount[(1u << kPlanRegionBitsMax) / 64u];
+    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;   // blockDim.x = bricks per region
     const bool live = lin < nb && cost[lin] != 0u;
     const unsigned long long m = __ballot(live);
     if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
@@ -187,26 +187,28 @@ uint32_t plan_layout(VoxelizeParams& p)
     p.superY = nby >> m;
     return nbx * nby * nbz;
 }
-uint32_t plan_regions(uint32_t nb) { return (nb + kPlanRegion - 1u) / kPlanRegion; }
+uint32_t plan_regions(uint32_t nb, uint32_t rb) { return (nb + (1u << rb) - 1u) >> rb; }
 
-hipError_t plan_probe(const VoxelizeParams& pin, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s)
+hipError_t plan_probe(const VoxelizeParams& pin, uint32_t rb, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s)
 {
     VoxelizeParams p = pin;
-    const uint32_t nb = plan_layout(p), nr = plan_regions(nb);
+    if (rb < 6u || rb > kPlanRegionBitsMax) return hipErrorInvalidValue;
+    const uint32_t nb = plan_layout(p), nr = plan_regions(nb, rb);
     hipError_t e = hipMemsetAsync(regionCost, 0, sizeof(uint32_t) * nr, s);
     if (e == hipSuccess) e = hipMemsetAsync(regionLive, 0, sizeof(uint32_t) * nr, s);
     if (e != hipSuccess) return e;
-    k_plan_probe<<<dim3(nb), dim3(64), 0, s>>>(p, nb, cost, regionCost, regionLive);
+    k_plan_probe<<<dim3(nb), dim3(64), 0, s>>>(p, nb, rb, cost, regionCost, regionLive);
     return hipGetLastError();
 }
 
-hipError_t plan_fill(const VoxelizeParams& pin, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s)
+hipError_t plan_fill(const VoxelizeParams& pin, uint32_t rb, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s)
 {
     VoxelizeParams p = pin;
-    const uint32_t nb = plan_layout(p), nr = plan_regions(nb);
+    if (rb < 6u || rb > kPlanRegionBitsMax) return hipErrorInvalidValue;
+    const uint32_t nb = plan_layout(p), nr = plan_regions(nb, rb);
     hipError_t e = hipMemsetAsync(plan, 0xff, sizeof(uint32_t) * (size_t)planWords, s);
     if (e != hipSuccess) return e;
-    k_plan_fill<<<dim3(nr), dim3(kPlanRegion), 0, s>>>(p, nb, cost, regionDst, plan);
+    k_plan_fill<<<dim3(nr), dim3(1u << rb), 0, s>>>(p, nb, cost, regionDst, plan);
     return hipGetLastError();
 }
 
