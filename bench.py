@@ -227,17 +227,22 @@ def main():
 
     # N > 1: block-cyclic Z partition (blocks of 8 slices dealt round-robin): contiguous slabs leave
     # the GPUs that own empty space idle (profiles/r01: 2.5x at 8 slabs); still no collective.
-    zblock = 8
+    # (blocks of 8 slices; of 4 -- one layer of 4^3-voxel bricks -- from 8 ranks on: the finer deal balances the ranks better,
+    # slowest rank 0.119 instead of 0.127 ms looped on one GPU: profiles/r03/rank_times_zblock.jsonl)
+    zblock = 4 if world >= 8 else 8
     interleave = (world > 1 or args.interleave) and N % (zblock * world) == 0
     z0, nz = slab_range(N, rank, world)
     if interleave:
         nz = N // world
 
-    def timed_region(frames, steps, warmup, n=None):
+    def timed_region(frames, steps, warmup, n=None, per_step=False):
         """`steps` steps with `frames` voxelizations in flight (frames of the one context, taking the steps in turn),
         barrier + synchronize on both sides; (wall seconds, mean kernel ms, per-step ms).  A rank's share of the grid is a
         short launch whose tail -- its last long rays running alone -- does not shrink with it; the reference hides the same
-        thing by keeping FrameCount = 3 grids in flight (Content/Voxelizer.h:24).  n: grid size (default: the headline's)."""
+        thing by keeping FrameCount = 3 grids in flight (Content/Voxelizer.h:24).  n: grid size (default: the headline's).
+        per_step: an event after every step as well (per-step times; ~4 us of stream time each, so not in the headline region).
+        With one voxelization in flight the library's own two events per launch are switched off for the region (option
+        events: ~8 us per step, 6 % of a rank's step at 8 ranks): the region is bracketed by two events of its own."""
         turn = [0]
         n = N if n is None else n
         inter = (world > 1 or args.interleave) and n % (zblock * world) == 0
@@ -254,27 +259,28 @@ def main():
         for _ in range(max(warmup, frames)):     # every frame launches at least once before the clock starts
             step()
         vox.SyncAll()
+        vox.set_option("events", 0 if frames == 1 else 1)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if frames == 1 else 2)]
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if per_step else 2)]
         t0 = time.perf_counter()
         evs[0].record(stream)
         for k in range(steps):
             step()
-            if frames == 1:
+            if per_step:
                 evs[k + 1].record(stream)        # (the launches queue back to back on this stream: event k+1 - event k = step k on the device)
-        if frames != 1:
+        if not per_step:
             evs[1].record(stream)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0            # this rank's K steps; the closing barrier (tens of us of RCCL) is not part of any
         if use_dist:                             # rank's work: the maximum over ranks is taken by reduce_max below
             dist.barrier()
         vox.SyncAll()                            # deferred kernel status (stack overflow) is an error
-        per_step = []
+        vox.set_option("events", 1)
+        steps_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)] if per_step else []
         if frames == 1:
-            per_step = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)]
-            k_ms = evs[0].elapsed_time(evs[steps]) / max(steps, 1)   # avg launch duration on the kernel's stream
+            k_ms = evs[0].elapsed_time(evs[-1]) / max(steps, 1)      # avg launch duration on the kernel's stream
         else:                                    # overlapping launches: the library's own events around each frame's last launch
             ks = []
             for f in range(frames):
@@ -282,7 +288,7 @@ def main():
                 ks.append(vox.stats()["voxelize_ms"])
             k_ms = float(np.mean(ks))
         vox.SetFrame(0)
-        return dt, k_ms, per_step
+        return dt, k_ms, steps_ms
 
     def reduce_max(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -303,8 +309,9 @@ def main():
         return {"median": float(np.median(xs)), "min": float(np.min(xs)), "max": float(np.max(xs))} if len(xs) else None
 
     frames = max(1, min(args.frames, vox.FrameCount))
-    dt, kernel_ms, per_step = timed_region(frames, args.steps, args.warmup)
+    dt, kernel_ms, _ = timed_region(frames, args.steps, args.warmup)
     dt_max = reduce_max(dt)
+    _, _, per_step = timed_region(1, args.steps, 1, per_step=True)      # the same steps once more with an event behind every one: their spread
     rank_kernel_ms = gather(kernel_ms)           # every rank's mean launch duration: an imbalance of the partition shows here
     rank_wall_ms = gather(dt / max(args.steps, 1) * 1e3)
     kmax = max(rank_kernel_ms)
@@ -378,7 +385,7 @@ def main():
             vox.InitFromArrays(vb4, ib4)
         if use_dist:
             broadcast_scene(vox, dist, torch.device("cuda", local_rank))
-        dt4, k4ms, step4 = timed_region(1, k4, 3, n=n4)
+        dt4, k4ms, step4 = timed_region(1, k4, 3, n=n4, per_step=True)
         rk4 = gather(k4ms)
         dt4 = reduce_max(dt4)
         extras["config4_dragon9_1024"] = {"workload": "dragon x9 (900,000 triangles), 1024^3, reference predicate, same partition",

@@ -72,6 +72,7 @@ struct dxv_ctx {
         int lastMode = 0;
         uint32_t lastZBlock = 1, lastZPeriod = 1;
         bool pending = false;            // a voxelize launch has not been checked by dxv_sync yet
+        bool timed = true;               // ... and it was bracketed by the frame's two events (option events)
         bool lastCanFail = true;         // ... and it can report something (a walk's column can run out; the lists have no column)
         bool ready = false;              // status words, redo list, events and stream exist
         uint64_t clearSig = 0;           // the partial launch whose memset this grid still carries (launch_shape, traverse.hip); 0 = none
@@ -123,7 +124,8 @@ struct dxv_ctx {
     Plan plans[kPlans];
     uint64_t listEpoch = 0, planClock = 0, planIds = 0;
     int optPlan = 1;                 // 0 = no plans (brick box + Morton order), 1 = from a partition's second launch, 2 = from the first
-    int optPlanRegion = 9;           // log2 bricks per region of a plan (6 .. 9)
+    int optEvents = 1;               // bracket every launch with two HIP events (stats.voxelize_ms); 0: none (a caller timing its own loop)
+    int optPlanRegion = 8;           // log2 bricks per region of a plan (6 .. 9): 256 bricks -1 ... -4 % against 512 at 512^3 (profiles/r03/ab_planregion.jsonl)
     int optPlanOrder = 3;            // order of the regions inside a plan (plan_for): 3 = balanced by cost, Morton order, cheapest regions last
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
@@ -727,7 +729,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
     }
     if (!p.lists && !p.scene.plCells && ensure_nodes(c, fs)) return 1;  // a tree walk after a refit: its copies of the hierarchy first
     if ((p.mode == DXV_MODE_REFERENCE && p.lists) || (p.mode == DXV_MODE_PARITY && c->optRows && p.scene.plCells)) f.lastCanFail = false;
-    DXV_HIP(c, hipEventRecord(f.ev0, fs));
+    if (c->optEvents) DXV_HIP(c, hipEventRecord(f.ev0, fs));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {
         // rows whose triangles span several voxels share a walk: 4 x 4 rows per wave above 1.5 voxels of
         // mean triangle extent, 2 x 2 above 1.2 -- as long as the launch still has enough waves to fill
@@ -758,7 +760,8 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             f.redoParity ^= 1u;
         }
     }
-    DXV_HIP(c, hipEventRecord(f.ev1, fs));
+    if (c->optEvents) DXV_HIP(c, hipEventRecord(f.ev1, fs));
+    f.timed = c->optEvents != 0;
     f.pending = true;
     return 0;
 }
@@ -1072,7 +1075,7 @@ int sync_frame(dxv_ctx* c, uint32_t i)
         DXV_HIP(c, hipStreamSynchronize(fs));
         const uint32_t status = words[0];
         if (f.pending) {
-            f.voxelize_ms = elapsed(f.ev0, f.ev1);
+            f.voxelize_ms = f.timed ? elapsed(f.ev0, f.ev1) : 0.0f;
             f.redo_rays = f.lastRedoParity < 0 ? 0u : words[1 + f.lastRedoParity];
         }
         f.pending = false;
@@ -1442,6 +1445,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "plan")) {
         if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
         c->optPlan = (int)value;
+    } else if (!strcmp(key, "events")) {
+        if (value != 0 && value != 1) return fail(c, "option events: %lld not in {0,1}", (long long)value);
+        c->optEvents = (int)value;
     } else if (!strcmp(key, "planregion")) {
         if (value < 6 || value > 9) return fail(c, "option planregion: %lld not in [6, 9]", (long long)value);
         if (c->optPlanRegion != (int)value) { if (sync_frames(c)) return 1; for (auto& pl : c->plans) pl.used = pl.valid = false; }

@@ -232,6 +232,10 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   plan   0|1|2  lists kernel: launch only the 4^3-voxel bricks that hold a live ray, 512-brick regions heaviest first and
  *                 dealt to the XCDs by estimated cost (1, default: from the second launch of a partition against the same
  *                 lists; 2: from the first; 0: brick box around the scene in Morton order)
+ *   planorder 0..3, planregion 6..9   order of the regions inside a plan (3, default: balanced over the XCDs by cost, Morton
+ *                 order, cheapest regions last) and log2 of their size in bricks (8, default)
+ *   events 0|1    bracket every launch with two HIP events for stats.voxelize_ms (default 1); 0 for a caller that times its own
+ *                 loop of back-to-back launches (the events cost ~8 us of stream time per launch)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
  *   morton 0|1, region 0..24, subbox 0|1   brick order, bricks per XCD region (log2), partial launch */
 DXV_API int dxv_set_option(dxv_ctx* ctx, const char* key, int64_t value);
