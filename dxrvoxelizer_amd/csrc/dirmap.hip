@@ -371,6 +371,25 @@ hipError_t dirmap_validate(const DirCell* cells, uint32_t R, const DirEntry* ent
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kThreads) void k_pl_validate(const uint32_t* __restrict__ cells, uint32_t ncells, const uint32_t* __restrict__ entries,
+                                                          uint32_t n, uint32_t T, uint32_t* __restrict__ out)
+{
+    uint32_t badCells = 0, badTris = 0;
+    for (uint32_t c = blockIdx.x * kThreads + threadIdx.x; c < ncells; c += gridDim.x * kThreads)
+        if (cells[2u * c + 1u] && ((uint64_t)cells[2u * c] + cells[2u * c + 1u] > (uint64_t)n)) ++badCells;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        if (entries[i] >= T) ++badTris;
+    if (badCells) atomicAdd(out, badCells);
+    if (badTris) atomicAdd(out + 1, badTris);
+}
+hipError_t parity_lists_validate(const uint32_t* cells, uint32_t R, const uint32_t* entries, uint32_t n, uint32_t T, uint32_t* out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    k_pl_validate<<<1024, kThreads, 0, s>>>(cells, R * R, entries, n, T, out);
+    return hipGetLastError();
+}
+
 // Row lists of the parity rule (above).  parity_lists_total: total[0] = entries the lists would have, total[1] = texels of the
 // largest single rectangle (one thread of the fill walks it); parity_lists_fill: cells = 2 words
 // (begin, count) per texel of the R x R grid, entries = `total` triangle slots (+ a few spare words behind them).

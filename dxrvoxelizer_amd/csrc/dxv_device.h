@@ -54,6 +54,7 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
 // out[1] = entries whose triangle slot is >= T
 hipError_t dirmap_validate(const DirCell* cells, uint32_t R, const DirEntry* entries, uint32_t n, uint32_t T, uint32_t* out, hipStream_t s);
 
+hipError_t parity_lists_validate(const uint32_t* cells, uint32_t R, const uint32_t* entries, uint32_t n, uint32_t T, uint32_t* out, hipStream_t s);
 hipError_t parity_lists_total(const TriPos* triPos, uint32_t T, uint32_t R, unsigned long long* total, hipStream_t s);
 hipError_t parity_lists_fill(const TriPos* triPos, uint32_t T, uint32_t R, uint32_t* counts, uint32_t* offsets, uint32_t* sums, uint32_t* cells,
                              uint32_t* entries, hipStream_t s);

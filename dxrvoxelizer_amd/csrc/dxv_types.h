@@ -62,7 +62,8 @@ struct alignas(16) TriPos { F4 v0, v1, v2; };
 // Vertex normals of the same triangle (hlsl:102-107, :114-116), fetched once per ray at the end.
 struct alignas(16) TriNrm { F4 n0, n1, n2; };
 
-// Relocatable scene blob: [SceneHeader | nodes | nodes32 | nodes64 | triPos | triNrm | (list cells | list entries)], sections 256-B aligned.
+// Relocatable scene blob: [SceneHeader | nodes | nodes32 | nodes64 | triPos | triNrm | (list cells | list entries) | (row cells | row entries)],
+// sections 256-B aligned.
 struct SceneHeader {
     uint32_t magic;       // 'DXVS'
     uint32_t version;
@@ -81,12 +82,15 @@ struct SceneHeader {
     // the ranks that import the scene need not build them again.  0 / 0 when the blob carries none.
     uint64_t offListCells, offListEntries;
     uint32_t listRes, listCount;
-    uint32_t pad[20];
+    // ... and the row lists of the parity rule (dirmap.hip): plRes x plRes cells of (begin, count), plCount triangle slots
+    uint64_t offPlCells, offPlEntries;
+    uint32_t plRes, plCount;
+    uint32_t pad[14];
 };
 static_assert(sizeof(SceneHeader) % 16 == 0, "header alignment");
 
 constexpr uint32_t kSceneMagic = 0x53565844u; // "DXVS"
-constexpr uint32_t kSceneVersion = 7;
+constexpr uint32_t kSceneVersion = 8;
 
 // canonical constants (hlsl:5, :76-77)
 constexpr float kThreshold = 0.12f;

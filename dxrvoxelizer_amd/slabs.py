@@ -45,7 +45,7 @@ def scatter_interleaved(parts, N, world, block):
     return full
 
 
-def broadcast_scene(engine, dist, device, src=0):
+def broadcast_scene(engine, dist, device, src=0, parity_lists=False):
     """Broadcast the built scene from rank `src` to every rank of the default process group.
 
     engine: object with scene_bytes() / scene_export(ptr, n) / scene_import(ptr, n) working on
@@ -57,7 +57,8 @@ def broadcast_scene(engine, dist, device, src=0):
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
         if hasattr(engine, "build_lists"):
-            engine.build_lists()              # the candidate lists travel with the blob: the other ranks adopt them
+            # the candidate lists travel with the blob: the other ranks adopt them (parity_lists: the parity rule's row lists too)
+            engine.build_lists(parity=True) if parity_lists else engine.build_lists()
         n[0] = engine.scene_bytes()
     dist.broadcast(n, src=src)
     nbytes = int(n.item())

@@ -194,9 +194,12 @@ class Voxelizer:
         self._check(self._lib.dxv_get_stats(self._ctx, C.byref(s)))
         return s.as_dict()
 
-    def build_lists(self):
-        """Build the candidate lists of the reference rule now (they then travel with scene_export)."""
+    def build_lists(self, parity=False):
+        """Build the candidate lists of the reference rule now (they then travel with scene_export); parity=True: the parity
+        rule's row lists as well."""
         self._check(self._lib.dxv_build_lists(self._ctx))
+        if parity:
+            self._check(self._lib.dxv_build_parity_lists(self._ctx))
 
     def scene_bytes(self):
         return self._lib.dxv_scene_bytes(self._ctx)

@@ -202,6 +202,9 @@ DXV_API int dxv_render(dxv_ctx* ctx, const float eye[3], const float view_proj[1
  * second launch (option lists); dxv_build_lists builds them now.  A scene exported after that carries them as two more
  * sections of the blob, and the importing contexts adopt them instead of building their own. */
 DXV_API int dxv_build_lists(dxv_ctx* ctx);
+/* The same for the parity rule's row lists (option plists): built now instead of at the scene's second parity launch; a scene
+ * exported after that carries them too (33 + 72 MB at 1 M triangles), and an importing context adopts them. */
+DXV_API int dxv_build_parity_lists(dxv_ctx* ctx);
 DXV_API size_t dxv_scene_bytes(const dxv_ctx* ctx);
 DXV_API int dxv_scene_export(dxv_ctx* ctx, void* device_dst, size_t bytes);
 DXV_API int dxv_scene_import(dxv_ctx* ctx, const void* device_src, size_t bytes);

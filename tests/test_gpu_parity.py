@@ -389,6 +389,28 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     b.scene_import(blob3.data_ptr(), n3)
     b.Voxelize(64)
     assert b.stats()["list_res"] == 64 and np.array_equal(b.Grid(), want)
+    b.set_option("listres", 0)
+    # the parity rule's row lists travel the same way once the exporter has built them
+    a.build_lists(parity=True)
+    n4 = a.scene_bytes()
+    assert n4 > n3
+    blob4 = torch.empty(n4, dtype=torch.uint8, device="cuda")
+    a.scene_export(blob4.data_ptr(), n4)
+    torch.cuda.synchronize()
+    b.scene_import(blob4.data_ptr(), n4)
+    wantp = orc.Scene(vb, ib).voxelize(64, mode=1)
+    a.Voxelize(64, dxv.MODE_PARITY), b.Voxelize(64, dxv.MODE_PARITY)       # b's first parity launch: through the imported row lists
+    sa, sb = a.stats(), b.stats()
+    assert sa["list_entries"] == sb["list_entries"] > 0 and sa["list_res"] == sb["list_res"] and sb["list_ms"] == 0.0
+    assert np.array_equal(a.Grid(), wantp) and np.array_equal(b.Grid(), wantp)
+    b.Voxelize(64)                                                          # (and the reference rule through the imported direction lists)
+    assert b.stats()["list_entries"] > 0 and np.array_equal(b.Grid(), want)
+    hdr = blob4[:512].cpu().numpy().view(np.uint64)
+    bad = blob4.clone()
+    bad[int(hdr[19]):int(hdr[19]) + 4].view(torch.int32)[0] = 0x7ffffff0   # SceneHeader.offPlEntries: the first row entry names no triangle
+    torch.cuda.synchronize()
+    with pytest.raises(dxv.DxvError, match="inconsistent"):
+        b.scene_import(bad.data_ptr(), n4)
     a.close(), b.close()
 
 
