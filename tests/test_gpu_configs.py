@@ -203,3 +203,25 @@ def test_lists_and_classes_checked_exhaustively_at_config_scale(dxv, configs, na
             assert hits >= whole["solid"]                      # every solid voxel is a hit
     finally:
         v.close()
+
+
+def test_headline_partition_of_bench_at_8_ranks(dxv, configs):
+    """What `bench.py --gpus 8` runs: torus-1M at 512^3, Z blocks of 4 slices dealt round-robin over 8 ranks, every rank's
+    share launched repeatedly (so: through its dispatch plan, with the kept memset).  One GPU plays the ranks in turn; the
+    reassembled grid must be the fixture's."""
+    from dxrvoxelizer_amd.slabs import scatter_interleaved
+    key = "torus1m/512/reference"
+    N, W, blk = 512, 8, 4
+    v = dxv.Voxelizer(0)
+    try:
+        init(v, configs, key)
+        v.set_option("lists", 2)
+        parts = []
+        for r in range(W):
+            for _ in range(3):
+                v.VoxelizeInterleaved(N, r, W, blk)
+            assert v.stats()["plan_bricks"] > 0
+            parts.append((r, v.Grid().copy()))
+        check_whole(scatter_interleaved(parts, N, W, blk), configs[key], "8 ranks x blocks of 4 slices")
+    finally:
+        v.close()
