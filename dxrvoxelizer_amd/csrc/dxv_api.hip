@@ -705,6 +705,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
     }
     f.plan_bricks = plan ? plan->live : 0u; f.plan_waves = plan ? plan->count : 0u; f.plan_ms = plan ? plan->ms : 0.0f;
     if (f.ptrExposed) p.clearSig = nullptr;                            // the caller may have written into the grid: clear it every time
+    st = stack_for_brick(c->optBrick, st);                             // (shapes other than the shipped one are compiled for three depths)
     f.stack_entries = (uint32_t)st;
     f.lastCanFail = true;
     if (p.mode == DXV_MODE_PARITY && c->optRows && !c->optRowBlock) {

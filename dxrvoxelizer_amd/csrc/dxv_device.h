@@ -98,6 +98,7 @@ hipError_t plan_fill(const VoxelizeParams& p, uint32_t regionBits, const uint32_
 hipError_t launch_voxelize_planned(const VoxelizeParams& p, uint64_t planId, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack
 int stack_round_up(int want);
+int stack_for_brick(int brickShape, int want);   // the column depth compiled for this brick shape that is >= want
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s);   // parity mode: one walk per row run (1) or per 2 x 2 rows (2)
 hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);   // test hook: superset claim of the lists (slices [p.z0, p.z0 + p.nz))
 hipError_t launch_class_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);  // test hook: per-triangle class of the normal test against the predicate

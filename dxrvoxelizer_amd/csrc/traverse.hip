@@ -774,18 +774,38 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
     return hipGetLastError();
 }
 
+int stack_round_up(int want);
+// Column depths a brick shape is compiled for: all eight for the shipped shape (4 x 4 x 4: the adaptive column and its
+// tuning), three for the shapes that exist for sweeps and cross-checks (16: the lists' queue, 20: the walks' default,
+// 64: always sufficient).  A depth in between takes the next one up -- a deeper column than asked is never wrong.
+int stack_for_brick(int brickShape, int want)
+{
+    want = stack_round_up(want);
+    if (brickShape == 4) return want;
+    return want <= 16 ? 16 : want <= 20 ? 20 : 64;
+}
+
 template <class B>
 static hipError_t launch_stack(const VoxelizeParams& p, int stackEntries, hipStream_t s)
 {
-    switch (stackEntries) {
-    case 8: return launch_shape<B, 8>(p, s);
-    case 12: return launch_shape<B, 12>(p, s);
-    case 16: return launch_shape<B, 16>(p, s);
-    case 20: return launch_shape<B, 20>(p, s);
-    case 24: return launch_shape<B, 24>(p, s);
-    case 32: return launch_shape<B, 32>(p, s);
-    case 48: return launch_shape<B, 48>(p, s);
-    default: return launch_shape<B, 64>(p, s);
+    if constexpr (B::x == 4 && B::y == 4 && B::z == 4) {
+        switch (stackEntries) {
+        case 8: return launch_shape<B, 8>(p, s);
+        case 12: return launch_shape<B, 12>(p, s);
+        case 16: return launch_shape<B, 16>(p, s);
+        case 20: return launch_shape<B, 20>(p, s);
+        case 24: return launch_shape<B, 24>(p, s);
+        case 32: return launch_shape<B, 32>(p, s);
+        case 48: return launch_shape<B, 48>(p, s);
+        default: return launch_shape<B, 64>(p, s);
+        }
+    } else {
+        switch (stackEntries) {
+        case 16: return launch_shape<B, 16>(p, s);
+        case 20: return launch_shape<B, 20>(p, s);
+        case 64: return launch_shape<B, 64>(p, s);
+        default: return hipErrorInvalidValue;              // (stack_for_brick maps every depth to one of the three)
+        }
     }
 }
 
@@ -800,7 +820,7 @@ int stack_round_up(int want)
 
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s)
 {
-    if (stack_round_up(stackEntries) != stackEntries) return hipErrorInvalidValue;
+    if (stack_round_up(stackEntries) != stackEntries || stack_for_brick(brickShape, stackEntries) != stackEntries) return hipErrorInvalidValue;
     switch (brickShape) {
     case 0: return launch_stack<Brick0>(p, stackEntries, s);
     case 1: return launch_stack<Brick1>(p, stackEntries, s);
