@@ -535,7 +535,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             const DirEntry* p = dm.entries + i;
             const DirEntry e0 = p[0], e1 = p[1];
             DirEntry e2, e3;
-            if (wide) { e2 = p[2]; e3 = p[3]; }
+            if (wide && i + 2u <= last) { e2 = p[2]; e3 = p[3]; }       // (lanes whose list ends here issue no access for what they would not look at)
             // The list is sorted by far radius and every entry knows (in 63rds of the texel's thickest entry) how far behind
             // its far radius the earliest start of any LATER entry lies: once that point is beyond the closest hit so far,
             // this entry and everything behind it start beyond the hit.  (Surface meshes have short lists and gain
