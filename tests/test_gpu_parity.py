@@ -1153,4 +1153,13 @@ def test_dispatch_plan_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon):
     v.set_option("plan", 0)
     v.Voxelize(N)
     assert np.array_equal(v.Grid(), g_auto)
+    # every region size and order of a plan, and launches without the library's two events (a caller timing its own loop)
+    v.set_option("plan", 2)
+    for region, order, events in ((6, 0, 1), (7, 1, 0), (8, 2, 1), (9, 3, 0), (8, 3, 1)):
+        v.set_option("planregion", region); v.set_option("planorder", order); v.set_option("events", events)
+        for _ in range(2):
+            v.Voxelize(N)
+        st = v.stats()
+        assert st["plan_bricks"] > 0 and (st["voxelize_ms"] > 0) == bool(events)
+        assert np.array_equal(v.Grid(), g_auto), (region, order, events)
     v.close()
