@@ -8,11 +8,9 @@
 namespace dxv {
 
 // radix_sort.hip
-// stable LSD sort by key bits [loBit, loBit + bits) in ceil(bits / 10) passes; *result = keys or tmp, whichever ends up sorted
-hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int bits, uint64_t** result,
+hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, hipStream_t s);
+hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int passes, uint64_t** result,
                                 hipStream_t s);
-// the LBVH's sort: the 30 Morton bits at [32, 62), three passes: unsorted keys in `keys`, sorted keys in `tmp`
-hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, uint64_t** result, hipStream_t s);
 uint32_t radix_sort_hist_words(uint32_t n);
 
 // lbvh.hip -- device-side build of the scene blob.

@@ -294,13 +294,10 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
 
     (void)hipEventRecord(ev[0], s);
     const uint32_t keyBlocks = blocks_for(T);
-    // (three sort passes: the unsorted keys go to the ping-pong buffer, the third pass lands in b.keys)
-    k_tri_keys<<<keyBlocks, kThreads, 0, s>>>(b.vb, b.ib, T, bnd, T > 1 ? b.keysTmp : b.keys, b.rootInfo, keyBlocks > 256u ? keyBlocks / 256u : 1u);
+    k_tri_keys<<<keyBlocks, kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.rootInfo, keyBlocks > 256u ? keyBlocks / 256u : 1u);
     (void)hipEventRecord(ev[1], s);
     if (T > 1) {
-        uint64_t* sorted = nullptr;
-        if ((e = radix_sort_keys(b.keysTmp, b.keys, T, b.hist, &sorted, s)) != hipSuccess) return e;
-        if (sorted != b.keys && (e = hipMemcpyAsync(b.keys, sorted, sizeof(uint64_t) * (size_t)T, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+        if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;
     }
     (void)hipEventRecord(ev[2], s);
     k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo);
