@@ -28,6 +28,8 @@ struct dxv_ctx {
     int device = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t copyStream = nullptr;    // dxv_update_vertices: the upload runs beside the frames' launches (made at its first call)
+    bool vbCopyQueued = false;           // dxv_update_vertices_device left a copy into the vertex buffer on `stream` (until the next refit / build)
     std::string err;
 
     // mesh (caller's layout)
@@ -139,7 +141,8 @@ struct dxv_ctx {
     int optPlists = 1;               // 1 = from a scene's second parity launch, 2 = from the first, 0 = tree walk
     uint32_t parityLaunchesOfScene = 0;
     float plMs = 0.0f;
-    bool nodesStale = false;         // a build / refit left the four-box copy (nodes64) behind (ensure_nodes brings it up to date before anything reads it)
+    int nodesStale = 0;              // what a build / refit left behind (ensure_nodes brings it up to date before anything reads it):
+                                     // 1 = the four-box copy (nodes64); 2 = every node box (dxv_refit stopped at the pyramid: deferBoxes)
     int listOpt = 0;                 // the listres option the current lists (or the decision against them) were made with
     uint8_t* dEmpty = nullptr;       // display pass: empty-brick flags of the grid
     size_t emptyCap = 0;
@@ -152,6 +155,7 @@ struct dxv_ctx {
     // options
     int optBrick = 4;        // 4x4x4 voxels = one wavefront per workgroup (fastest in the r01 sweeps)
     int optStack = 0;        // 0 = adaptive (start small, grow on overflow), else forced depth
+    int optDeferBoxes = 1;   // dxv_refit with lists wanted: node boxes only when a tree walk asks for them (0: always, as dxv_build does)
     int optRefit = 1;        // box merge of build and refit: 1 = min/max pyramid (default), 2 = level sweeps, 0 = atomic one-pass climb (17-30x slower, cross-check)
     int optMorton = 1;       // Morton brick order
     int optQueue = 1;        // postponed-leaf traversal
@@ -817,6 +821,7 @@ void dxv_destroy(dxv_ctx* c)
     (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dPlCells); (void)hipFree(c->dPlEntries); (void)hipFree(c->dPlScratch); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
     (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -877,7 +882,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -910,9 +915,10 @@ int ensure_nodes(dxv_ctx* c, hipStream_t stream)
     if (!c->nodesStale) return 0;
     BuildBuffers b{};
     fill_build_buffers(c, b);
-    DXV_HIP(c, lbvh_traversal_copies(b, stream));
+    if (c->nodesStale == 2) DXV_HIP(c, lbvh_refit_boxes(b, stream));
+    else DXV_HIP(c, lbvh_traversal_copies(b, stream));
     DXV_HIP(c, hipStreamSynchronize(stream));
-    c->nodesStale = false;
+    c->nodesStale = 0;
     return 0;
 }
 
@@ -924,11 +930,14 @@ int alloc_pyramid(dxv_ctx* c)
     return 0;
 }
 
-int finish_build(dxv_ctx* c, const char* who)
+// headerToDevice: the resident copy of the header (nothing on the device reads it -- launches get their words through kernel
+// arguments, an export writes the blob's header from the host's copy): dxv_build keeps it current, a refit saves the round trip
+int finish_build(dxv_ctx* c, const char* who, bool headerToDevice = true)
 {
     uint32_t rootInfo[16];
     DXV_HIP(c, hipMemcpyAsync(rootInfo, c->dRootInfo, sizeof(rootInfo), hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
+    c->vbCopyQueued = false;
     if (rootInfo[7] != 1) return fail(c, "%s: did not complete", who);
     if (rootInfo[11]) return fail(c, "%s: %u triangle(s) have a non-finite vertex position (NaN / Inf in the vertex buffer)", who, rootInfo[11]);
     memcpy(c->hdr.rootLo, &rootInfo[0], 12);
@@ -944,8 +953,10 @@ int finish_build(dxv_ctx* c, const char* who)
             return fail(c, "%s: refit produced an invalid root box (axis %d: %g > %g)", who, a,
                         (double)c->hdr.rootLo[a], (double)c->hdr.rootHi[a]);
     if (c->hdr.treeHeight == 0 || c->hdr.treeHeight > 64) return fail(c, "%s: implausible tree height %u", who, c->hdr.treeHeight);
-    DXV_HIP(c, hipMemcpyAsync(c->dScene, &c->hdr, sizeof(SceneHeader), hipMemcpyHostToDevice, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    if (headerToDevice) {
+        DXV_HIP(c, hipMemcpyAsync(c->dScene, &c->hdr, sizeof(SceneHeader), hipMemcpyHostToDevice, c->stream));
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->haveScene = true;
     c->stackNow = stack_round_up((int)(c->hdr.treeHeight + 3 < (uint32_t)c->optStack0 ? c->hdr.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_nodes = c->hdr.numNodes;
@@ -961,9 +972,13 @@ int dxv_update_vertices(dxv_ctx* c, const float* vb, uint32_t V)
     if (!c->haveMesh || !c->dVb) return fail(c, "dxv_update_vertices: no mesh resident on this context");
     if (!vb || V != c->V) return fail(c, "dxv_update_vertices: vertex count must stay %u, got %u", c->V, V);
     DXV_HIP(c, hipSetDevice(c->device));
-    if (sync_frames(c)) return 1;
-    DXV_HIP(c, hipMemcpyAsync(c->dVb, vb, sizeof(float) * 6 * (size_t)V, hipMemcpyHostToDevice, c->stream));
-    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    // No wait for the frames: their launches read the scene's triangle records and lists, never the vertex buffer -- its only
+    // readers are dxv_build and dxv_refit, which return after their work is done.  The upload therefore runs on a stream of its
+    // own, beside whatever the frames still have in flight (12 MB over PCIe at 1 M triangles: 0.25 ms hidden behind a launch).
+    if (!c->copyStream) DXV_HIP(c, hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+    if (c->vbCopyQueued) { DXV_HIP(c, hipStreamSynchronize(c->stream)); c->vbCopyQueued = false; }    // (an earlier device update lands first)
+    DXV_HIP(c, hipMemcpyAsync(c->dVb, vb, sizeof(float) * 6 * (size_t)V, hipMemcpyHostToDevice, c->copyStream));
+    DXV_HIP(c, hipStreamSynchronize(c->copyStream));
     return 0;
 }
 
@@ -975,6 +990,7 @@ int dxv_update_vertices_device(dxv_ctx* c, const void* dvb, uint32_t V)
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dVb, dvb, sizeof(float) * 6 * (size_t)V, hipMemcpyDeviceToDevice, c->stream));
+    c->vbCopyQueued = true;
     return 0;                                                          // (dxv_refit, on the same stream, comes next)
 }
 
@@ -994,9 +1010,12 @@ int dxv_refit(dxv_ctx* c)
     // goes through the lists, which are built from the triangle records alone (the half-float copy comes out of the box
     // merge's registers and is always current)
     b.deferCopies = c->optLists != 0 && c->hdr.hasWide;
+    // ... and so do the node boxes themselves (half of the refit's time at 1 M triangles): the refit stops at the min/max
+    // pyramid, whose top is the root box the launch needs, and ensure_nodes finishes it in front of the first tree walk
+    b.deferBoxes = c->optLists != 0 && c->optDeferBoxes && b.pyramid && c->T > 1;
     DXV_HIP(c, lbvh_refit(b, c->optRefit, c->hdr.treeHeight, c->stream, c->ev + 3));
-    c->nodesStale = b.deferCopies;
-    if (finish_build(c, "dxv_refit")) return 1;
+    c->nodesStale = b.deferBoxes ? 2 : b.deferCopies ? 1 : 0;
+    if (finish_build(c, "dxv_refit", false)) return 1;
     c->stats.refit_ms = elapsed(c->ev[3], c->ev[4]);
     return 0;
 }
@@ -1007,7 +1026,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -1018,7 +1037,7 @@ int dxv_build(dxv_ctx* c)
     if (c->optRefit != 1) b.pyramid = nullptr;
     b.deferCopies = c->optLists != 0 && c->hdr.hasWide;                // (as in dxv_refit: 0.6 ms of a 10 M-triangle build that most scenes never need)
     DXV_HIP(c, lbvh_build(b, c->optRefit, c->stream, c->ev));
-    c->nodesStale = b.deferCopies;
+    c->nodesStale = b.deferCopies ? 1 : 0;
     if (finish_build(c, "dxv_build")) return 1;
     c->haveHierarchy = true;
     c->stats.prep_ms = elapsed(c->ev[0], c->ev[1]);
@@ -1381,7 +1400,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         (withPl && (h.offPlCells != b.offPlCells || h.offPlEntries != b.offPlEntries)) || (!withPl && (h.offPlCells || h.offPlEntries || h.plCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = false;
+    c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
     // triangle count over the old, smaller buffers.
@@ -1491,6 +1510,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "refit")) {
         if (value < 0 || value > 2) return fail(c, "option refit: %lld not in {0,1,2}", (long long)value);
         c->optRefit = (int)value;
+    } else if (!strcmp(key, "deferboxes")) {
+        if (value < 0 || value > 1) return fail(c, "option deferboxes: %lld not in {0,1}", (long long)value);
+        c->optDeferBoxes = (int)value;
     } else if (!strcmp(key, "subbox")) {
         if (value != 0 && value != 1) return fail(c, "option subbox: %lld not in {0,1}", (long long)value);
         c->optSubbox = (int)value;
@@ -1628,7 +1650,7 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     const void* src = nullptr;
     size_t want = 0;
     const size_t T = c->T;
-    if ((what == DXV_DBG_NODES32 || what == DXV_DBG_NODES64) && c->haveScene && ensure_nodes(c, c->stream)) return 1;
+    if ((what == DXV_DBG_NODES || what == DXV_DBG_NODES32 || what == DXV_DBG_NODES64) && c->haveScene && ensure_nodes(c, c->stream)) return 1;
     switch (what) {
     case DXV_DBG_SORTED_KEYS: src = c->dKeys; want = sizeof(uint64_t) * T; if (c->scratchT != c->T) src = nullptr; break;
     case DXV_DBG_PARENTS: src = c->dParents; want = sizeof(uint32_t) * (2 * T - 1); if (c->scratchT != c->T) src = nullptr; break;

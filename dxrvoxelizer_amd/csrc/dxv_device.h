@@ -33,6 +33,8 @@ struct BuildBuffers {
     TriPos* triPos;         // T
     TriNrm* triNrm;         // T
     bool deferCopies;       // leave the four-box copy (nodes64) stale: lbvh_traversal_copies brings it up to date when a walk needs it (nodes32 always is)
+    bool deferBoxes;        // lbvh_refit only (pyramid refit): stop after the min/max pyramid -- root box from its top, node boxes left stale
+                            // until lbvh_refit_boxes; the lists are built from the triangle records alone
 };
 struct BuildTimes { float prep, sort, hierarchy, refit; };
 // refitMode: 0 = one pass, bottom-up with per-node arrival counters; 1 = level-synchronous sweeps
@@ -40,6 +42,7 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
 uint32_t pyramid_slots(uint32_t T);
 hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight, hipStream_t s, hipEvent_t ev[2]);
 hipError_t lbvh_traversal_copies(const BuildBuffers& b, hipStream_t s);   // nodes32 -> nodes64: the four-box copy the wide tree walks read
+hipError_t lbvh_refit_boxes(const BuildBuffers& b, hipStream_t s);        // what a refit with deferBoxes left undone: node boxes from the pyramid it made, then the copies
 
 // dirmap.hip -- direction-space lists of the reference rule (dxv_dirmap.h)
 struct DirEntry;

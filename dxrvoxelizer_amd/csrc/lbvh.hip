@@ -238,7 +238,7 @@ __global__ void k_root_info(const Node* __restrict__ nodes, uint32_t* __restrict
     rootInfo[7] = rootReady ? (*rootReady != 0u ? 1u : 0u) : 1u;      // sweep refit: the root has been stamped
 }
 
-static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStream_t s);
+static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStream_t s, uint32_t knownHeight = 0);
 __global__ void k_widen_from32(const Node32* __restrict__ nodes32, uint32_t n, Node64* __restrict__ out);    // (below, with the pyramid refit)
 
 // K4 + K5 + root info over an existing hierarchy (links and parent words in place).
@@ -506,7 +506,20 @@ uint32_t pyramid_slots(uint32_t T)            // entries (24 B box + 4 B depth e
 }
 
 // withHeights: first build -- subtree heights from the parent links as well (scratch: keysTmp, free after the sort)
-static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStream_t s)
+// rootInfo of a refit that stops at the pyramid: the root's box is the pyramid's top entry (the union of all leaf boxes by the
+// same min / max: the same bits as the union of the root's two child boxes), the height is the hierarchy's
+__global__ void k_root_info_pyramid(const Box6* __restrict__ pyr, uint32_t height, uint32_t* __restrict__ rootInfo)
+{
+    const Box6 b = pyr[1];
+    for (int a = 0; a < 3; ++a) {
+        rootInfo[a] = __builtin_bit_cast(uint32_t, b.lo[a]);
+        rootInfo[3 + a] = __builtin_bit_cast(uint32_t, b.hi[a]);
+    }
+    rootInfo[6] = height;
+    rootInfo[7] = 1u;
+}
+
+static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStream_t s, uint32_t knownHeight)
 {
     const uint32_t T = b.T, P = pyramid_slots(T);
     const uint32_t numNodes = T > 1 ? T - 1 : 1;
@@ -522,6 +535,10 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
     } else {
         k_pyramid_low<false><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, nullptr, nullptr);
         if (P > kPyrLeaves) k_pyramid_high<false><<<1, 1024, 0, s>>>(P, pyr, nullptr);
+        if (b.deferBoxes && knownHeight) {                       // (lbvh_refit_boxes does the rest when a walk wants the tree)
+            k_root_info_pyramid<<<1, 1, 0, s>>>(pyr, knownHeight, b.rootInfo);
+            return hipGetLastError();
+        }
         k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr, b.nodes32);
     }
     // (the half-float copy came out of k_refit_ranges' registers; the four-box copy is a re-arrangement of it)
@@ -539,6 +556,17 @@ hipError_t lbvh_traversal_copies(const BuildBuffers& b, hipStream_t s)
     return hipGetLastError();
 }
 
+// The node boxes a refit with deferBoxes did not write: the pyramid it built (b.pyramid, untouched since) and the triangle
+// records are current, so this is the refit's own last launch, late -- the same words as an undeferred refit (tests).
+hipError_t lbvh_refit_boxes(const BuildBuffers& b, hipStream_t s)
+{
+    const uint32_t T = b.T, P = pyramid_slots(T);
+    if (T < 2 || !b.pyramid) return hipErrorInvalidValue;
+    k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, reinterpret_cast<const Box6*>(b.pyramid), b.flags2, b.nodes,
+                                                                 nullptr, nullptr, nullptr, b.nodes32);
+    return lbvh_traversal_copies(b, s);
+}
+
 // Dynamic meshes (the reference API's ALLOW_UPDATE / PERFORM_UPDATE, XUSG/RayTracing/XUSGRayTracing.h:13-22,
 // unused by the sample): vertices moved, topology and Morton order kept -> re-gather the triangle
 // records and refit the boxes.  ev[0..1] bracket the work.
@@ -551,7 +579,7 @@ hipError_t lbvh_refit(const BuildBuffers& b, int refitMode, uint32_t treeHeight,
     if ((e = hipMemsetAsync(b.rootInfo + 11, 0, sizeof(uint32_t), s)) != hipSuccess) return e;      // (words 8..10: the build's triangle extent stays)
     (void)hipEventRecord(ev[0], s);
     k_tri_gather<<<blocks_for(b.T), kThreads, 0, s>>>(b.vb, b.ib, b.T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo);
-    if (b.pyramid && refitMode != 0 && b.T > 1) e = refit_pyramid(b, false, s);
+    if (b.pyramid && refitMode != 0 && b.T > 1) e = refit_pyramid(b, false, s, treeHeight);
     else e = refit_stage(b, refitMode, s, treeHeight);
     if (e != hipSuccess) return e;
     (void)hipEventRecord(ev[1], s);

@@ -83,6 +83,11 @@ class Voxelizer:
             self._check(self._lib.dxv_refit(self._ctx))
         return True
 
+    def Refit(self):
+        """dxv_refit on its own: after UpdateVertices(vb, refit=False), whose upload overlapped a launch still in flight."""
+        self._check(self._lib.dxv_refit(self._ctx))
+        return True
+
     def UpdateVerticesDevice(self, device_ptr, num_verts, refit=True):
         """The same from a device buffer (6 floats per vertex on this GPU, e.g. a torch tensor's data_ptr()): a mesh animated
         on the GPU never passes through the host."""

@@ -140,8 +140,11 @@ DXV_API int dxv_sync(dxv_ctx* ctx);
  * following dxv_voxelize* / dxv_sync / dxv_grid_* / dxv_texels_download / dxv_render / dxv_get_stats calls refer to
  * (default 0).  Each frame owns its grid, texel image, status words and -- frames 1 and 2 -- an internal stream,
  * so launches of different frames overlap on the GPU; scene, candidate lists and options are shared (an extra frame
- * costs its grid).  Calls that change what the frames read (dxv_set_mesh, dxv_build, dxv_refit, dxv_update_vertices,
- * dxv_scene_import, dxv_set_stream) first wait for every frame; dxv_sync_all does only that. */
+ * costs its grid).  Calls that change what the frames read (dxv_set_mesh, dxv_build, dxv_refit, dxv_scene_import,
+ * dxv_set_stream) first wait for every frame; dxv_sync_all does only that.  dxv_update_vertices does NOT wait: launches read
+ * the scene's triangle records, not the vertex buffer, so the next frame's vertices upload (on a stream of the library's own)
+ * while the current frame's launch still runs -- dxv_voxelize_async, dxv_update_vertices, dxv_refit (waits for the launch),
+ * dxv_voxelize_async, ... is a loop whose PCIe time is hidden. */
 #define DXV_FRAME_COUNT 3
 DXV_API int dxv_set_frame(dxv_ctx* ctx, uint32_t frame_index);
 DXV_API int dxv_sync_all(dxv_ctx* ctx);
@@ -222,6 +225,9 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   rowblock 0|1|2|4  ... per row (1), per 2 x 2 or 4 x 4 rows; 0 (default) decides by triangle size
  *   refit  0|1|2  box merge of dxv_build and dxv_refit: min/max pyramid over the leaf order (1,
  *                 default), level sweeps (2), one atomic pass (0)
+ *   deferboxes 0|1  dxv_refit while lists are wanted (lists != 0, refit = 1): stop at the pyramid -- triangle records and root
+ *                 box are current, the node boxes are written when a tree walk, an export or a debug download first needs them
+ *                 (1, default: a refit at 1 M triangles 0.14 -> 0.07 ms); 0 = every refit writes them
  *   lists  0|1|2  reference rule through direction-space lists (dxv_dirmap.h) or the tree walk (0).  The
  *                 lists are built from the scene's triangle records (0.65 ms at 1 M triangles): at the second
  *                 launch after a build / refit / import, or at the first when that launch is large enough for

@@ -798,6 +798,84 @@ def test_pyramid_refit_equals_sweep_refit_word_for_word(dxv, bunny):
             assert np.array_equal(words[0][0], other[0]) and np.array_equal(words[0][1], other[1]) and words[0][2] == other[2], len(ib) // 3
 
 
+def test_refit_defers_node_boxes_until_a_walk_needs_them(dxv, orc, bunny):
+    """A refit while lists are wanted stops at the min/max pyramid (deferboxes=1, default): the launch through the lists
+    needs triangle records and root box only.  The node boxes -- exact, half-float and four-box -- written later, when a
+    tree walk or a download asks, are word for word those of a refit that writes them at once, and the walk's grid is
+    the oracle's."""
+    vb, ib, _ = bunny
+    lo, hi = vb[:, :3].min(0) - 0.1, vb[:, :3].max(0) + 0.1
+    pins = np.zeros((2, 6), np.float32)
+    pins[0, :3], pins[1, :3] = lo, hi
+    vb0 = np.concatenate([vb, pins]).astype(np.float32)
+    rng = np.random.default_rng(5)
+    late, now = dxv.Voxelizer(0), dxv.Voxelizer(0)
+    now.set_option("deferboxes", 0)
+    for v in (late, now):
+        v.set_option("lists", 2)
+        v.InitFromArrays(vb0, ib)
+    for step in range(3):
+        vb1 = vb0.copy()
+        vb1[:-2, :3] += rng.uniform(-0.004, 0.004, size=(len(vb), 3)).astype(np.float32)
+        want = orc.Scene(vb1, ib).voxelize(64)
+        for v in (late, now):
+            v.UpdateVertices(vb1)
+            v.Voxelize(64)                                   # through the lists: no node is read
+            assert v.stats()["list_entries"] > 0
+            assert np.array_equal(v.Grid(), want), step
+        assert late.stats()["refit_ms"] > 0 and np.array_equal(late.stats()["bound"], now.stats()["bound"])
+        if step == 1:
+            continue                                         # (two refits in a row without a walk in between)
+        for what in (DBG_NODES, DBG_NODES32, DBG_NODES64):
+            assert np.array_equal(late.debug(what), now.debug(what)), (step, what)
+        late.set_option("lists", 0)
+        late.Voxelize(64)                                    # the tree walk over the late boxes
+        assert np.array_equal(late.Grid(), want)
+        late.set_option("lists", 2)
+    # a walk straight after a deferred refit (no download in between) finishes the boxes itself
+    late.UpdateVertices(vb0)
+    late.set_option("lists", 0)
+    late.Voxelize(64, 1)                                     # parity rule, tree walk (first parity launch: no row lists yet)
+    late.Voxelize(64)
+    assert np.array_equal(late.Grid(), orc.Scene(vb0, ib).voxelize(64))
+    late.close(), now.close()
+
+
+def test_vertex_upload_overlaps_a_launch_in_flight(dxv, orc, bunny):
+    """dxv_update_vertices does not wait for the frames (launches read the scene, not the vertex buffer): an upload made
+    while a launch is in flight changes nothing about that launch's grid, and the following refit + launch give the moved
+    mesh's grid.  A device update queued before a host update lands first."""
+    import torch
+    vb, ib, _ = bunny
+    lo, hi = vb[:, :3].min(0) - 0.1, vb[:, :3].max(0) + 0.1
+    pins = np.zeros((2, 6), np.float32)
+    pins[0, :3], pins[1, :3] = lo, hi
+    vb0 = np.concatenate([vb, pins]).astype(np.float32)
+    vb1 = vb0.copy()
+    vb1[:-2, 1] += np.float32(0.05)
+    s0, s1 = orc.Scene(vb0, ib).voxelize(96), orc.Scene(vb1, ib).voxelize(96)
+    assert not np.array_equal(s0, s1)
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 2)
+    v.InitFromArrays(vb0, ib)
+    for frame in range(4):
+        cur, nxt = (vb0, vb1) if frame % 2 == 0 else (vb1, vb0)
+        v.Voxelize(96, sync=False)
+        v.UpdateVertices(nxt, refit=False)                   # upload beside the launch
+        v.Sync()
+        assert np.array_equal(v.Grid(), s0 if cur is vb0 else s1), frame
+        v.Refit()
+    v.Voxelize(96)
+    assert np.array_equal(v.Grid(), s0)
+    d = torch.from_numpy(vb1).cuda()
+    v.UpdateVerticesDevice(d.data_ptr(), len(vb1), refit=False)      # queued on the context's stream ...
+    v.UpdateVertices(vb0, refit=False)                               # ... the later host update must win
+    v.Refit()
+    v.Voxelize(96)
+    assert np.array_equal(v.Grid(), s0)
+    v.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # direction-space lists (option lists): the reference rule without a tree walk
 # ---------------------------------------------------------------------------------------------
