@@ -34,8 +34,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t* __re
 // Two-level exclusive scan of the digit-major histogram hist[256][numTiles]:
 //   k_sort_scan_rows   one workgroup per digit: in-place exclusive scan of its row (coalesced),
 //                      row total -> totals[digit]
-//   k_sort_scan_digits one workgroup: exclusive scan of the 256 totals -> digitBase[256]
-// The scatter kernel adds digitBase[d] + hist[d][tile].  (A single-workgroup scan of the whole
+//   the 256 totals     scanned by every workgroup of the scatter kernel for itself (eight steps in LDS: less than the
+//                      launch of a one-workgroup kernel in between, 5 us + its gap per pass)
+// The scatter kernel adds base[d] + hist[d][tile].  (A single-workgroup scan of the whole
 // 256 x numTiles array took 92 us per pass at 1 M keys, 80 % of the sort.)
 __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t* __restrict__ hist, uint32_t numTiles, uint32_t* __restrict__ totals)
 {
@@ -64,31 +65,27 @@ __global__ __launch_bounds__(256) void k_sort_scan_rows(uint32_t* __restrict__ h
     if (tid == 0) totals[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_sort_scan_digits(const uint32_t* __restrict__ totals, uint32_t* __restrict__ digitBase)
-{
-    __shared__ uint32_t part[256];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t v = totals[tid];
-    part[tid] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        const uint32_t a = tid >= off ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += a;
-        __syncthreads();
-    }
-    digitBase[tid] = part[tid] - v;
-}
-
 __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                                uint32_t n, int shift, const uint32_t* __restrict__ offs,
-                                                               const uint32_t* __restrict__ digitBase, uint32_t numTiles)
+                                                               const uint32_t* __restrict__ totals, uint32_t numTiles)
 {
     __shared__ uint32_t run[256];            // keys of each digit already placed by earlier items
     __shared__ uint32_t wcnt[kWaves][256];   // per-wave digit counts of the current item
     const uint32_t tile = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    run[tid] = digitBase[tid] + offs[(uint64_t)tid * numTiles + tile]; // global start of (digit = tid, this tile)
+    // where digit `tid` starts in the output: exclusive scan of the 256 digit totals (run[] as the scan's scratch)
+    const uint32_t mine = totals[tid];
+    run[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t a = tid >= off ? run[tid - off] : 0u;
+        __syncthreads();
+        run[tid] += a;
+        __syncthreads();
+    }
+    const uint32_t digitStart = run[tid] - mine;
+    __syncthreads();
+    run[tid] = digitStart + offs[(uint64_t)tid * numTiles + tile];     // global start of (digit = tid, this tile)
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) wcnt[w][tid] = 0;
     __syncthreads();
@@ -134,12 +131,10 @@ hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint3
     uint64_t* dst = tmp;
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = loBit + 8 * pass;
-        uint32_t* totals = hist + 256u * (size_t)numTiles;      // 256 row totals + 256 digit bases behind the histogram
-        uint32_t* digitBase = totals + 256;
+        uint32_t* totals = hist + 256u * (size_t)numTiles;      // 256 row totals behind the histogram
         k_sort_hist<<<numTiles, kSortThreads, 0, s>>>(src, n, shift, hist, numTiles);
         k_sort_scan_rows<<<256, 256, 0, s>>>(hist, numTiles, totals);
-        k_sort_scan_digits<<<1, 256, 0, s>>>(totals, digitBase);
-        k_sort_scatter<<<numTiles, kSortThreads, 0, s>>>(src, dst, n, shift, hist, digitBase, numTiles);
+        k_sort_scatter<<<numTiles, kSortThreads, 0, s>>>(src, dst, n, shift, hist, totals, numTiles);
         uint64_t* t = src; src = dst; dst = t;
     }
     if (result) *result = src;
