@@ -60,6 +60,7 @@ def main():
         v.set_option("refit", int(rng.choice([1, 1, 2, 0])) if T < 30000 else int(rng.choice([1, 2])))   # box merge of the build
         v.InitFromArrays(vb, ib)
         if rng.integers(0, 3) == 0:                       # same vertices again: the refit must reproduce the build's boxes
+            v.set_option("deferboxes", int(rng.integers(0, 2)))       # ... at once, or when the first tree walk asks for them
             v.UpdateVertices(np.ascontiguousarray(vb, np.float32))
         cases += 1
         for _ in range(4):
