@@ -78,6 +78,16 @@ public:
 		return dxv_update_vertices(m_ctx, vb, numVerts) == 0 && dxv_refit(m_ctx) == 0;
 	}
 
+	// The two halves on their own, for a loop that hides the upload: VoxelizeAsync(frame i); UploadVertices(frame i + 1) --
+	// dxv_update_vertices does not wait for launches in flight, they read the scene and not the vertex buffer --;
+	// Refit() (waits for the launch, then refits); VoxelizeAsync(frame i + 1); ...
+	bool UploadVertices(const float* vb, uint32_t numVerts)
+	{
+		if (!m_ctx) return setError("UploadVertices before Init");
+		return dxv_update_vertices(m_ctx, vb, numVerts) == 0;
+	}
+	bool Refit() { return m_ctx ? dxv_refit(m_ctx) == 0 : setError("Refit before Init"); }
+
 	// ... from a device buffer (a mesh animated on the GPU)
 	bool UpdateVerticesDevice(const void* deviceVb, uint32_t numVerts)
 	{
