@@ -880,6 +880,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
     DXV_HIP(c, hipStreamSynchronize(c->stream));
+    c->vbCopyQueued = false;
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
     c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
