@@ -71,8 +71,9 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "dxv.h"\nint main(void) { dxv_ctx* c = 0; dxv_stats s; (void)s; return dxv_create(&c, 0) == 0 ? (dxv_destroy(c), 0) : 1; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                            "-o", str(tmp_path / "use.o")])
-    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "voxelize_obj.cpp")])
+    for prog in ("voxelize_obj.cpp", "refit_loop.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", prog)])
 
 
 def test_cpp_multi_gpu_host_compiles_and_links(tmp_path, dxvlib):

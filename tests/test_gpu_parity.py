@@ -570,6 +570,34 @@ def test_cpp_voxelizer_mirror(orc, tmp_path):
     assert np.array_equal(g, want) and int(r.stdout.strip()) == int(want.sum())
 
 
+def test_cpp_refit_loop_with_overlapped_upload(orc, bunny, tmp_path):
+    """The animated-mesh loop from C++ (tests/cpp/refit_loop.cpp over include/dxv_voxelizer.hpp): VoxelizeAsync, UploadVertices of
+    the next pose beside the launch, Refit -- the last frame's grid equals the oracle's on that pose, whichever it is."""
+    vb, ib, _ = bunny
+    lo, hi = vb[:, :3].min(0) - 0.1, vb[:, :3].max(0) + 0.1
+    pins = np.zeros((2, 6), np.float32)
+    pins[0, :3], pins[1, :3] = lo, hi                        # unreferenced vertices pin the bound of both poses
+    a = np.concatenate([vb, pins]).astype(np.float32)
+    b = a.copy()
+    b[:-2, 0] += np.float32(0.04) * np.sin(9.0 * b[:-2, 1]).astype(np.float32)
+    a.tofile(tmp_path / "a.bin"), b.tofile(tmp_path / "b.bin"), np.ascontiguousarray(ib, np.uint32).tofile(tmp_path / "ib.bin")
+    exe = tmp_path / "refit_loop"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "refit_loop.cpp"),
+                           "-o", str(exe), "-L" + os.path.join(ROOT, "dxrvoxelizer_amd"), "-ldxv",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dxrvoxelizer_amd")])
+    want = {"a": orc.Scene(a, ib).voxelize(64), "b": orc.Scene(b, ib).voxelize(64)}
+    assert not np.array_equal(want["a"], want["b"])
+    for frames in (1, 4, 7):
+        out = tmp_path / ("grid%d.bin" % frames)
+        r = subprocess.run([str(exe), str(tmp_path / "a.bin"), str(tmp_path / "b.bin"), str(tmp_path / "ib.bin"), "64", str(frames), str(out)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        solid, pose = r.stdout.split()
+        assert pose == ("a" if frames % 2 else "b")
+        g = np.fromfile(out, np.uint8).reshape(64, 64, 64)
+        assert np.array_equal(g, want[pose]) and int(solid) == int(want[pose].sum()), frames
+
+
 def test_cpp_multi_gpu_host(orc, bunny, grids_json, tmp_path):
     """The multi-GPU host in C++ (include/dxv_multi.hpp): device-set constructor, rank-0 build, ncclBroadcast of the scene blob
     through the RCCL C API, block-cyclic and slab Voxelize, reassembly -- no Python in the path.  Runs with the devices this
