@@ -268,7 +268,10 @@ def main_wide():
     jobs += [(f"{n}/64/parity", lambda n=n: compare_parity(n, 64)) for n in ("bunny", "dragon")]
     jobs += [(f"{n}/128/parity", lambda n=n: compare_parity(n, 128)) for n in ("bunny", "dragon")]
     jobs += [("torus1m/512/parity/slices", lambda: compare_parity("torus1m", 512, 6)),
-             ("dragon9/512/parity/slices", lambda: compare_parity("dragon9", 512, 6))]
+             ("dragon9/512/parity/slices", lambda: compare_parity("dragon9", 512, 6)),
+             ("bunny16/512/parity/slices", lambda: compare_parity("bunny16", 512, 6))]      # (closed surfaces only: a crossing count
+                                                                                               # has no inside to find in a soup)
+    jobs += [(f"turingbowl/{n}/parity", lambda n=n: compare_parity("turingbowl", n)) for n in (64, 128)]
     only = sys.argv[2:]
     for key, job in jobs:
         if only and not any(o in key for o in only):

@@ -126,7 +126,8 @@ def test_anchor_wide_committed_results(anchor_wide, grids_json):
         assert rec["sampled_voxels"] >= 8000 and rec["near_surface"] >= rec["sampled_voxels"] // 3
         assert rec["differ"] == sum(rec["classes"].values())
         assert 0 < rec["solid_oracle"] < rec["sampled_voxels"]
-    for key in ("bunny/64/parity", "dragon/64/parity", "bunny/128/parity", "dragon/128/parity", "torus1m/512/parity/slices", "dragon9/512/parity/slices"):
+    for key in ("bunny/64/parity", "dragon/64/parity", "bunny/128/parity", "dragon/128/parity", "turingbowl/64/parity", "turingbowl/128/parity",
+                "torus1m/512/parity/slices", "dragon9/512/parity/slices", "bunny16/512/parity/slices"):
         rec = anchor_wide[key]
         assert rec["rule"] == "parity" and rec["classes"]["unexplained"] == 0
         assert rec["differ"] <= rec["near_edge_voxels"] <= rec["voxels_compared"] // 1000
