@@ -1555,7 +1555,7 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
         c->optListRes = (int)value;
     } else if (!strcmp(key, "ablate")) {
 #if defined(DXV_ABLATE)
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8}", (long long)value);
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8 && value != 16 && value != 18) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8,16,18}", (long long)value);
         c->optAblate = (int)value;
 #else
         // the timing-only variants of the lists kernel write wrong grids by design: they exist only in the library that

@@ -484,7 +484,7 @@ DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32
 // and tested when some lane's queue is full or every lane has finished scanning -- all lanes with
 // work test together.
 // ABL (timing-only builds, tools/ablate.py; 0 in every shipped path): 8 = stop before the texel lookup, 1 = stop after it,
-// 2 = scan the entries but test no triangle
+// 2 = scan the entries but test no triangle, 16 = the scan's loads wave-uniform (with 2: 18)
 template <class Stack, int ABL = 0>
 DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, const Stack& stk, int cap, Hit& best, float& bestDet)
 {
@@ -533,6 +533,11 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
             // -5 % on the 1 M-triangle scene; voting on the second one as well: +7 %)
             const bool wide = wave_any(i + 2u <= last);
             const DirEntry* p = dm.entries + i;
+#if defined(DXV_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
+            // (timing only, 16: every lane loads the FIRST active lane's entries -- one line access per load instead of one per
+            // lane, instruction count unchanged: what the launch would gain if the scan's loads were wave-uniform)
+            if (ABL & 16) p = dm.entries + __builtin_amdgcn_readfirstlane(i);
+#endif
             const DirEntry e0 = p[0], e1 = p[1];
             DirEntry e2, e3;
             if (wide && i + 2u <= last) { e2 = p[2]; e3 = p[3]; }       // (lanes whose list ends here issue no access for what they would not look at)

@@ -752,6 +752,8 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
                 case 4: k_voxelize<B, 16, 0, false, 4, 4><<<g, b, 0, s>>>(p); return hipGetLastError();
                 case 6: k_voxelize<B, 16, 0, false, 4, 6><<<g, b, 0, s>>>(p); return hipGetLastError();
                 case 8: k_voxelize<B, 16, 0, false, 4, 8><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 16: k_voxelize<B, 16, 0, false, 4, 16><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 18: k_voxelize<B, 16, 0, false, 4, 18><<<g, b, 0, s>>>(p); return hipGetLastError();
                 default: return hipErrorInvalidValue;
                 }
             }
