@@ -168,6 +168,8 @@ def load_mesh(name):
         return meshes.torus()
     if name == "soup1m":
         return meshes.soup(1_000_000)
+    if name == "soup10m":
+        return meshes.soup()                                 # BASELINE config 5's own mesh (10,000,000 triangles)
     raise KeyError(name)
 
 
@@ -264,7 +266,8 @@ def main_wide():
     jobs += [("dragon9/512/reference/sample", lambda: compare_sampled("dragon9", 512, 60000)),
              ("torus1m/512/reference/sample", lambda: compare_sampled("torus1m", 512, 60000)),
              ("soup1m/256/reference/sample", lambda: compare_sampled("soup1m", 256, 60000)),
-             ("bunny16/512/reference/sample", lambda: compare_sampled("bunny16", 512, 60000))]
+             ("bunny16/512/reference/sample", lambda: compare_sampled("bunny16", 512, 60000)),
+             ("soup10m/512/reference/sample", lambda: compare_sampled("soup10m", 512, 20000))]      # BASELINE config 5 itself
     jobs += [(f"{n}/64/parity", lambda n=n: compare_parity(n, 64)) for n in ("bunny", "dragon")]
     jobs += [(f"{n}/128/parity", lambda n=n: compare_parity(n, 128)) for n in ("bunny", "dragon")]
     jobs += [("torus1m/512/parity/slices", lambda: compare_parity("torus1m", 512, 6)),
