@@ -267,7 +267,8 @@ def main_wide():
              ("torus1m/512/reference/sample", lambda: compare_sampled("torus1m", 512, 60000)),
              ("soup1m/256/reference/sample", lambda: compare_sampled("soup1m", 256, 60000)),
              ("bunny16/512/reference/sample", lambda: compare_sampled("bunny16", 512, 60000)),
-             ("soup10m/512/reference/sample", lambda: compare_sampled("soup10m", 512, 20000))]      # BASELINE config 5 itself
+             ("soup10m/512/reference/sample", lambda: compare_sampled("soup10m", 512, 20000)),      # BASELINE config 5 itself
+             ("dragon9/1024/reference/sample", lambda: compare_sampled("dragon9", 1024, 20000))]    # ... config 4's own grid
     jobs += [(f"{n}/64/parity", lambda n=n: compare_parity(n, 64)) for n in ("bunny", "dragon")]
     jobs += [(f"{n}/128/parity", lambda n=n: compare_parity(n, 128)) for n in ("bunny", "dragon")]
     jobs += [("torus1m/512/parity/slices", lambda: compare_parity("torus1m", 512, 6)),

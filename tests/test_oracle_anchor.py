@@ -122,7 +122,7 @@ def test_anchor_wide_committed_results(anchor_wide, grids_json):
     tb = anchor_wide["turingbowl/128/reference"]
     assert tb["differ"] == tb["classes"]["edge"] == 10
     for key in ("dragon9/512/reference/sample", "torus1m/512/reference/sample", "soup1m/256/reference/sample", "bunny16/512/reference/sample",
-                "soup10m/512/reference/sample"):
+                "soup10m/512/reference/sample", "dragon9/1024/reference/sample"):
         rec = anchor_wide[key]
         assert rec["sampled_voxels"] >= 8000 and rec["near_surface"] >= rec["sampled_voxels"] // 3
         assert rec["differ"] == sum(rec["classes"].values())
