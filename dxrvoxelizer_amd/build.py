@@ -56,16 +56,18 @@ def _compile(src, extra, objdir=None):
     return obj, r.stderr
 
 
-def build(force=False, save_temps=False, verbose=False, ablate=False):
+def build(force=False, save_temps=False, verbose=False, ablate=False, defines=(), name=None):
     """ablate=True: a second library, libdxv_ablate.so, with the timing-only variants of the lists kernel (-DDXV_ABLATE:
     option `ablate`, wrong grids by design) for tools/ablate.py; the product library never contains them."""
     lib = os.path.join(HERE, "libdxv_ablate.so") if ablate else LIB
     objdir = OBJDIR + ("_ablate" if ablate else "")
+    if name:                                                    # a diagnostic variant: libdxv_<name>.so built with extra -D flags
+        lib, objdir = os.path.join(HERE, f"libdxv_{name}.so"), OBJDIR + "_" + name
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS] + [__file__]
     if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
         return lib
     os.makedirs(objdir, exist_ok=True)
-    extra = (["-save-temps=obj"] if save_temps else []) + (["-DDXV_ABLATE"] if ablate else [])
+    extra = (["-save-temps=obj"] if save_temps else []) + (["-DDXV_ABLATE"] if ablate else []) + ["-D" + d for d in defines]
     with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         results = list(ex.map(lambda s: _compile(s, extra, objdir), SOURCES))
     for _, err in results:

@@ -250,6 +250,60 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
     if (count > 0xffffu) atomicMax(longest, count);                    // (only what does not fit is reported: one address, 300 k texels)
 }
 
+// Max-mip of the texels' far radii (dm_mip_max, dxv_dirmap.h).  k_dm_mip_tiles: one workgroup per TILE x TILE texels of a face
+// (TILE = min(R, 32)): level 0 from the cells, levels 1 .. log2(TILE) through LDS.  k_dm_mip_top: the levels above, one
+// workgroup, each level from the one below (a few hundred words at R = 256).
+__global__ __launch_bounds__(256) void k_dm_mip_tiles(const DirCell* __restrict__ cells, uint32_t R, uint32_t tile, uint16_t* __restrict__ mip)
+{
+    __shared__ uint16_t lds[2][32 * 32];
+    const uint32_t tilesPerSide = R / tile, face = blockIdx.x / (tilesPerSide * tilesPerSide), in = blockIdx.x % (tilesPerSide * tilesPerSide);
+    const uint32_t ti0 = (in % tilesPerSide) * tile, tj0 = (in / tilesPerSide) * tile;
+    for (uint32_t k = threadIdx.x; k < tile * tile; k += 256u) {
+        const uint32_t i = ti0 + k % tile, j = tj0 + k / tile;
+        const uint32_t key = dm_mip_key(cells[(face * R + j) * R + i]);
+        lds[0][k] = (uint16_t)key;
+        mip[(face * R + j) * R + i] = (uint16_t)key;
+    }
+    __syncthreads();
+    uint32_t side = tile, cur = 0, off = 0, r = R;
+    for (uint32_t l = 1; side > 1u; ++l) {
+        off += 6u * r * r; r >>= 1;
+        const uint32_t half = side >> 1;
+        for (uint32_t k = threadIdx.x; k < half * half; k += 256u) {
+            const uint32_t x = k % half, y = k / half;
+            const uint16_t* a = lds[cur] + (2u * y) * side + 2u * x;
+            uint16_t m = a[0];
+            if (a[1] > m) m = a[1];
+            if (a[side] > m) m = a[side];
+            if (a[side + 1u] > m) m = a[side + 1u];
+            lds[cur ^ 1u][y * half + x] = m;
+            mip[off + (face * r + (tj0 >> l) + y) * r + (ti0 >> l) + x] = m;
+        }
+        __syncthreads();
+        side = half; cur ^= 1u;
+    }
+}
+__global__ __launch_bounds__(1024) void k_dm_mip_top(uint32_t R, uint32_t fromLevel, uint16_t* mip)
+{
+    const uint32_t levels = dm_mip_levels(R);
+    for (uint32_t l = fromLevel + 1u; l < levels; ++l) {
+        const uint32_t r = R >> l, rp = r << 1;
+        const uint16_t* below = mip + dm_mip_offset(R, l - 1u);
+        uint16_t* out = mip + dm_mip_offset(R, l);
+        for (uint32_t k = threadIdx.x; k < 6u * r * r; k += 1024u) {
+            const uint32_t face = k / (r * r), y = (k % (r * r)) / r, x = k % r;
+            const uint16_t* a = below + (face * rp + 2u * y) * rp + 2u * x;
+            uint16_t m = a[0];
+            if (a[1] > m) m = a[1];
+            if (a[rp] > m) m = a[rp];
+            if (a[rp + 1u] > m) m = a[rp + 1u];
+            out[k] = m;
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row lists of the parity rule.  All its rays are +X lines: a row of voxels (fixed y, z) is one point of the (y, z)
 // plane, and the triangles its rays can cross are those whose padded box covers that point (parity_row_setup's first
@@ -347,6 +401,17 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries, longCells, sums + 1);
     k_dm_stops_long<<<4096, 64, 0, s>>>(cells, longCells, sums + 1, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+// mip: dm_mip_words(R) 16-bit words
+hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream_t s)
+{
+    const uint32_t tile = R < 32u ? R : 32u;
+    uint32_t tileLevel = 0;
+    while ((1u << tileLevel) < tile) ++tileLevel;
+    k_dm_mip_tiles<<<6u * (R / tile) * (R / tile), 256, 0, s>>>(cells, R, tile, mip);
+    if (tileLevel + 1u < dm_mip_levels(R)) k_dm_mip_top<<<1, 1024, 0, s>>>(R, tileLevel, mip);
     return hipGetLastError();
 }
 

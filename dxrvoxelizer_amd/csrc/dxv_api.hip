@@ -85,6 +85,12 @@ struct dxv_ctx {
         uint32_t grid_dim = 0, z0 = 0, nz = 0, stack_entries = 0, redo_rays = 0, row_block = 0, list_entries = 0, list_res = 0;
         uint32_t plan_bricks = 0, plan_waves = 0;
         float plan_ms = 0.0f;
+        // work queue of the lists kernel (traverse.hip): the frame's own, written and read on the frame's stream only
+        uint32_t* dQueue = nullptr;
+        size_t queueWords = 0;           // allocated 32-bit words
+        bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
+        bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
+        hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
     };
     Frame frames[DXV_FRAME_COUNT];
     uint32_t cur = 0;                    // dxv_set_frame
@@ -109,26 +115,15 @@ struct dxv_ctx {
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
     uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
-    // dispatch plans of the lists kernel (traverse.hip: live bricks only, regions heaviest first, dealt to the XCDs by cost):
-    // one per partition launched against the current lists, built at the partition's second launch (option plan = 1) so
-    // that a mesh refitted every frame never pays for one
-    struct Plan {
-        bool used = false, valid = false;
-        uint64_t epoch = 0;              // listEpoch of the lists it was probed against
-        uint32_t N = 0, nz = 0, z0 = 0, zBlock = 0, zPeriod = 0;
-        uint32_t* dPlan = nullptr;
-        size_t cap = 0;
-        uint32_t count = 0, live = 0, bricks = 0, seen = 0;
-        uint64_t id = 0, lastUse = 0;
-        float ms = 0.0f;
-    };
-    static constexpr int kPlans = 8;
-    Plan plans[kPlans];
-    uint64_t listEpoch = 0, planClock = 0, planIds = 0;
-    int optPlan = 1;                 // 0 = no plans (brick box + Morton order), 1 = from a partition's second launch, 2 = from the first
+    // max-mip of the lists' far radii (dxv_dirmap.h): made with the lists, what a launch's work queue is probed against
+    uint16_t* dMip = nullptr;
+    size_t mipCap = 0;               // 16-bit words
+    uint64_t listEpoch = 0;          // counts list builds / imports: a frame's queue belongs to the lists it was probed against
+    int optPlan = 1;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
+                                     // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch, 2 = on every launch
+    int optQueueSteal = 1;           // A/B only: 0 = waves never take another XCD's bricks
+    int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
     int optEvents = 1;               // bracket every launch with two HIP events (stats.voxelize_ms); 0: none (a caller timing its own loop)
-    int optPlanRegion = 8;           // log2 bricks per region of a plan (6 .. 9): 256 bricks -1 ... -4 % against 512 at 512^3 (profiles/r03/ab_planregion.jsonl)
-    int optPlanOrder = 3;            // order of the regions inside a plan (plan_for): 3 = balanced by cost, Morton order, cheapest regions last
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
     uint32_t* dPlCells = nullptr;
@@ -202,6 +197,8 @@ int frame_prepare(dxv_ctx* c, uint32_t i)
     if (i && !f.ownStream) DXV_HIP(c, hipStreamCreateWithFlags(&f.ownStream, hipStreamNonBlocking));
     if (!f.ev0) DXV_HIP(c, hipEventCreate(&f.ev0));
     if (!f.ev1) DXV_HIP(c, hipEventCreate(&f.ev1));
+    if (!f.evP0) DXV_HIP(c, hipEventCreate(&f.evP0));
+    if (!f.evP1) DXV_HIP(c, hipEventCreate(&f.evP1));
     if (!f.dStatus) DXV_HIP(c, hipMalloc(&f.dStatus, 256));
     if (!f.dRedo) DXV_HIP(c, hipMalloc(&f.dRedo, sizeof(uint64_t) * kRedoCap));
     // on the frame's own stream, and finished before anything reads the words: the streams are non-blocking, a memset on the
@@ -340,7 +337,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     // for the gigabytes of a 10 M-triangle scene)
     uint8_t *scratchA = nullptr, *scratchB = nullptr;
     auto scratch = [&](uint8_t*& keep, size_t& cap, size_t bytes, uint8_t*& out) -> hipError_t {
-        if (bytes <= cap) { out = keep; return hipSuccess; }
+        if (bytes <= cap && (cap < (256ull << 20) || bytes >= cap / 4)) { out = keep; return hipSuccess; }    // (a much smaller scene gives the gigabytes back)
         (void)hipFree(keep); keep = nullptr; cap = 0;
         const hipError_t err = hipMalloc(&out, bytes);
         if (err == hipSuccess && bytes <= (16ull << 30)) { keep = out; cap = bytes; }    // (kept: a multi-GB hipMalloc is 0.1 - 0.3 s, ten builds' worth)
@@ -435,6 +432,13 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, &longest, stream)) != hipSuccess)
         return bail(e, "dirmap_fill");
 
+    // the max-mip of the texels' far radii goes with the lists (a launch's work queue is probed against it)
+    if (dm_mip_words(R) > c->mipCap) {
+        (void)hipFree(c->dMip); c->dMip = nullptr; c->mipCap = 0;
+        if ((e = hipMalloc(&c->dMip, sizeof(uint16_t) * (size_t)dm_mip_words(R))) != hipSuccess) return bail(e, "hipMalloc");
+        c->mipCap = dm_mip_words(R);
+    }
+    if ((e = dirmap_mip(c->dListCells, R, c->dMip, stream)) != hipSuccess) return bail(e, "dirmap_mip");
     if (t1) (void)hipEventRecord(t1, stream);
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     if (t0 && t1) c->listMs = elapsed(t0, t1);
@@ -447,7 +451,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     c->listRes = R;
     c->listState = 1;
     c->listOpt = c->optListRes;
-    ++c->listEpoch;                                       // (dispatch plans probed against older lists are stale)
+    ++c->listEpoch;                                       // (work queues probed against older lists are stale)
     return 0;
 }
 
@@ -524,124 +528,6 @@ int build_plists(dxv_ctx* c, hipStream_t stream)
     return done(1);
 }
 
-// The dispatch plan of this launch's partition against the current lists, or NULL (not yet worth one / none wanted / no
-// memory: the launch then takes the brick box in Morton order).  Builds it when due: one probe launch over the partition, a
-// few KB to the host, the regions placed by cost (LPT over the eight XCDs, heaviest first), one fill launch; synchronous on
-// the launching stream, once per (lists, partition).
-dxv_ctx::Plan* plan_for(dxv_ctx* c, const VoxelizeParams& p, hipStream_t stream, int& err)
-{
-    using Plan = dxv_ctx::Plan;
-    err = 0;
-    if (!c->optPlan) return nullptr;
-    Plan* pl = nullptr;
-    for (Plan& q : c->plans)
-        if (q.used && q.epoch == c->listEpoch && q.N == p.N && q.nz == p.nz && q.z0 == p.z0 && q.zBlock == p.zBlock && q.zPeriod == p.zPeriod) { pl = &q; break; }
-    if (!pl) {
-        pl = &c->plans[0];
-        for (Plan& q : c->plans) {
-            if (!q.used) { pl = &q; break; }
-            if (q.lastUse < pl->lastUse) pl = &q;
-        }
-        pl->used = true; pl->valid = false; pl->seen = 0;
-        pl->epoch = c->listEpoch; pl->N = p.N; pl->nz = p.nz; pl->z0 = p.z0; pl->zBlock = p.zBlock; pl->zPeriod = p.zPeriod;
-    }
-    pl->lastUse = ++c->planClock;
-    ++pl->seen;
-    if (pl->valid) return pl;
-    if (c->optPlan == 1 && pl->seen < 2) return nullptr;
-    // build
-    VoxelizeParams q = p;
-    const uint32_t rb = (uint32_t)c->optPlanRegion;
-    const uint32_t nb = plan_layout(q), nr = plan_regions(nb, rb);
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    uint32_t* scratch = nullptr;
-    auto done = [&](hipError_t e, const char* what) -> Plan* {
-        if (t0) (void)hipEventDestroy(t0);
-        if (t1) (void)hipEventDestroy(t1);
-        (void)hipFree(scratch);
-        if (e == hipSuccess) return pl;
-        pl->valid = false;
-        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); pl->seen = 0; return nullptr; }   // no plan: the plain launch still works
-        err = fail(c, "dispatch plan: %s failed: %s", what, hipGetErrorString(e));
-        return nullptr;
-    };
-    hipError_t e;
-    if ((e = hipMalloc(&scratch, sizeof(uint32_t) * ((size_t)nb + 4 * (size_t)nr))) != hipSuccess) return done(e, "hipMalloc");
-    uint32_t *cost = scratch, *regionCost = scratch + nb, *regionLive = regionCost + nr, *regionDst = regionLive + nr;
-    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, stream);
-    if ((e = plan_probe(p, rb, cost, regionCost, regionLive, stream)) != hipSuccess) return done(e, "plan_probe");
-    std::vector<uint32_t> host(2 * (size_t)nr), dst(2 * (size_t)nr, 0u);
-    if ((e = hipMemcpyAsync(host.data(), regionCost, sizeof(uint32_t) * 2 * (size_t)nr, hipMemcpyDeviceToHost, stream)) != hipSuccess) return done(e, "hipMemcpyAsync");
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e, "hipStreamSynchronize");
-    std::vector<uint32_t> order;
-    order.reserve(nr);
-    for (uint32_t r = 0; r < nr; ++r) if (host[nr + r]) order.push_back(r);
-    uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t len[8] = {0, 0, 0, 0, 0, 0, 0, 0}, live = 0;
-    for (uint32_t r : order) live += host[nr + r];
-    std::vector<uint32_t> seq[8];                                       // regions of every XCD in launch order
-    auto lpt = [&](const std::vector<uint32_t>& rs) {                   // each region onto the XCD with the least cost so far
-        for (uint32_t r : rs) {
-            int x = 0;
-            for (int k = 1; k < 8; ++k) if (load[k] < load[x]) x = k;
-            seq[x].push_back(r);
-            load[x] += host[r];
-        }
-    };
-    const int mode = c->optPlanOrder;
-    if (mode == 0) {                                                    // Morton order, dealt round-robin (the plain launch minus its dead bricks)
-        for (size_t k = 0; k < order.size(); ++k) seq[k & 7].push_back(order[k]);
-    } else if (mode == 1) {                                             // heaviest first
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return host[a] > host[b]; });
-        lpt(order);
-    } else {
-        // balanced by cost, every XCD in Morton order; mode 3: the regions that are cheapest per live brick -- two rounds of
-        // wave slots' worth per XCD -- go last, dearest of them first, so that the launch drains through short waves
-        std::vector<uint32_t> body = order, tail;
-        if (mode == 3) {
-            std::stable_sort(body.begin(), body.end(), [&](uint32_t a, uint32_t b) {
-                return (uint64_t)host[a] * host[nr + b] < (uint64_t)host[b] * host[nr + a]; });    // cost per live brick, ascending
-            uint32_t pool = 0;
-            size_t cut = 0;
-            while (cut < body.size() && pool < 8u * 2048u && cut < body.size() / 3) pool += host[nr + body[cut++]];
-            tail.assign(body.begin(), body.begin() + cut);
-            body.erase(body.begin(), body.begin() + cut);
-            std::reverse(tail.begin(), tail.end());
-        }
-        std::stable_sort(body.begin(), body.end(), [&](uint32_t a, uint32_t b) { return host[a] > host[b]; });
-        lpt(body);
-        for (auto& q : seq) std::sort(q.begin(), q.end());
-        size_t mark[8];
-        for (int k = 0; k < 8; ++k) mark[k] = seq[k].size();
-        lpt(tail);                                                      // (appended behind the body, in the order given)
-        (void)mark;
-    }
-    for (int x = 0; x < 8; ++x)
-        for (uint32_t r : seq[x]) { dst[2 * r] = (uint32_t)x; dst[2 * r + 1] = len[x]; len[x] += host[nr + r]; }
-    uint32_t longest = 0;
-    for (int k = 0; k < 8; ++k) if (len[k] > longest) longest = len[k];
-    const uint32_t words = 8u * longest;
-    if ((size_t)words > pl->cap) {
-        // (another frame may still be running the plan this slot held before)
-        for (uint32_t i = 0; i < DXV_FRAME_COUNT; ++i)
-            if (c->frames[i].ready && (e = hipStreamSynchronize(frame_stream(c, i))) != hipSuccess) return done(e, "hipStreamSynchronize");
-        (void)hipFree(pl->dPlan); pl->dPlan = nullptr; pl->cap = 0;
-        if ((e = hipMalloc(&pl->dPlan, sizeof(uint32_t) * (size_t)(words ? words : 8u))) != hipSuccess) return done(e, "hipMalloc");
-        pl->cap = words ? words : 8u;
-    }
-    if (words) {
-        if ((e = hipMemcpyAsync(regionDst, dst.data(), sizeof(uint32_t) * 2 * (size_t)nr, hipMemcpyHostToDevice, stream)) != hipSuccess) return done(e, "hipMemcpyAsync");
-        if ((e = plan_fill(p, rb, cost, regionDst, pl->dPlan, words, stream)) != hipSuccess) return done(e, "plan_fill");
-    }
-    if (t1) (void)hipEventRecord(t1, stream);
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e, "hipStreamSynchronize");
-    pl->ms = t0 && t1 ? elapsed(t0, t1) : 0.0f;
-    pl->count = words; pl->live = live; pl->bricks = nb;
-    pl->id = ++c->planIds;
-    pl->valid = true;
-    return done(hipSuccess, "");
-}
-
 // relaunch: the same launch again with a deeper column (sync_frame, after a walk reported an overflow) -- possibly on behalf of
 // a caller that is about to replace the scene (sync_frames): it builds nothing, it takes the candidate structures that exist.
 int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
@@ -665,7 +551,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
     p.subbox = (uint32_t)c->optSubbox;
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     int st = c->optStack ? c->optStack : c->stackNow;
-    dxv_ctx::Plan* plan = nullptr;
+    bool queued = false;
     f.list_entries = 0; f.list_res = 0;
     // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
@@ -700,14 +586,25 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             st = 16;                                                // no stack: the column is the queue of selected triangles (8 items of two words)
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
             f.list_entries = c->listEntries; f.list_res = c->listRes;
-            if (c->optBrick == 4 && !c->optAblate && !relaunch) {
-                int perr = 0;
-                plan = plan_for(c, p, fs, perr);
-                if (perr) return 1;
+            if (c->optBrick == 4 && !c->optAblate && c->optPlan && c->dMip) {
+                // the frame's work queue: sized for the partition (worst case: every brick live)
+                uint32_t cap = 0;
+                const size_t words = plan_queue_words(p.N, p.nz, &cap);
+                if (words > f.queueWords) {
+                    DXV_HIP(c, hipStreamSynchronize(fs));
+                    (void)hipFree(f.dQueue); f.dQueue = nullptr; f.queueWords = 0;
+                    const hipError_t qe = hipMalloc(&f.dQueue, sizeof(uint32_t) * words);
+                    if (qe == hipSuccess) f.queueWords = words;
+                    else if (qe == hipErrorOutOfMemory) (void)hipGetLastError();       // no queue: the brick-box launch still works
+                    else return fail(c, "work queue: hipMalloc failed: %s", hipGetErrorString(qe));
+                    f.clearSig = 0;
+                }
+                if (f.dQueue) { queued = true; p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip; p.queueSteal = (uint32_t)c->optQueueSteal; p.queueWaves = (uint32_t)c->optQueueWaves; }
             }
         }
     }
-    f.plan_bricks = plan ? plan->live : 0u; f.plan_waves = plan ? plan->count : 0u; f.plan_ms = plan ? plan->ms : 0.0f;
+    if (!queued) { f.plan_bricks = 0; f.plan_waves = 0; f.plan_ms = 0.0f; }
+    f.lastQueued = false;
     if (f.ptrExposed) p.clearSig = nullptr;                            // the caller may have written into the grid: clear it every time
     st = stack_for_brick(c->optBrick, st);                             // (shapes other than the shipped one are compiled for three depths)
     f.stack_entries = (uint32_t)st;
@@ -754,9 +651,20 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
         DXV_HIP(c, launch_parity_rows(p, rowBlock, fs));
         f.lastRedoParity = -1;
     } else {
-        if (plan) {
-            p.plan = plan->dPlan; p.planCount = plan->count;
-            DXV_HIP(c, launch_voxelize_planned(p, plan->id, fs));
+        if (queued) {
+            // The grid's zeros outside the queued bricks and the queue itself are still good when the frame's last writer was this
+            // very launch -- same lists, partition and buffers (the kernel writes the same bricks every time): the frame's signature
+            // word says so, every other writer of the grid resets it.  plan = 2, or a grid whose pointer the caller holds: never.
+            uint64_t sig = 0;
+            auto mix = [&](uint64_t v) { sig = (sig ^ v) * 0x9E3779B97F4A7C15ull; sig ^= sig >> 29; };
+            mix(0x7175657565ull); mix(c->listEpoch); mix(p.N); mix(p.nz); mix(p.z0); mix(p.zBlock); mix(p.zPeriod);
+            mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels)); mix(reinterpret_cast<uint64_t>(p.queue));
+            sig |= 1ull;
+            const bool rebuild = c->optPlan == 2 || f.ptrExposed || f.clearSig != sig;
+            hipEvent_t pe[2] = {f.evP0, f.evP1};
+            DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, fs));
+            f.clearSig = f.ptrExposed ? 0 : sig;
+            f.lastQueued = true; f.lastRebuilt = rebuild;
         } else DXV_HIP(c, launch_voxelize(p, c->optBrick, st, fs));
         if (p.lists) f.lastRedoParity = -1;                        // no column to run out of, nothing to redo
         else {
@@ -810,13 +718,15 @@ void dxv_destroy(dxv_ctx* c)
     for (uint32_t i = 0; i < DXV_FRAME_COUNT; ++i) {
         Frame& f = c->frames[i];
         if (frame_stream(c, i)) (void)hipStreamSynchronize(frame_stream(c, i));
-        (void)hipFree(f.dGrid); (void)hipFree(f.dTexels); (void)hipFree(f.dStatus); (void)hipFree(f.dRedo);
+        (void)hipFree(f.dGrid); (void)hipFree(f.dTexels); (void)hipFree(f.dStatus); (void)hipFree(f.dRedo); (void)hipFree(f.dQueue);
         if (f.ev0) (void)hipEventDestroy(f.ev0);
         if (f.ev1) (void)hipEventDestroy(f.ev1);
+        if (f.evP0) (void)hipEventDestroy(f.evP0);
+        if (f.evP1) (void)hipEventDestroy(f.evP1);
         if (f.ownStream) (void)hipStreamDestroy(f.ownStream);
     }
     free_scratch(c);
-    for (auto& pl : c->plans) (void)hipFree(pl.dPlan);
+    (void)hipFree(c->dMip);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene);
     (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dPlCells); (void)hipFree(c->dPlEntries); (void)hipFree(c->dPlScratch); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
     (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
@@ -824,6 +734,20 @@ void dxv_destroy(dxv_ctx* c)
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
+}
+
+int dxv_api_version(void) { return DXV_API_VERSION; }
+
+int dxv_trim(dxv_ctx* c)
+{
+    if (!c) return 1;
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
+    c->dListScratchA = c->dListScratchB = nullptr; c->listScratchACap = c->listScratchBCap = 0;
+    if (!c->haveHierarchy) free_scratch(c);                             // (a built scene keeps keys and links: dxv_refit reads them)
+    return 0;
 }
 
 const char* dxv_last_error(const dxv_ctx* c) { return c ? c->err.c_str() : g_createError.c_str(); }
@@ -1098,6 +1022,14 @@ int sync_frame(dxv_ctx* c, uint32_t i)
         if (f.pending) {
             f.voxelize_ms = f.timed ? elapsed(f.ev0, f.ev1) : 0.0f;
             f.redo_rays = f.lastRedoParity < 0 ? 0u : words[1 + f.lastRedoParity];
+            if (f.lastQueued) {
+                uint32_t hdr[kQueueHeaderWords];
+                DXV_HIP(c, hipMemcpyAsync(hdr, f.dQueue, sizeof(hdr), hipMemcpyDeviceToHost, fs));
+                DXV_HIP(c, hipStreamSynchronize(fs));
+                f.plan_bricks = 0;
+                for (uint32_t x = 0; x < 8u; ++x) f.plan_bricks += hdr[queue_len_word(x)];
+                if (f.lastRebuilt) f.plan_ms = f.timed ? elapsed(f.evP0, f.evP1) : 0.0f;
+            }
         }
         f.pending = false;
         if (!status) return 0;
@@ -1436,6 +1368,14 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         if (bad[0] || bad[1])
             return fail(c, "dxv_scene_import: the list section is inconsistent (%u texels point outside the %u entries, %u entries name a triangle >= %u)",
                         bad[0], h.listCount, bad[1], h.numTris);
+        // the max-mip of the far radii is a function of the cells: made here, not carried in the blob
+        if (dm_mip_words(h.listRes) > c->mipCap) {
+            (void)hipFree(c->dMip); c->dMip = nullptr; c->mipCap = 0;
+            DXV_HIP(c, hipMalloc(&c->dMip, sizeof(uint16_t) * (size_t)dm_mip_words(h.listRes)));
+            c->mipCap = dm_mip_words(h.listRes);
+        }
+        DXV_HIP(c, dirmap_mip(c->dListCells, h.listRes, c->dMip, c->stream));
+        DXV_HIP(c, hipStreamSynchronize(c->stream));
     }
     if (withPl) {
         // ... and so do the row lists of the parity rule (1.6 ms per rank at 1 M triangles)
@@ -1531,17 +1471,15 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "plan")) {
         if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
         c->optPlan = (int)value;
+    } else if (!strcmp(key, "queuesteal")) {
+        if (value != 0 && value != 1) return fail(c, "option queuesteal: %lld not in {0,1}", (long long)value);
+        c->optQueueSteal = (int)value;
+    } else if (!strcmp(key, "queuewaves")) {
+        if (value < 0 || value > (1 << 20)) return fail(c, "option queuewaves: %lld not in [0, 2^20]", (long long)value);
+        c->optQueueWaves = (int)value;
     } else if (!strcmp(key, "events")) {
         if (value != 0 && value != 1) return fail(c, "option events: %lld not in {0,1}", (long long)value);
         c->optEvents = (int)value;
-    } else if (!strcmp(key, "planregion")) {
-        if (value < 6 || value > 9) return fail(c, "option planregion: %lld not in [6, 9]", (long long)value);
-        if (c->optPlanRegion != (int)value) { if (sync_frames(c)) return 1; for (auto& pl : c->plans) pl.used = pl.valid = false; }
-        c->optPlanRegion = (int)value;
-    } else if (!strcmp(key, "planorder")) {
-        if (value < 0 || value > 3) return fail(c, "option planorder: %lld not in {0,1,2,3}", (long long)value);
-        if (c->optPlanOrder != (int)value) { if (sync_frames(c)) return 1; for (auto& pl : c->plans) pl.used = pl.valid = false; }
-        c->optPlanOrder = (int)value;
     } else if (!strcmp(key, "plistres")) {
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option plistres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
         if (c->optPlistRes != (int)value) { if (sync_frames(c)) return 1; c->plState = 0; }     // the next parity launch rebuilds the row lists
@@ -1645,6 +1583,38 @@ int dxv_debug_class_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, uint
     return 0;
 }
 
+int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
+{
+    if (!c || !out) return 1;
+    Frame& f = cur_frame(c);
+    if (!c->haveScene || c->listState != 1 || !f.lastQueued || !f.dQueue || !f.grid_dim)
+        return fail(c, "dxv_debug_plan_check: the current frame's last launch did not go through a work queue");
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
+    const hipStream_t fs = cur_stream(c);
+    VoxelizeParams p{};
+    memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
+    memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
+    p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
+    p.N = f.grid_dim; p.z0 = f.z0; p.nz = f.nz; p.zBlock = f.lastZBlock; p.zPeriod = f.lastZPeriod;
+    while ((1u << p.zShift) < p.zBlock) ++p.zShift;
+    uint32_t cap = 0;
+    (void)plan_queue_words(p.N, p.nz, &cap);
+    p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip;
+    VoxelizeParams q = p;
+    const uint32_t nb = plan_layout(q);
+    uint32_t* bits = nullptr;
+    unsigned long long* dOut = nullptr;
+    DXV_HIP(c, hipMalloc(&bits, sizeof(uint32_t) * (((size_t)nb + 31u) / 32u)));
+    hipError_t e = hipMalloc(&dOut, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = launch_plan_check(p, bits, dOut, fs);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, fs);
+    if (e == hipSuccess) e = hipStreamSynchronize(fs);
+    (void)hipFree(bits); (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(c, "dxv_debug_plan_check failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
 {
     if (!c || !host) return 1;
@@ -1662,6 +1632,10 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     case DXV_DBG_TRI_NRM: if (c->haveScene) { src = scene_trinrm(c); want = sizeof(TriNrm) * T; } break;
     case DXV_DBG_LIST_CELLS: if (c->haveScene && c->listState == 1) { src = c->dListCells; want = sizeof(DirCell) * 6 * (size_t)c->listRes * c->listRes; } break;
     case DXV_DBG_LIST_ENTRIES: if (c->haveScene && c->listState == 1) { src = c->dListEntries; want = sizeof(DirEntry) * (size_t)c->listEntries; } break;
+    case DXV_DBG_LIST_MIP: if (c->haveScene && c->listState == 1 && c->dMip) { src = c->dMip; want = sizeof(uint16_t) * (size_t)dm_mip_words(c->listRes); } break;
+#if defined(DXV_QUEUE_TIMES)
+    case 100: src = c->frames[c->cur].dRedo; want = sizeof(uint64_t) * kRedoCap; break;      // per-wave start / end ticks of the last queue launch
+#endif
     default: return fail(c, "dxv_debug_download: unknown selector %d", what);
     }
     if (!src) return fail(c, "dxv_debug_download: selector %d not available", what);

@@ -53,6 +53,9 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
                        uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longest,
                        hipStream_t s);
 
+// max-mip of the texels' far radii (dxv_dirmap.h: dm_mip_max), dm_mip_words(R) 16-bit words: what the launch's work queue is probed against
+hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream_t s);
+
 // consistency of a list section that arrived in a blob (dxv_scene_import): out[0] = cells whose range leaves the entries,
 // out[1] = entries whose triangle slot is >= T
 hipError_t dirmap_validate(const DirCell* cells, uint32_t R, const DirEntry* entries, uint32_t n, uint32_t T, uint32_t* out, hipStream_t s);
@@ -88,17 +91,27 @@ struct VoxelizeParams {
     uint32_t lists;         // 1: reference rule reads the direction-space lists of p.scene (no tree walk)
     uint64_t* clearSig;     // host word of the frame (or NULL): signature of the partial launch whose memset the grid still carries -- the same launch again skips the memset
     uint32_t ablate;        // timing-only builds of the lists kernel (wrong grids; tools/ablate.py), 0 = the real kernel
-    const uint32_t* plan;   // dispatch plan of the lists kernel (traverse.hip): planCount words, one brick (or ~0) per workgroup
-    uint32_t planCount;
+    uint32_t* queue;        // work queue of the lists kernel (traverse.hip): len[8], head[8], spare header words, then 8 x queueCap brick words
+    uint32_t queueCap;
+    uint32_t queueSteal;    // 1: a wave whose XCD's queue is empty takes bricks of the other XCDs' queues (default), 0: exits (A/B only)
+    uint32_t queueWaves;    // persistent waves to launch; 0 = what the device holds at once
+    const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
-// dispatch plan of the lists kernel with 4 x 4 x 4 bricks (traverse.hip): probe = per-brick cost (0 = no live ray) in the
-// partition's Morton order + cost and live bricks per region of 512; fill = the plan from the host's region placement
+// header of the queue memory: 64 heads (eight per queue: head h of queue x hands out the slots k = h mod 8 of that queue), then the
+// eight lengths, every word in a 256-byte line of its own; then the slots
+constexpr uint32_t kQueueHeaderWords = 5120u;
+DXV_HD constexpr uint32_t queue_head_word(uint32_t x, uint32_t h) { return 64u * (1u + 8u * x + h); }
+DXV_HD constexpr uint32_t queue_len_word(uint32_t x) { return 64u * (65u + x); }
+// work queue of the lists kernel with 4 x 4 x 4 bricks (traverse.hip): built on the device in front of the launch
 uint32_t plan_layout(VoxelizeParams& p);           // fills the brick-order fields for the whole partition, returns its bricks
-uint32_t plan_regions(uint32_t bricks, uint32_t regionBits);           // regions of 2^regionBits consecutive bricks, 6 <= regionBits <= 9
-hipError_t plan_probe(const VoxelizeParams& p, uint32_t regionBits, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s);
-hipError_t plan_fill(const VoxelizeParams& p, uint32_t regionBits, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s);
-hipError_t launch_voxelize_planned(const VoxelizeParams& p, uint64_t planId, hipStream_t s);
+size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut);     // 32-bit words of queue memory for a partition; *capOut = words per XCD queue
+hipError_t plan_build(const VoxelizeParams& p, hipStream_t s);          // header cleared + k_plan_bricks (p.queue, p.queueCap, p.mip set)
+// rebuild: grid cleared + queue built in front of the kernel; else only the queue heads are reset (same launch as before into the same buffers)
+// (planEvents: two events recorded around the queue build of a rebuilding launch, or NULL)
+hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, hipStream_t s);
+// test hook: every voxel's first-step decision against the queue; bits: one per brick of the partition, out: 16 words
+hipError_t launch_plan_check(const VoxelizeParams& p, uint32_t* bits, unsigned long long* out, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack
 int stack_round_up(int want);
 int stack_for_brick(int brickShape, int want);   // the column depth compiled for this brick shape that is >= want

@@ -182,6 +182,117 @@ DXV_HD void dm_ray_point(float ox, float oy, float oz, uint32_t& face, float& u,
     rho = __builtin_sqrtf((ox * ox + oy * oy) + oz * oz);
 }
 
+// The first step of a ray through the lists -- its texel, its cell inside the texel, and whether it has any candidate at
+// all: a ray whose texel is empty, or that starts beyond the far radius of its texel's last entry, is a miss after this
+// one load.  ONE definition: the kernel (trace_reference_dm), the plan's exact checker (k_plan_check, traverse.hip) and
+// the exhaustive list check make this decision through it, and the brick test below bounds it from above.
+struct DirRayStart { DirCell cell; uint32_t cx, cy; float rho, near; bool live; };
+DXV_HD DirRayStart dm_ray_start(float ox, float oy, float oz, const DirMapView& dm)
+{
+    DirRayStart s;
+    uint32_t face, ti, tj;
+    float u, v;
+    dm_ray_point(ox, oy, oz, face, u, v, s.rho);
+    dm_local(u, dm.R, ti, s.cx); dm_local(v, dm.R, tj, s.cy);
+    s.cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
+    s.near = s.rho * 0.999f;
+    s.live = s.cell.count != 0u && !(half_bits_to_float(s.cell.r1max) < s.near);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Max-mip of the texels' far radii: which 4 x 4 x 4-voxel bricks can hold a live ray at all (the launch's work queue,
+// k_plan_bricks in traverse.hip).  Key of a texel = its r1max as half bits (positive halfs order like integers), 0 for an
+// empty texel; level l holds, for 6 faces of (R >> l)^2 cells, the maximum over the 2^l x 2^l texels below a cell.
+// Built from the cells (dirmap.hip: dirmap_mip), never exported: a function of the cells alone.
+// ---------------------------------------------------------------------------------------------
+DXV_HD uint32_t dm_mip_levels(uint32_t R) { uint32_t l = 1u; while ((R >> (l - 1u)) > 1u) ++l; return l; }   // R = 256: 9 (256 .. 1)
+DXV_HD uint32_t dm_mip_offset(uint32_t R, uint32_t level)
+{
+    uint32_t off = 0;
+    for (uint32_t l = 0; l < level; ++l) off += 6u * (R >> l) * (R >> l);
+    return off;
+}
+DXV_HD uint32_t dm_mip_words(uint32_t R) { return dm_mip_offset(R, dm_mip_levels(R)); }    // 16-bit words
+DXV_HD uint32_t dm_mip_key(const DirCell& c) { return c.count ? (uint32_t)c.r1max : 0u; }
+
+// maximum key over texels [i0, i1] x [j0, j1] of a face (a superset: the coarsest level at which the rectangle is at most
+// 2 x 2 cells; four loads)
+DXV_HD uint32_t dm_mip_max(const uint16_t* mip, uint32_t R, uint32_t face, uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1)
+{
+    uint32_t l = 0, off = 0, r = R;
+    while (((i1 >> l) - (i0 >> l)) > 1u || ((j1 >> l) - (j0 >> l)) > 1u) { off += 6u * r * r; r >>= 1; ++l; }
+    const uint16_t* base = mip + off + face * r * r;
+    const uint32_t a0 = i0 >> l, a1 = i1 >> l, b0 = j0 >> l, b1 = j1 >> l;
+    uint32_t m = base[b0 * r + a0], t = base[b0 * r + a1];
+    if (t > m) m = t;
+    t = base[b1 * r + a0]; if (t > m) m = t;
+    t = base[b1 * r + a1]; if (t > m) m = t;
+    return m;
+}
+
+// Can a voxel whose centre lies in the box [x0, x1] x [y0, y1] x [z0, z1] (the hull of a brick's voxel centres; x0 <= x1 ...)
+// hold a live ray, i.e. pass origin_leaves_root and dm_ray_start().live?  False negatives are not allowed, false positives
+// cost a wave that finds nothing to do.  Every step bounds the per-voxel arithmetic through its monotonicity in fp32
+// (correctly rounded operations are monotone): coordinates of one sign, |u| = |p_b| / |p_a| grows with |p_b| and falls
+// with |p_a|, the texel index grows with u, rho grows with every |coordinate|, near = rho * 0.999f with rho.
+//  * root box: on an axis whose coordinates are all of one sign, axis_leaves_root is monotone -- all of them leave iff the
+//    one nearest to zero does;
+//  * a box that straddles a centre plane (grids whose half is no multiple of the brick) is kept;
+//  * faces: in one octant a box meets the cone of face A iff its corner with the largest |a| and smallest |b|, |c| lies in
+//    it, and likewise for the tie-breaking order of dm_ray_point -- the faces present among its voxels are exactly the
+//    faces of three of its corners; per present face the texel rectangle of the box comes from the extreme quotients;
+//  * every ray of the box starts at or beyond rhoMin: dead iff every texel it can look into is empty or ends before
+//    rhoMin * 0.999f.
+DXV_HD bool dm_box_may_be_live(float x0, float x1, float y0, float y1, float z0, float z1, const float* rootLo, const float* rootHi,
+                               const uint16_t* mip, uint32_t R)
+{
+    if ((x0 > 0.0f && axis_leaves_root(x0, rootLo[0], rootHi[0])) || (x1 < 0.0f && axis_leaves_root(x1, rootLo[0], rootHi[0]))) return false;
+    if ((y0 > 0.0f && axis_leaves_root(y0, rootLo[1], rootHi[1])) || (y1 < 0.0f && axis_leaves_root(y1, rootLo[1], rootHi[1]))) return false;
+    if ((z0 > 0.0f && axis_leaves_root(z0, rootLo[2], rootHi[2])) || (z1 < 0.0f && axis_leaves_root(z1, rootLo[2], rootHi[2]))) return false;
+    if (!(x0 > 0.0f || x1 < 0.0f) || !(y0 > 0.0f || y1 < 0.0f) || !(z0 > 0.0f || z1 < 0.0f)) return true;     // straddles a centre plane
+    const bool nx = x1 < 0.0f, ny = y1 < 0.0f, nz = z1 < 0.0f;
+    const float xa = nx ? -x1 : x0, xb = nx ? -x0 : x1, ya = ny ? -y1 : y0, yb = ny ? -y0 : y1, za = nz ? -z1 : z0, zb = nz ? -z0 : z1;
+    const float rhoMin = __builtin_sqrtf((xa * xa + ya * ya) + za * za), nearMin = rhoMin * 0.999f;
+    // rectangle of texels for numerator range [na, nb] (sign neg) over denominator range [da, db]
+    auto range = [&](float na, float nb, bool neg, float da, float db, uint32_t& t0, uint32_t& t1) {
+        const float lo = na / db, hi = nb / da;
+        t0 = dm_texel(neg ? -hi : lo, R); t1 = dm_texel(neg ? -lo : hi, R);
+    };
+    auto face_live = [&](uint32_t face, uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1) {
+        const uint32_t key = dm_mip_max(mip, R, face, i0, i1, j0, j1);
+        return key != 0u && !(half_bits_to_float(key) < nearMin);
+    };
+    uint32_t i0, i1, j0, j1;
+    if (xb >= ya && xb >= za) {                                         // face X: u = y / |x|, v = z / |x|
+        range(ya, yb, ny, xa, xb, i0, i1); range(za, zb, nz, xa, xb, j0, j1);
+        if (face_live(nx ? 1u : 0u, i0, i1, j0, j1)) return true;
+    }
+    if (!(xa >= yb && xa >= za) && yb >= za) {                          // face Y: u = z / |y|, v = x / |y|
+        range(za, zb, nz, ya, yb, i0, i1); range(xa, xb, nx, ya, yb, j0, j1);
+        if (face_live(ny ? 3u : 2u, i0, i1, j0, j1)) return true;
+    }
+    if (!(xa >= ya && xa >= zb) && !(ya >= zb)) {                       // face Z: u = x / |z|, v = y / |z|
+        range(xa, xb, nx, za, zb, i0, i1); range(ya, yb, ny, za, zb, j0, j1);
+        if (face_live(nz ? 5u : 4u, i0, i1, j0, j1)) return true;
+    }
+    return false;
+}
+
+// the hull of the voxel centres of brick (bx, by, bz) of 4 x 4 x 4 voxels in a partition's local brick grid (x0 <= x1 ...; y falls
+// with iy, hlsl:49).  Local slice lz <-> global slice z0 + (lz >> zShift) * zPeriod + (lz & (zBlock - 1)) (zBlock == nz: a slab);
+// the map is increasing, so the hull's z range comes from the brick's first and last slice.
+DXV_HD void dm_brick_hull(uint32_t N, uint32_t nz, uint32_t z0, uint32_t zBlock, uint32_t zShift, uint32_t zPeriod, uint32_t bx, uint32_t by,
+                          uint32_t bz, float& x0, float& x1, float& y0, float& y1, float& zlo, float& zhi)
+{
+    const uint32_t ix0 = bx * 4u, iy0 = by * 4u, lz0 = bz * 4u;
+    const uint32_t ix1 = ix0 + 3u < N ? ix0 + 3u : N - 1u, iy1 = iy0 + 3u < N ? iy0 + 3u : N - 1u, lz1 = lz0 + 3u < nz ? lz0 + 3u : nz - 1u;
+    const uint32_t iz0 = zBlock == nz ? z0 + lz0 : z0 + (lz0 >> zShift) * zPeriod + (lz0 & (zBlock - 1u));
+    const uint32_t iz1 = zBlock == nz ? z0 + lz1 : z0 + (lz1 >> zShift) * zPeriod + (lz1 & (zBlock - 1u));
+    ray_origin(N, ix0, iy1, iz0, x0, y0, zlo);
+    ray_origin(N, ix1, iy0, iz1, x1, y1, zhi);
+}
+
 // next float towards +inf / -inf (finite inputs)
 DXV_HD float dm_up(float x)
 {
@@ -485,23 +596,22 @@ DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32
 // work test together.
 // ABL (timing-only builds, tools/ablate.py; 0 in every shipped path): 8 = stop before the texel lookup, 1 = stop after it,
 // 2 = scan the entries but test no triangle, 16 = the scan's loads wave-uniform (with 2: 18)
+// (split at the ray's first step: the work-queue kernel makes that step for all 64 lanes of a brick at once and collects the brick
+// it asked for in advance behind it -- k_voxelize_queue, traverse.hip)
 template <class Stack, int ABL = 0>
-DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, const Stack& stk, int cap, Hit& best, float& bestDet)
+DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRayStart& start, const TriPos* tris, const Stack& stk, int cap, Hit& best,
+                                    float& bestDet)
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
     if (ABL & 8) return;
-    uint32_t face;
-    float u, v, rho;
-    dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
-    uint32_t ti, tj, cx, cy;
-    dm_local(u, dm.R, ti, cx); dm_local(v, dm.R, tj, cy);
-    const DirCell cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
-    const float near = rho * 0.999f;
+    const DirCell cell = start.cell;
+    const uint32_t cx = start.cx, cy = start.cy;
+    const float rho = start.rho, near = start.near;
     // entries wholly nearer the centre than the ray's start (r1 < near: t < 0) come first: skip them --
     // all of them at once for a ray that starts beyond the texel's last triangle
     uint32_t end = cell.begin + cell.count;
     uint32_t i = cell.begin, hi = end;
-    if (half_bits_to_float(cell.r1max) < near) i = hi;
+    if (!start.live) i = hi;
     if (ABL & 1) { if (i == 0xffffffffu) best.k = 0u; return; }
     if (hi - i > 8u) {                                                  // the first two steps of the search from the texel's own words
         const uint32_t mid = i + ((hi - i) >> 1);
@@ -593,6 +703,14 @@ DXV_HD void pl_rect(const TriPos& tp, uint32_t R, uint32_t& j0, uint32_t& j1, ui
     float lo[3], hi[3];
     tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
     j0 = dm_texel(lo[1], R); j1 = dm_texel(hi[1], R); k0 = dm_texel(lo[2], R); k1 = dm_texel(hi[2], R);
+}
+
+template <class Stack, int ABL = 0>
+DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris, const Stack& stk, int cap, Hit& best, float& bestDet)
+{
+    if (ABL & 8) { best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1; return; }
+    const DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
+    trace_reference_dm_from<Stack, ABL>(r, dm, start, tris, stk, cap, best, bestDet);
 }
 
 template <class Stack, int ABL>

@@ -604,6 +604,27 @@ struct SceneView {
 template <class Stack, int ABL = 0>
 DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best, float& bestDet);      // dxv_dirmap.h
 
+// closestHitMain / missMain for the closest hit a walk (or the lists: WALK 4, hit not yet divided) found
+template <int WALK, int ABL = 0>
+DXV_HD uint8_t shade_reference(const SceneView& sc, Ray& r, Hit& best, float bestDet, uint32_t* texel)
+{
+    if (best.k == 0xffffffffu) return 0;                                         // missMain
+    if (ABL & 4) return 1;
+    if (WALK == 4) {
+        // most triangles answer the predicate for every ray that can hit them (normal_class): no normals, no barycentrics
+        const uint32_t cls = (uint32_t)best.leaf >> kClassShift;
+        best.leaf &= (int32_t)((1u << kClassShift) - 1u);
+        if (cls != 0u && !texel) return cls == kClassIn ? 1 : 0;
+        finish_hit(best, bestDet);
+        finish_ray_reference(r);                                        // the direction again (not kept through the scan)
+    }
+    const TriNrm tn = sc.triNrm[best.leaf];
+    float nx, ny, nz;
+    const bool in = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz);
+    if (in && texel) *texel = pack_texel(nx, ny, nz);
+    return in ? 1 : 0;
+}
+
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set
 // when the traversal stack was too small.
 // WALK: 0 = leaves tested as they are met, 1 = postponed-leaf walk, 2 = postponed-leaf walk over the
@@ -626,21 +647,7 @@ DXV_HD uint8_t voxel_reference(const SceneView& sc, uint32_t N, uint32_t ix, uin
                   : WALK == 1 ? trace_reference_q(r, sc.nodes, sc.triPos, stk, cap, best)
                               : trace_reference(r, sc.nodes, sc.triPos, stk, cap, best);
     if (!ok) { overflow = true; return 0; }
-    if (best.k == 0xffffffffu) return 0;                                         // missMain
-    if (ABL & 4) return 1;
-    if (WALK == 4) {
-        // most triangles answer the predicate for every ray that can hit them (normal_class): no normals, no barycentrics
-        const uint32_t cls = (uint32_t)best.leaf >> kClassShift;
-        best.leaf &= (int32_t)((1u << kClassShift) - 1u);
-        if (cls != 0u && !texel) return cls == kClassIn ? 1 : 0;
-        finish_hit(best, bestDet);
-        finish_ray_reference(r);                                        // the direction again (not kept through the scan)
-    }
-    const TriNrm tn = sc.triNrm[best.leaf];
-    float nx, ny, nz;
-    const bool in = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz);
-    if (in && texel) *texel = pack_texel(nx, ny, nz);
-    return in ? 1 : 0;
+    return shade_reference<WALK, ABL>(sc, r, best, bestDet, texel);
 }
 
 template <bool QUEUED, class Stack>

@@ -51,23 +51,12 @@ __device__ __forceinline__ void brick_of_lin(const VoxelizeParams& p, uint32_t l
 }
 
 // WALK: 0 = leaves tested as met, 1 = postponed-leaf walk, 2 = the same over the wide nodes (MODE 0)
-// PLAN: the workgroup's brick comes from the launch's dispatch plan (k_plan_probe / k_plan_fill below): p.plan[blockIdx.x] =
-// bx | by << 10 | bz << 20, or ~0 for a slot that pads the shorter XCD sequences.
-template <class B, int STACK, int MODE, bool TEXELS, int WALK, int ABL = 0, bool PLAN = false>
-__global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(VoxelizeParams p)   // 8 waves/SIMD: <= 64 VGPRs (lists: the bound is 6, the kernel needs 62 and runs 8)
+template <class B, int STACK, int MODE, bool TEXELS, int WALK, int ABL = 0>
+__global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(VoxelizeParams p)   // walks: <= 64 VGPRs, 8 waves/SIMD; lists (WALK 4): 70 VGPRs, 7 waves
 {
     __shared__ int32_t stack[STACK * B::threads];
     const uint32_t N = p.N;
     uint32_t bx, by, bz;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (PLAN) {
-        uint32_t w;                                                     // through the scalar cache: one word per wave
-        const uint32_t* slot = p.plan + blockIdx.x;
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
-        if (w == 0xffffffffu) return;
-        bx = w & 1023u; by = (w >> 10) & 1023u; bz = w >> 20;
-    } else
-#endif
     {
     const uint32_t nb = p.nbx * p.nby * p.nbz;
     // XCD-aware remap: workgroups b and b + 8 share an XCD.  Bricks are numbered along a Morton
@@ -110,71 +99,58 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dispatch plan of the lists kernel (4 x 4 x 4 bricks): WHICH bricks a launch runs and in WHAT order.
+// Work queue of the lists kernel (4 x 4 x 4 bricks): WHICH bricks a launch runs, decided on the device inside the stream.
 //  * which: a ray that starts beyond the last entry of its texel (or whose texel is empty, or whose origin has left the
-//    root box) is a miss after one load -- on torus-1M four launched waves in ten held no other ray.  k_plan_probe makes
-//    exactly that decision (same functions, same floats as trace_reference_dm's first step) for every voxel of the
-//    partition once; bricks without a single live ray are not launched, their voxels are zero by the launch's memset;
-//  * in what order: regions of 512 consecutive bricks of the Morton order (8 x 8 x 8 bricks) are the unit; a region's cost
-//    is estimated from the list lengths of its live rays; the host deals the regions to the eight XCDs heaviest first
-//    onto the least loaded one (LPT), so that every XCD ends on its cheapest regions and the launch's tail -- what does
-//    not shrink when the grid is cut into eight ranks' shares -- is made of short waves.
-// The plan depends on the lists and on the partition (N, slab or block-cyclic set), not on the frame: dxv_api.hip keeps a
-// few per context and builds one when the same partition is launched a second time against the same lists.
+//    root box) is a miss after one load -- on torus-1M four waves in ten of a launch over the brick box held no other
+//    ray.  k_plan_bricks decides per BRICK, conservatively (dm_box_may_be_live, dxv_dirmap.h: the brick's footprint in
+//    direction space and its smallest start radius against a max-mip of the texels' far radii; a false positive costs a
+//    wave that finds nothing, a false negative cannot happen -- k_plan_check below is the exhaustive proof obligation);
+//  * layout: regions of 256 consecutive bricks of the Morton order (8 x 8 x 4 bricks) are dealt round-robin to eight
+//    queues, one per XCD (blocks b and b + 8 share one), so that an XCD's private L2 sees compact regions; a region's
+//    workgroup appends its live bricks to its queue with one atomic add.  Queue memory: 1024 header words (len[8]; the
+//    head of queue x in a 256-byte line of its own) + 8 x cap brick words (bx | by << 10 | bz << 20);
+//  * how: k_voxelize_queue is launched with as many single-wave workgroups as the GPU holds at once.  Every wave takes
+//    bricks from its XCD's queue with one returning atomic add per chunk (guided: up to 4 bricks while the queue is long,
+//    single bricks towards its end, so that the launch drains through single bricks), and moves on to the other XCDs'
+//    queues when its own is empty: placement is for speed only, any wave may take any brick.  No host round trip: the
+//    launch's size does not depend on how many bricks are live.
+// Bricks that are not queued are zero by the launch's memset of the grid.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kPlanRegionBitsMax = 9u;                            // regions of 2^rb consecutive bricks, rb <= 9 (one workgroup of k_plan_fill each)
+constexpr uint32_t kPlanRegionBits = 8u;                               // regions of 256 consecutive bricks = one workgroup of k_plan_bricks
+// (header layout: queue_len_word / queue_head_word in dxv_device.h -- every queue's two words in a 256-byte line of its own:
+// returning atomics on ONE line serialise at ~90 per us for all eight queues together, 2.7 ms of a launch when first tried)
 
-__global__ __launch_bounds__(64) void k_plan_probe(VoxelizeParams p, uint32_t nb, uint32_t rb, uint32_t* __restrict__ cost,
-                                                   uint32_t* __restrict__ regionCost, uint32_t* __restrict__ regionLive)
+__global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t nb)
 {
-    const uint32_t lin = blockIdx.x;
-    if (lin >= nb) return;
-    uint32_t bx, by, bz;
-    brick_of_lin(p, lin, bx, by, bz);
-    const uint32_t tid = threadIdx.x, N = p.N;
-    const uint32_t ix = bx * 4u + (tid & 3u), iy = by * 4u + ((tid >> 2) & 3u), lz = bz * 4u + (tid >> 4);
-    uint32_t c = 0;
-    if (ix < N && iy < N && lz < p.nz) {
-        const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
-        float ox, oy, oz;
-        ray_origin(N, ix, iy, iz, ox, oy, oz);
-        if (!origin_leaves_root(ox, oy, oz, p.scene.rootLo, p.scene.rootHi)) {
-            const DirMapView dm{static_cast<const DirCell*>(p.scene.dmCells), static_cast<const DirEntry*>(p.scene.dmEntries), p.scene.dmR};
-            uint32_t face, ti, tj, cx, cy;
-            float u, v, rho;
-            dm_ray_point(ox, oy, oz, face, u, v, rho);
-            dm_local(u, dm.R, ti, cx); dm_local(v, dm.R, tj, cy);
-            const DirCell cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
-            const float near = rho * 0.999f;                            // (trace_reference_dm: i = hi when the far radius of the texel's last entry < near)
-            if (cell.count != 0u && !(half_bits_to_float(cell.r1max) < near)) c = 8u + (cell.count < 120u ? cell.count : 120u);
-        }
+    __shared__ uint32_t waveCount[4];
+    __shared__ uint32_t regionBase;
+    const uint32_t lin = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    bool live = false;
+    uint32_t bx = 0, by = 0, bz = 0;
+    if (lin < nb) {
+        brick_of_lin(p, lin, bx, by, bz);
+        float x0, x1, y0, y1, z0, z1;
+        dm_brick_hull(p.N, p.nz, p.z0, p.zBlock, p.zShift, p.zPeriod, bx, by, bz, x0, x1, y0, y1, z0, z1);
+        live = dm_box_may_be_live(x0, x1, y0, y1, z0, z1, p.scene.rootLo, p.scene.rootHi, p.mip, p.scene.dmR);
     }
-    for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
-    if (tid == 0u) {
-        cost[lin] = c;
-        if (c) { atomicAdd(regionCost + (lin >> rb), c); atomicAdd(regionLive + (lin >> rb), 1u); }
-    }
-}
-
-// regionDst[2 r] = XCD of region r, regionDst[2 r + 1] = position of its first live brick in that XCD's sequence
-__global__ __launch_bounds__(1u << kPlanRegionBitsMax) void k_plan_fill(VoxelizeParams p, uint32_t nb, const uint32_t* __restrict__ cost,
-                                                                        const uint32_t* __restrict__ regionDst, uint32_t* __restrict__ plan)
-{
-    __shared__ uint32_t waveCount[(1u << kPlanRegionBitsMax) / 64u];
-    const uint32_t lin = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;   // blockDim.x = bricks per region
-    const bool live = lin < nb && cost[lin] != 0u;
     const unsigned long long m = __ballot(live);
     if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    // (dealing finer -- runs of 64 bricks -- or to the queue that is shortest at the moment was measured: no faster, the eight queues
+    // end within 2 % of each other as it is: profiles/r04/queue_wave_times.jsonl)
+    const uint32_t x = blockIdx.x & 7u;
+    if (threadIdx.x == 0u) {
+        const uint32_t n = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
+        regionBase = n ? atomicAdd(p.queue + queue_len_word(x), n) : 0u;
+    }
     __syncthreads();
     if (!live) return;
     uint32_t rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
     for (uint32_t k = 0; k < w; ++k) rank += waveCount[k];
-    uint32_t bx, by, bz;
-    brick_of_lin(p, lin, bx, by, bz);
-    plan[(size_t)(regionDst[2u * blockIdx.x + 1u] + rank) * 8u + regionDst[2u * blockIdx.x]] = bx | (by << 10) | (bz << 20);
+    p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + regionBase + rank] = bx | (by << 10) | (bz << 20);
 }
 
-// the brick order of the whole partition (no brick box): what k_plan_probe, k_plan_fill and the host agree on
+// the brick order of the whole partition (no brick box): what k_plan_bricks, the checker and the host agree on
 uint32_t plan_layout(VoxelizeParams& p)
 {
     const uint32_t nbx = (p.N + 3u) / 4u, nby = nbx, nbz = (p.nz + 3u) / 4u;
@@ -187,28 +163,229 @@ uint32_t plan_layout(VoxelizeParams& p)
     p.superY = nby >> m;
     return nbx * nby * nbz;
 }
-uint32_t plan_regions(uint32_t nb, uint32_t rb) { return (nb + (1u << rb) - 1u) >> rb; }
+// words of queue memory a partition needs (header + eight queues, each able to hold every region dealt to it in full)
+size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut)
+{
+    const uint64_t nb = (uint64_t)((N + 3u) / 4u) * ((N + 3u) / 4u) * ((nz + 3u) / 4u);
+    const uint64_t nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
+    const uint64_t cap = ((nr + 7u) / 8u) << kPlanRegionBits;
+    if (capOut) *capOut = (uint32_t)cap;
+    return kQueueHeaderWords + 8u * (size_t)cap;
+}
 
-hipError_t plan_probe(const VoxelizeParams& pin, uint32_t rb, uint32_t* cost, uint32_t* regionCost, uint32_t* regionLive, hipStream_t s)
+// header cleared, then one workgroup per region; p.queue / p.queueCap / p.mip set by the caller
+hipError_t plan_build(const VoxelizeParams& pin, hipStream_t s)
 {
     VoxelizeParams p = pin;
-    if (rb < 6u || rb > kPlanRegionBitsMax) return hipErrorInvalidValue;
-    const uint32_t nb = plan_layout(p), nr = plan_regions(nb, rb);
-    hipError_t e = hipMemsetAsync(regionCost, 0, sizeof(uint32_t) * nr, s);
-    if (e == hipSuccess) e = hipMemsetAsync(regionLive, 0, sizeof(uint32_t) * nr, s);
+    const uint32_t nb = plan_layout(p), nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
+    hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kQueueHeaderWords, s);
     if (e != hipSuccess) return e;
-    k_plan_probe<<<dim3(nb), dim3(64), 0, s>>>(p, nb, rb, cost, regionCost, regionLive);
+    k_plan_bricks<<<dim3(nr), dim3(256), 0, s>>>(p, nb);
     return hipGetLastError();
 }
 
-hipError_t plan_fill(const VoxelizeParams& pin, uint32_t rb, const uint32_t* cost, const uint32_t* regionDst, uint32_t* plan, uint32_t planWords, hipStream_t s)
+// ---------------------------------------------------------------------------------------------
+// Test hook (dxv_debug_plan_check): the queue's claim -- no live ray sits in a brick that is not queued -- checked
+// exhaustively.  k_plan_mark sets one bit per queued brick (and counts bricks queued twice); k_plan_check makes, for every
+// voxel of the partition, exactly the decision the kernel's first step makes (origin_leaves_root, dm_ray_start: the same
+// functions) and requires the brick of every live voxel to be marked.
+// out[0] live voxels, out[1] bricks with a live voxel, out[2] queued bricks, out[3] violations (must be 0), out[4] bricks
+// queued more than once (must be 0), out[5 + k]: brick word of the first 11 violations.  Not a product path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plan_mark(VoxelizeParams p, uint32_t* __restrict__ bits, unsigned long long* __restrict__ out)
+{
+    const uint32_t nbx = (p.N + 3u) / 4u;
+    for (uint32_t x = 0; x < 8u; ++x) {
+        const uint32_t len = p.queue[queue_len_word(x)];
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < len; k += gridDim.x * 256u) {
+            const uint32_t w = p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + k];
+            const uint32_t id = ((w >> 20) * nbx + ((w >> 10) & 1023u)) * nbx + (w & 1023u);
+            const uint32_t old = atomicOr(bits + (id >> 5), 1u << (id & 31u));
+            if (old & (1u << (id & 31u))) atomicAdd(out + 4, 1ull);
+            atomicAdd(out + 2, 1ull);
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_plan_check(VoxelizeParams p, uint32_t nb, const uint32_t* __restrict__ bits, unsigned long long* __restrict__ out)
+{
+    const uint32_t lin = blockIdx.x;
+    if (lin >= nb) return;
+    uint32_t bx, by, bz;
+    brick_of_lin(p, lin, bx, by, bz);
+    const uint32_t tid = threadIdx.x, N = p.N;
+    const uint32_t ix = bx * 4u + (tid & 3u), iy = by * 4u + ((tid >> 2) & 3u), lz = bz * 4u + (tid >> 4);
+    bool live = false;
+    if (ix < N && iy < N && lz < p.nz) {
+        const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
+        float ox, oy, oz;
+        ray_origin(N, ix, iy, iz, ox, oy, oz);
+        if (!origin_leaves_root(ox, oy, oz, p.scene.rootLo, p.scene.rootHi)) {
+            const DirMapView dm{static_cast<const DirCell*>(p.scene.dmCells), static_cast<const DirEntry*>(p.scene.dmEntries), p.scene.dmR};
+            live = dm_ray_start(ox, oy, oz, dm).live;
+        }
+    }
+    const unsigned long long m = __ballot(live);
+    if (tid != 0u || !m) return;
+    atomicAdd(out, (unsigned long long)__builtin_popcountll(m));
+    atomicAdd(out + 1, 1ull);
+    const uint32_t nbx = (N + 3u) / 4u, id = (bz * nbx + by) * nbx + bx;
+    if (!(bits[id >> 5] & (1u << (id & 31u)))) {
+        const unsigned long long slot = atomicAdd(out + 3, 1ull);
+        if (slot < 11ull) out[5 + slot] = bx | (by << 10) | (bz << 20);
+    }
+}
+hipError_t launch_plan_check(const VoxelizeParams& pin, uint32_t* bits, unsigned long long* out, hipStream_t s)
 {
     VoxelizeParams p = pin;
-    if (rb < 6u || rb > kPlanRegionBitsMax) return hipErrorInvalidValue;
-    const uint32_t nb = plan_layout(p), nr = plan_regions(nb, rb);
-    hipError_t e = hipMemsetAsync(plan, 0xff, sizeof(uint32_t) * (size_t)planWords, s);
+    const uint32_t nb = plan_layout(p);
+    hipError_t e = hipMemsetAsync(bits, 0, sizeof(uint32_t) * (((size_t)nb + 31u) / 32u), s);
+    if (e == hipSuccess) e = hipMemsetAsync(out, 0, 16 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    k_plan_fill<<<dim3(nr), dim3(1u << rb), 0, s>>>(p, nb, cost, regionDst, plan);
+    k_plan_mark<<<dim3(256), dim3(256), 0, s>>>(p, bits, out);
+    k_plan_check<<<dim3(nb), dim3(64), 0, s>>>(p, nb, bits, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The lists kernel over the work queue: persistent single-wave workgroups (see above).  One brick = one pass of the body of
+// k_voxelize<Brick<4,4,4>, 16, 0, TEXELS, 4>; the 64 result bytes of a brick leave as 16 dwords (one per 4-voxel row,
+// assembled from the wave's ballot) instead of 64 bytes.
+// ---------------------------------------------------------------------------------------------
+template <bool TEXELS>
+__global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int32_t stack[16 * 64];
+    // Queue x is handed out through eight heads: head h counts the slots k = h (mod 8), so that the eight groups of an XCD's waves
+    // (a wave's home head: its number among the XCD's waves mod 8) advance through the queue together, one brick per add -- the
+    // bricks in flight on an XCD stay a compact window of its queue (what hardware dispatch of one workgroup per brick gave:
+    // neighbouring bricks look into the same texels while they are in the caches; chunks of 8 consecutive bricks per wave
+    // cost 7 %, of 16 15 %), and no head sees more than a few adds per microsecond (all bricks through ONE word: 2.7 ms).
+    const uint32_t home = (blockIdx.x >> 3) & 7u;
+#if defined(DXV_QUEUE_TIMES)
+    const uint64_t tStart = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (uint32_t turn = 0; turn < (p.queueSteal ? 64u : 8u); ++turn) {
+        const uint32_t x = (blockIdx.x + (turn >> 3)) & 7u, h = (home + turn) & 7u;
+        const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
+        if (len <= h) continue;
+        uint32_t* head = p.queue + queue_head_word(x, h);
+        // not the wave's first head: a look before the add (a load that may be stale, i.e. too small -- then the add below finds
+        // out), so that the waves of an emptied queue do not hammer 63 more heads with adds that fail
+        if (turn != 0u && 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + h >= len) continue;
+        const uint32_t* slots = p.queue + kQueueHeaderWords + (size_t)x * p.queueCap;
+        // One brick ahead: the add for the next brick is issued in front of the current one, and its answer is taken out of its
+        // vector register as soon as the brick's first load (the rays' cells: all 64 lanes make that step together) has arrived --
+        // by then it is there (memory operations return in order) -- so nothing of the queue lives in a vector register through
+        // the scan and the triangle tests.
+        uint32_t jv = 0;
+        if (threadIdx.x == 0u) jv = atomicAdd(head, 1u);
+        uint32_t next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);
+        for (;;) {
+            const uint32_t k = 8u * next + h;
+            if (k >= len) break;
+            if (threadIdx.x == 0u) jv = atomicAdd(head, 1u);
+            uint32_t w;                                                 // through the scalar cache: one word per wave
+            const uint32_t* slot = slots + k;
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
+            // The launch's parameters are read from the kernel-argument segment again for every brick (scalar loads that
+            // hit the scalar cache): kept across the loop they would hold fifty SGPRs through the whole brick body, and the
+            // body (the one of k_voxelize: 70 VGPRs, 56 SGPRs) would lose a wave per SIMD to registers.
+            typedef const __attribute__((address_space(4))) VoxelizeParams* KernArg;
+            KernArg pp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(pp));
+            SceneView sc;                                               // (what the lists' path reads of it)
+            sc.nodes = nullptr; sc.wide = nullptr; sc.plCells = nullptr; sc.plEntries = nullptr; sc.plR = 0;
+            sc.triPos = pp->scene.triPos; sc.triNrm = pp->scene.triNrm;
+            sc.dmCells = pp->scene.dmCells; sc.dmEntries = pp->scene.dmEntries; sc.dmR = pp->scene.dmR;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { sc.rootLo[a] = pp->scene.rootLo[a]; sc.rootHi[a] = pp->scene.rootHi[a]; }
+            const uint32_t N = pp->N, nz = pp->nz;
+            const uint32_t bx = w & 1023u, by = (w >> 10) & 1023u, bz = w >> 20;
+            // (the lane number anew for every brick, and once more behind the body: nothing of the loop lives in vector registers
+            // through the body)
+            uint32_t tid;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
+            uint32_t ix = bx * 4u + (tid & 3u), iy = by * 4u + ((tid >> 2) & 3u), lz = bz * 4u + (tid >> 4);
+            ix = ix < N ? ix : N - 1u; iy = iy < N ? iy : N - 1u; lz = lz < nz ? lz : nz - 1u;   // (lanes that hang over the grid's end repeat its last voxels and store nothing)
+            const uint32_t zBlock = pp->zBlock;
+            const uint32_t iz = zBlock == nz ? pp->z0 + lz : pp->z0 + (lz >> pp->zShift) * pp->zPeriod + (lz & (zBlock - 1u));
+            // raygenMain for the 64 voxels of the brick (voxel_reference<4>, dxv_trace.h, with its first step made by all lanes)
+            Ray r;
+            ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+            const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
+            DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
+            next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);    // the next brick's number
+            if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) start.live = false;   // provably missMain
+            Hit best;
+            float bestDet = 1.0f;
+            const StridedStack stk{stack + tid, 64};
+            trace_reference_dm_from<StridedStack, 0>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
+            uint32_t texel = 0;
+            const uint8_t occ = shade_reference<4, 0>(sc, r, best, bestDet, TEXELS ? &texel : nullptr);
+            // the lane's voxel once more (nothing of it was kept through the body)
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
+            uint8_t* grid = pp->grid;
+            if (TEXELS || (N & 3u) != 0u) {
+                const uint32_t vx = bx * 4u + (tid & 3u), vy = by * 4u + ((tid >> 2) & 3u), vz = bz * 4u + (tid >> 4);
+                if (vx < N && vy < N && vz < nz) {
+                    const size_t id = ((size_t)vz * N + vy) * N + vx;
+                    if (TEXELS) pp->texels[id] = texel;
+                    if ((N & 3u) != 0u) grid[id] = occ;
+                }
+            }
+            if ((N & 3u) == 0u) {
+                // rows of 4 voxels are aligned dwords: lane r < 16 stores row (y = r & 3, z = r >> 2) from the wave's ballot
+                const uint64_t m = __builtin_amdgcn_ballot_w64(occ != 0);
+                const uint32_t ry = by * 4u + (tid & 3u), rz = bz * 4u + ((tid >> 2) & 3u);
+                if (tid < 16u && rz < nz) {
+                    const uint32_t nib = (uint32_t)(m >> (4u * tid)) & 15u;
+                    *reinterpret_cast<uint32_t*>(grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;   // bit i -> byte i
+                }
+            }
+        }
+    }
+#if defined(DXV_QUEUE_TIMES)
+    // (diagnostic build only, tools/queue_times.py: start and end of every wave in 100 MHz ticks, in the frame's unused redo list)
+    if (threadIdx.x == 0u && 2u * blockIdx.x + 1u < p.redoCap) { p.redo[2u * blockIdx.x] = tStart; p.redo[2u * blockIdx.x + 1u] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#else
+    (void)p;
+#endif
+}
+
+// persistent waves the device holds at once (occupancy of the kernel x compute units), a multiple of 8
+static uint32_t queue_waves(bool texels)
+{
+    static uint32_t cached[2] = {0, 0};
+    uint32_t& c = cached[texels ? 1 : 0];
+    if (c) return c;
+    int dev = 0, cus = 0, perCu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const hipError_t e = texels ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_voxelize_queue<true>, 64, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_voxelize_queue<false>, 64, 0);
+    if (e != hipSuccess || perCu <= 0) { (void)hipGetLastError(); perCu = 24; }
+    c = ((uint32_t)cus * (uint32_t)perCu + 7u) & ~7u;
+    return c;
+}
+
+// rebuild: clear the grid and build the queue in front of the launch (a launch that may not rely on anything an earlier
+// launch left behind); else the caller vouches that the frame's grid and queue are those of the same launch made before
+// (same lists, partition and buffers: the kernel writes the same bricks every time) and only the queue heads are reset.
+hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, hipStream_t s)
+{
+    hipError_t e;
+    if (rebuild) {
+        if ((e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s)) != hipSuccess) return e;
+        if (p.texels && (e = hipMemsetAsync(p.texels, 0, (size_t)p.N * p.N * p.nz * 4, s)) != hipSuccess) return e;
+        if (planEvents && (e = hipEventRecord(planEvents[0], s)) != hipSuccess) return e;
+        if ((e = plan_build(p, s)) != hipSuccess) return e;
+        if (planEvents && (e = hipEventRecord(planEvents[1], s)) != hipSuccess) return e;
+    } else if ((e = hipMemsetAsync(p.queue + queue_head_word(0, 0), 0, sizeof(uint32_t) * (queue_len_word(0) - queue_head_word(0, 0)), s)) != hipSuccess) return e;   // the 64 heads
+    const uint32_t waves = p.queueWaves ? (p.queueWaves + 7u) & ~7u : queue_waves(p.texels != nullptr);
+    if (wavesOut) *wavesOut = waves;
+    if (p.texels) k_voxelize_queue<true><<<dim3(waves), dim3(64), 0, s>>>(p);
+    else k_voxelize_queue<false><<<dim3(waves), dim3(64), 0, s>>>(p);
     return hipGetLastError();
 }
 
@@ -237,13 +414,10 @@ __global__ __launch_bounds__(64) void k_list_check(VoxelizeParams p, unsigned lo
     finish_ray_reference(r);
     ray_shear(r);
     const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
-    uint32_t face, ti, tj, cx, cy;
-    float u, v, rho;
-    dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
-    dm_local(u, dm.R, ti, cx); dm_local(v, dm.R, tj, cy);
-    const DirCell cell = dm.cells[(face * dm.R + tj) * dm.R + ti];
-    const DirRayLocal loc = dm_ray_local(cx, cy);
-    const float near = rho * 0.999f;
+    const DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
+    const DirCell cell = start.cell;
+    const DirRayLocal loc = dm_ray_local(start.cx, start.cy);
+    const float rho = start.rho, near = start.near;
     const size_t id = ((size_t)lz * N + iy) * N + ix;
     auto leaf = [&](int32_t l) {
         const TriPos tp = load_tri(sc.triPos, l);
@@ -255,7 +429,7 @@ __global__ __launch_bounds__(64) void k_list_check(VoxelizeParams p, unsigned lo
         const uint32_t rc = dm_radial_word(near, (rho + t) * 1.001f + 1e-4f);
         bool found = false;
         const float step = dm_stop_step(half_bits_to_float(cell.thick)), bound = (rho + t) * 1.001f + 1e-4f;
-        if (!(half_bits_to_float(cell.r1max) < near))
+        if (start.live)
             for (uint32_t k = cell.begin; k < cell.begin + cell.count && !found; ++k) {
                 const DirEntry e = dm.entries[k];
                 if (dm_stop_radius(e, step) > bound) break;             // a scan with this hit in hand would stop here: the entry must come before
@@ -834,28 +1008,6 @@ hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEnt
     case 7: return launch_stack<Brick7>(p, stackEntries, s);
     default: return hipErrorInvalidValue;
     }
-}
-
-// Launch through a dispatch plan (above): the plan's bricks only, everything else is zero by the memset -- which the frame's
-// grid keeps while the same plan is launched into it again (the kernel writes the same set of bricks every time).
-hipError_t launch_voxelize_planned(const VoxelizeParams& p, uint64_t planId, hipStream_t s)
-{
-    uint64_t sig = 0;
-    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 0x9E3779B97F4A7C15ull; sig ^= sig >> 29; };
-    mix(0x706c616eull); mix(planId); mix(p.N); mix(p.nz); mix(p.z0); mix(p.zBlock); mix(p.zPeriod);
-    mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels));
-    sig |= 1ull;
-    if (!(p.clearSig && *p.clearSig == sig)) {
-        hipError_t e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s);
-        if (e != hipSuccess) return e;
-        if (p.texels && (e = hipMemsetAsync(p.texels, 0, (size_t)p.N * p.N * p.nz * 4, s)) != hipSuccess) return e;
-    }
-    if (p.clearSig) *p.clearSig = sig;
-    if (!p.planCount) return hipSuccess;                                // no live brick at all
-    const dim3 g(p.planCount), b(64);
-    if (p.texels) k_voxelize<Brick4, 16, 0, true, 4, 0, true><<<g, b, 0, s>>>(p);
-    else k_voxelize<Brick4, 16, 0, false, 4, 0, true><<<g, b, 0, s>>>(p);
-    return hipGetLastError();
 }
 
 // Solid-voxel count: 16 B per lane streaming reduction, one atomic per workgroup.

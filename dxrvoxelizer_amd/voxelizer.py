@@ -9,7 +9,7 @@ import numpy as np
 from ._lib import DxvError, Stats, load_library
 
 MODE_REFERENCE, MODE_PARITY = 0, 1
-DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64, DBG_LIST_CELLS, DBG_LIST_ENTRIES = range(9)
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64, DBG_LIST_CELLS, DBG_LIST_ENTRIES, DBG_LIST_MIP = range(10)
 
 
 def obj_load(path):
@@ -233,6 +233,18 @@ class Voxelizer:
         nv = int(min(out[1], 15))
         return int(out[0]), int(out[1]), int(out[2]), [(int(out[3 + 2 * k]), int(out[4 + 2 * k])) for k in range(nv)]
 
+    def plan_check(self):
+        """dxv_debug_plan_check for the current frame's last launch (which went through a work queue): dict with live_voxels,
+        live_bricks (bricks holding a live voxel, exact), queued_bricks, violations (live bricks that are not queued: must be 0),
+        duplicates (bricks queued twice: must be 0) and the first violating brick words."""
+        out = np.zeros(16, np.uint64)
+        self._check(self._lib.dxv_debug_plan_check(self._ctx, out.ctypes.data_as(C.c_void_p)))
+        return {"live_voxels": int(out[0]), "live_bricks": int(out[1]), "queued_bricks": int(out[2]), "violations": int(out[3]),
+                "duplicates": int(out[4]), "first": [int(v) for v in out[5:5 + int(min(out[3], 11))]]}
+
+    def trim(self):
+        self._check(self._lib.dxv_trim(self._ctx))
+
     def debug(self, what):
         st = self.stats()
         T = st["num_tris"]
@@ -240,7 +252,8 @@ class Voxelizer:
                   DBG_TRI_POS: ((T, 12), np.float32), DBG_TRI_NRM: ((T, 12), np.float32),
                   DBG_PARENTS: ((2 * T - 1,), np.uint32), DBG_NODES32: ((st["num_nodes"], 8), np.uint32),
                   DBG_NODES64: ((st["num_nodes"], 16), np.uint32),
-                  DBG_LIST_CELLS: ((6 * st["list_res"] ** 2, 4), np.uint32), DBG_LIST_ENTRIES: ((st["list_entries"], 4), np.uint32)}
+                  DBG_LIST_CELLS: ((6 * st["list_res"] ** 2, 4), np.uint32), DBG_LIST_ENTRIES: ((st["list_entries"], 4), np.uint32),
+                  DBG_LIST_MIP: ((sum(6 * (st["list_res"] >> l) ** 2 for l in range(max(st["list_res"], 1).bit_length())),), np.uint16)}
         shape, dt = shapes[what]
         out = np.empty(shape, dt)
         self._check(self._lib.dxv_debug_download(self._ctx, what, out.ctypes.data_as(C.c_void_p), out.nbytes))

@@ -20,6 +20,13 @@ extern "C" {
 
 #define DXV_API __attribute__((visibility("default")))
 
+/* Bumped whenever an entry point changes its signature or a struct of this header its layout; dxv_api_version() returns the
+ * value the loaded library was built with -- a binding compares the two before its first call.
+ * 4: dxv_stats plan fields describe the work queue, options planorder / planregion gone, dxv_debug_plan_check, dxv_trim;
+ * 3: dxv_debug_list_check takes a slab (z0, nz). */
+#define DXV_API_VERSION 4
+DXV_API int dxv_api_version(void);
+
 typedef struct dxv_ctx dxv_ctx;
 
 /* Occupancy rule. */
@@ -43,7 +50,8 @@ enum {
     DXV_DBG_NODES32 = 5,     /* max(T-1,1) x 32 B traversal nodes (half-float boxes)          */
     DXV_DBG_NODES64 = 6,     /* max(T-1,1) x 64 B wide traversal nodes (up to 4 boxes each)   */
     DXV_DBG_LIST_CELLS = 7,  /* 6 R R x 16 B: begin, end, far radius of every texel's list       */
-    DXV_DBG_LIST_ENTRIES = 8 /* stats.list_entries x 16 B entries of the direction-space lists  */
+    DXV_DBG_LIST_ENTRIES = 8,/* stats.list_entries x 16 B entries of the direction-space lists  */
+    DXV_DBG_LIST_MIP = 9     /* max-mip of the texels' far radii: 16-bit words, levels R^2 .. 1 x 6 faces */
 };
 
 typedef struct dxv_stats {
@@ -61,9 +69,9 @@ typedef struct dxv_stats {
     uint32_t list_entries;   /* reference rule: entries of the direction-space lists in use, 0 = tree walk */
     uint32_t list_res;       /* ... texels per cube-map face side                                   */
     float list_ms;           /* ... time of their build (first launch after a build / refit / import) */
-    uint32_t plan_bricks;    /* reference rule through a dispatch plan: bricks of 4^3 voxels with a live ray (0 = no plan) */
-    uint32_t plan_waves;     /* ... workgroups launched (the eight XCD sequences padded to the longest)               */
-    float plan_ms;           /* ... time of the plan's build (probe + placement + fill), once per (lists, partition)  */
+    uint32_t plan_bricks;    /* reference rule through a work queue: 4^3-voxel bricks queued as possibly holding a live ray (0 = no queue) */
+    uint32_t plan_waves;     /* ... persistent single-wave workgroups the launch ran (what the GPU holds at once)        */
+    float plan_ms;           /* ... time of the queue's build on the device, in front of the kernel (launches that built one) */
 } dxv_stats;
 
 /* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that
@@ -238,11 +246,12 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
  *   plists 0|1|2    parity rule through row lists of the (y, z) plane: 1 (default) from a scene's second parity launch,
  *                 2 from the first, 0 = always walk the tree; plistres 0|16..4096: texels per side of their grid
- *   plan   0|1|2  lists kernel: launch only the 4^3-voxel bricks that hold a live ray, 512-brick regions heaviest first and
- *                 dealt to the XCDs by estimated cost (1, default: from the second launch of a partition against the same
- *                 lists; 2: from the first; 0: brick box around the scene in Morton order)
- *   planorder 0..3, planregion 6..9   order of the regions inside a plan (3, default: balanced over the XCDs by cost, Morton
- *                 order, cheapest regions last) and log2 of their size in bricks (8, default)
+ *   plan   0|1|2  lists kernel through a work queue: only the 4^3-voxel bricks that can hold a live ray are run (decided per
+ *                 brick on the device, in front of the kernel in the same stream: the brick's footprint in direction space and
+ *                 its smallest start radius against a max-mip of the lists' far radii; no host round trip), taken from per-XCD
+ *                 queues by persistent waves; the rest of the grid is the launch's memset.  1 (default): queue and memset are
+ *                 kept while the frame's next launch is the same one (same lists, partition, buffers); 2: built and cleared on
+ *                 every launch (nothing carried from launch to launch); 0: no queue, brick box around the scene in Morton order
  *   events 0|1    bracket every launch with two HIP events for stats.voxelize_ms (default 1); 0 for a caller that times its own
  *                 loop of back-to-back launches (the events cost ~8 us of stream time per launch)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
@@ -262,6 +271,17 @@ DXV_API int dxv_debug_list_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, u
  * class the canonical predicate (hlsl:137-138) is evaluated and compared.  out[0] = hits on classified triangles, out[1] =
  * disagreements (must be 0), out[2] = all hits, out[3 + 2k], out[4 + 2k] = voxel id and triangle slot of the first 15. */
 DXV_API int dxv_debug_class_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, uint32_t nz, uint64_t out[34]);
+
+/* Test hook: the work queue's claim -- no live ray in a brick that is not queued -- checked exhaustively on the device for the
+ * partition of the current frame's last launch (which must have gone through a queue): every voxel makes exactly the first-step
+ * decision of the kernel (origin beyond the root box / texel empty / start beyond the texel's far radius -> miss).
+ * out[0] = live voxels, out[1] = bricks with a live voxel, out[2] = queued bricks, out[3] = live bricks that are NOT queued (must
+ * be 0), out[4] = bricks queued more than once (must be 0), out[5 + k] = brick word (bx | by << 10 | bz << 20) of the first 11. */
+DXV_API int dxv_debug_plan_check(dxv_ctx* ctx, uint64_t out[16]);
+
+/* Give back what the context keeps only to make the next build faster: the list build's scratch (up to 16 GiB per buffer
+ * after a 10 M-triangle scene), the LBVH build's scratch when no refit can follow (imported scenes).  Nothing a launch reads. */
+DXV_API int dxv_trim(dxv_ctx* ctx);
 
 /* Test hook: copy an internal device array to the host (enum above). */
 DXV_API int dxv_debug_download(dxv_ctx* ctx, int what, void* host, size_t bytes);

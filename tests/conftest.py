@@ -177,5 +177,23 @@ def hostcheck():
             ovf = L.hc_voxelize(self.h, N, mode, z0, nz, stack, g, t.ctypes.data_as(C.c_void_p) if texels else None)
             return (g, t, ovf) if texels else (g, ovf)
 
+    L.hc_plan_check.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.hc_dirmap_mip.argtypes = [C.c_void_p, C.c_void_p]
+
+    def plan_check(self, N, z0=0, nz=None, zBlock=None, zPeriod=None):
+        """(live voxels, bricks with a live voxel, bricks the work queue's box test keeps, violations) for a partition, against the
+        lists built last (Host.lists)"""
+        nz = N - z0 if nz is None else nz
+        out = np.zeros(4, np.uint64)
+        L.hc_plan_check(self.h, N, z0, nz, nz if zBlock is None else zBlock, nz if zPeriod is None else zPeriod, out.ctypes.data_as(C.c_void_p))
+        return tuple(int(v) for v in out)
+
+    def mip(self, R):
+        out = np.zeros(sum(6 * (R >> l) ** 2 for l in range(R.bit_length())), np.uint16)
+        L.hc_dirmap_mip(self.h, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    Host.plan_check = plan_check
+    Host.mip = mip
     Host.lib = L
     return Host

@@ -169,6 +169,70 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
     }
     return keys.size();
 }
+// the max-mip of the far radii from the host-built cells, level by level with the definitions of dxv_dirmap.h (the device builds
+// it in tiles: dirmap.hip; same words)
+static std::vector<uint16_t> host_mip(const HcScene* s)
+{
+    const uint32_t R = s->dmR, levels = dm_mip_levels(R);
+    std::vector<uint16_t> mip(dm_mip_words(R), 0);
+    for (size_t c = 0; c < s->dmCells.size(); ++c) mip[c] = (uint16_t)dm_mip_key(s->dmCells[c]);
+    for (uint32_t l = 1; l < levels; ++l) {
+        const uint32_t r = R >> l, rp = r << 1;
+        const uint16_t* below = mip.data() + dm_mip_offset(R, l - 1);
+        uint16_t* out = mip.data() + dm_mip_offset(R, l);
+        for (uint32_t f = 0; f < 6; ++f)
+            for (uint32_t y = 0; y < r; ++y)
+                for (uint32_t x = 0; x < r; ++x) {
+                    const uint16_t* a = below + (f * rp + 2 * y) * rp + 2 * x;
+                    out[(f * r + y) * r + x] = std::max(std::max(a[0], a[1]), std::max(a[rp], a[rp + 1]));
+                }
+    }
+    return mip;
+}
+__attribute__((visibility("default"))) void hc_dirmap_mip(void* p, void* out)
+{
+    const std::vector<uint16_t> mip = host_mip(static_cast<HcScene*>(p));
+    memcpy(out, mip.data(), mip.size() * sizeof(uint16_t));
+}
+// The work queue's brick test (dm_box_may_be_live over dm_brick_hull) against the per-voxel first-step decision of the kernel
+// (origin_leaves_root, dm_ray_start) for every brick of a partition: out[0] live voxels, out[1] bricks with a live voxel,
+// out[2] bricks the box test keeps, out[3] violations (a live voxel in a brick the test drops: must be 0).
+__attribute__((visibility("default"))) void hc_plan_check(void* p, uint32_t N, uint32_t z0, uint32_t nz, uint32_t zBlock, uint32_t zPeriod, uint64_t* out)
+{
+    HcScene* s = static_cast<HcScene*>(p);
+    const std::vector<uint16_t> mip = host_mip(s);
+    const DirMapView dm{s->dmCells.data(), s->dmEntries.data(), s->dmR};
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }
+    for (const TriPos& tp : s->triPos) {                                  // root box = union of the canonical triangle boxes
+        float l[3], h[3];
+        tri_box(tp.v0, tp.v1, tp.v2, l, h);
+        for (int a = 0; a < 3; ++a) { lo[a] = min_(lo[a], l[a]); hi[a] = max_(hi[a], h[a]); }
+    }
+    uint32_t zShift = 0;
+    while ((1u << zShift) < zBlock) ++zShift;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    const uint32_t nbx = (N + 3) / 4, nbz = (nz + 3) / 4;
+    for (uint32_t bz = 0; bz < nbz; ++bz)
+        for (uint32_t by = 0; by < nbx; ++by)
+            for (uint32_t bx = 0; bx < nbx; ++bx) {
+                uint32_t live = 0;
+                for (uint32_t t = 0; t < 64; ++t) {
+                    const uint32_t ix = bx * 4 + (t & 3), iy = by * 4 + ((t >> 2) & 3), lz = bz * 4 + (t >> 4);
+                    if (ix >= N || iy >= N || lz >= nz) continue;
+                    const uint32_t iz = zBlock == nz ? z0 + lz : z0 + (lz >> zShift) * zPeriod + (lz & (zBlock - 1u));
+                    float ox, oy, oz;
+                    ray_origin(N, ix, iy, iz, ox, oy, oz);
+                    if (origin_leaves_root(ox, oy, oz, lo, hi)) continue;
+                    if (dm_ray_start(ox, oy, oz, dm).live) ++live;
+                }
+                float x0, x1, y0, y1, zl, zh;
+                dm_brick_hull(N, nz, z0, zBlock, zShift, zPeriod, bx, by, bz, x0, x1, y0, y1, zl, zh);
+                const bool kept = dm_box_may_be_live(x0, x1, y0, y1, zl, zh, lo, hi, mip.data(), s->dmR);
+                out[0] += live; out[1] += live ? 1 : 0; out[2] += kept ? 1 : 0;
+                if (live && !kept) ++out[3];
+            }
+}
 // dm_footprint of one triangle (9 floats) on one face: out = u0, u1, v0, v1, r0, r1; returns 0 when the face does not see it
 __attribute__((visibility("default"))) int hc_dm_footprint(const float* tri, uint32_t face, float* out)
 {

@@ -100,15 +100,25 @@ def test_config_grid_equals_oracle_fixture(dxv, configs, key):
             check_whole(v.Grid(), configs[key], f"{key} lists={lists}")
             assert v.CountSolid() == configs[key]["solid"]
             if mode == 0 and lists == 2 and st["list_entries"] > 0:
-                # the same launch through a dispatch plan (live bricks only, regions by cost), twice: the second one keeps
-                # the first one's memset
+                # (the launches above went through the work queue -- the default: live bricks only, decided on the device in
+                # front of the kernel.)  Exhaustively: no live ray sits in a brick that was not queued; then the same launch
+                # again (it keeps queue and memset), with everything rebuilt on every launch (plan = 2), and over the brick box
+                assert 0 < st["plan_bricks"] <= (N // 4) ** 3 and st["plan_waves"] % 8 == 0 and st["plan_waves"] > 0
+                chk = v.plan_check()
+                assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == st["plan_bricks"], chk
+                assert chk["live_bricks"] <= chk["queued_bricks"] <= 1.5 * chk["live_bricks"] + 64, chk
+                v.Voxelize(N, mode)
+                check_whole(v.Grid(), configs[key], f"{key} queue, second launch")
                 v.set_option("plan", 2)
                 for again in range(2):
                     v.Voxelize(N, mode)
-                    sp = v.stats()
-                    assert 0 < sp["plan_bricks"] <= (N // 4) ** 3 and sp["plan_waves"] >= sp["plan_bricks"]
-                    check_whole(v.Grid(), configs[key], f"{key} plan, launch {again}")
+                    assert v.stats()["plan_bricks"] == st["plan_bricks"]
+                    check_whole(v.Grid(), configs[key], f"{key} queue rebuilt, launch {again}")
                 v.set_option("plan", 0)
+                v.Voxelize(N, mode)
+                assert v.stats()["plan_bricks"] == 0
+                check_whole(v.Grid(), configs[key], f"{key} brick box")
+                v.set_option("plan", 1)
     finally:
         v.close()
 
@@ -139,17 +149,22 @@ def test_config4_dragon9_1024_slabs_and_block_cyclic(dxv, configs):
             if lists == 2:
                 # (launched at 1024^3 more than once: the lists have moved to the 512 map, a texel stays ~2 voxels wide)
                 assert v.stats()["list_res"] == 512
-                # every rank's share through its dispatch plan (what bench.py --gpus 8 runs), and two slabs
-                v.set_option("plan", 2)
-                for r in range(W):
-                    v.VoxelizeInterleaved(N, r, W, blk)
-                    assert v.stats()["plan_bricks"] > 0
-                    assert sha(v.Grid()) == want["cyclic8x8_sha256"][r], f"block-cyclic rank {r} through a plan"
+                # (every launch above went through its partition's work queue; one rank's share and one slab checked exhaustively)
+                assert v.stats()["plan_bricks"] > 0
+                for part in ("cyclic", "slab"):
+                    if part == "cyclic":
+                        v.VoxelizeInterleaved(N, 5, W, blk)
+                    else:
+                        v.Voxelize(N, 0, *slab_range(N, 3, W))
+                    chk = v.plan_check()
+                    assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == v.stats()["plan_bricks"], (part, chk)
+                # ... and over the brick box (no queue)
+                v.set_option("plan", 0)
                 for r in (0, 3):
                     z0, nz = slab_range(N, r, W)
                     v.Voxelize(N, 0, z0, nz)
-                    assert sha(v.Grid()) == want["slabs8_sha256"][r], f"slab {r} through a plan"
-                v.set_option("plan", 0)
+                    assert v.stats()["plan_bricks"] == 0 and sha(v.Grid()) == want["slabs8_sha256"][r], f"slab {r} over the brick box"
+                v.set_option("plan", 1)
     finally:
         v.close()
 
@@ -168,11 +183,16 @@ def test_config5_soup10m_512(dxv, configs):
             v.Voxelize(512)
             check_whole(v.Grid(), configs[key], f"{key} lists={lists}")
         v.set_option("lists", 2)
-        v.set_option("plan", 2)
+        v.set_option("plan", 0)
+        v.Voxelize(512)
+        assert v.stats()["plan_bricks"] == 0
+        check_whole(v.Grid(), configs[key], f"{key} brick box")
+        v.set_option("plan", 1)
         v.Voxelize(512)
         if v.stats()["list_entries"]:
             assert v.stats()["plan_bricks"] > 0
-        check_whole(v.Grid(), configs[key], f"{key} plan")
+            chk = v.plan_check()
+            assert chk["violations"] == 0 and chk["duplicates"] == 0, chk
     finally:
         v.close()
         _cache.clear()
@@ -207,7 +227,7 @@ def test_lists_and_classes_checked_exhaustively_at_config_scale(dxv, configs, na
 
 def test_headline_partition_of_bench_at_8_ranks(dxv, configs):
     """What `bench.py --gpus 8` runs: torus-1M at 512^3, Z blocks of 4 slices dealt round-robin over 8 ranks, every rank's
-    share launched repeatedly (so: through its dispatch plan, with the kept memset).  One GPU plays the ranks in turn; the
+    share launched repeatedly (through its work queue; from the second launch on with the kept queue and memset).  One GPU plays the ranks in turn; the
     reassembled grid must be the fixture's."""
     from dxrvoxelizer_amd.slabs import scatter_interleaved
     key = "torus1m/512/reference"

@@ -15,7 +15,7 @@ from dxrvoxelizer_amd.slabs import gather_slabs, slab_range
 
 pytestmark = pytest.mark.gpu
 
-DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64, DBG_LIST_CELLS, DBG_LIST_ENTRIES = range(9)
+DBG_SORTED_KEYS, DBG_NODES, DBG_TRI_POS, DBG_TRI_NRM, DBG_PARENTS, DBG_NODES32, DBG_NODES64, DBG_LIST_CELLS, DBG_LIST_ENTRIES, DBG_LIST_MIP = range(10)
 
 
 @pytest.fixture(scope="module")
@@ -1150,8 +1150,9 @@ def test_kept_memset_of_partial_launches(dxv, orc):
     v.InitFromArrays(vb, ib)
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-    for lists in (2, 0):
+    for lists, plan in ((2, 1), (2, 0), (0, 0)):                        # lists through the work queue / over the brick box, tree walk
         v.set_option("lists", lists)
+        v.set_option("plan", plan)
         for frame in (0, 2):
             v.SetFrame(frame)
             v.Voxelize(N); assert np.array_equal(v.Grid(), ref)
@@ -1182,12 +1183,13 @@ def test_kept_memset_of_partial_launches(dxv, orc):
 
 
 @pytest.mark.gpu
-def test_dispatch_plan_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon):
-    """Lists kernel through a dispatch plan (option plan: only bricks with a live ray are launched, 512-brick regions
-    heaviest first, dealt to the XCDs by cost; everything else is the launch's memset): same grid as the plain launch and
-    the oracle -- whole grids, grids that are no multiple of the brick or the region, slabs, block-cyclic ranks, texels,
-    frames in flight, a refit (new lists: a new plan), the automatic policy (second launch of a partition), and the
-    caller writing into the grid between two planned launches."""
+def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, hostcheck):
+    """Lists kernel through the work queue (option plan: only bricks that can hold a live ray are run, decided per brick on
+    the device in front of the kernel and taken from per-XCD queues by persistent waves; everything else is the launch's
+    memset): same grid as the launch over the brick box and the oracle -- whole grids, grids that are no multiple of the
+    brick or the region, slabs, block-cyclic ranks, texels, frames in flight, a refit (new lists: a new queue), every launch
+    rebuilt (plan = 2), the caller writing into the grid between two launches -- and the queue's claim checked exhaustively
+    (no live ray in a brick that is not queued; no brick queued twice)."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
@@ -1201,71 +1203,86 @@ def test_dispatch_plan_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon):
             v.set_option("plan", 0)
             v.Voxelize(N)
             assert np.array_equal(v.Grid(), want) and v.stats()["plan_bricks"] == 0
-            v.set_option("plan", 2)
-            for again in range(3):
-                v.Voxelize(N)
-                st = v.stats()
-                assert st["plan_bricks"] > 0 and st["plan_waves"] % 8 == 0 and st["plan_waves"] >= st["plan_bricks"]
-                assert np.array_equal(v.Grid(), want), (N, again)
+            for plan in (1, 2):
+                v.set_option("plan", plan)
+                for again in range(3):
+                    v.Voxelize(N)
+                    st = v.stats()
+                    assert st["plan_bricks"] > 0 and st["plan_waves"] % 8 == 0 and st["plan_waves"] > 0
+                    assert np.array_equal(v.Grid(), want), (N, plan, again)
+                chk = v.plan_check()
+                assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == st["plan_bricks"], (N, chk)
+                assert chk["live_bricks"] <= chk["queued_bricks"]
+            v.set_option("plan", 1)
             assert hip.hipMemset(C.c_void_p(v.grid_device_ptr()), 1, N ** 3) == 0 and hip.hipDeviceSynchronize() == 0
             v.Voxelize(N)
-            assert np.array_equal(v.Grid(), want), "the caller's bytes in bricks the plan does not launch"
+            assert np.array_equal(v.Grid(), want), "the caller's bytes in bricks that are not queued"
             if N % 16 == 0:
                 for z0, nz in ((0, N // 2), (N // 4, 10), (N - 6, 6)):
                     v.Voxelize(N, 0, z0, nz)
                     assert np.array_equal(v.Grid(), want[z0:z0 + nz]), (N, z0, nz)
-                for world, zb in ((2, 4), (4, 2)):
+                    assert v.plan_check()["violations"] == 0
+                for world, zb in ((2, 4), (4, 2), (4, 1)):
                     for r in range(world):
                         v.VoxelizeInterleaved(N, r, world, zb)
                         zs = [z for z in range(N) if (z // zb) % world == r]
                         assert np.array_equal(v.Grid(), want[zs]), (N, world, zb, r)
-    # texels, frames in flight (one plan serves all frames; every frame's grid needs its own memset)
+                        assert v.plan_check()["violations"] == 0
+    # the device's max-mip of the far radii is the host's, word for word
     vb, ib, _ = bunny
     s = orc.Scene(vb, ib)
+    v.InitFromArrays(vb, ib)
+    v.Voxelize(64)
+    R = v.stats()["list_res"]
+    h = hostcheck(vb, ib, s.bound)
+    h.lists(R)
+    assert np.array_equal(v.debug(DBG_LIST_MIP), h.mip(R))
+    # texels, frames in flight (every frame owns its queue and its grid's memset)
     N = 128
     want, wtex = s.voxelize(N, texels=True)
-    v.InitFromArrays(vb, ib)
     v.EnableTexels(True)
-    v.Voxelize(N)
-    assert np.array_equal(v.Grid(), want) and np.array_equal(v.Texels(), wtex)
+    for _ in range(2):
+        v.Voxelize(N)
+        assert np.array_equal(v.Grid(), want) and np.array_equal(v.Texels(), wtex)
     v.EnableTexels(False)
-    for f in range(v.FrameCount):
-        v.Voxelize(N, 0, sync=False, frameIndex=f)
+    for rounds in range(2):
+        for f in range(v.FrameCount):
+            v.Voxelize(N, 0, sync=False, frameIndex=f)
     v.SyncAll()
     for f in range(v.FrameCount):
         v.SetFrame(f)
         assert v.stats()["plan_bricks"] > 0 and np.array_equal(v.Grid(), want), f
     v.SetFrame(0)
-    # automatic policy: the first launch of a partition against new lists takes the brick box, the second builds the plan
-    v.set_option("plan", 1)
+    # a refit makes new lists: the next launch builds its queue against them
     lo, hi = vb[:, :3].min(0), vb[:, :3].max(0)
     pins = np.zeros((2, 6), np.float32)
     pins[0, :3], pins[1, :3] = (lo + hi) / 2 - 1.25 * (hi - lo).max() / 2, (lo + hi) / 2 + 1.25 * (hi - lo).max() / 2
     vb0 = np.concatenate([vb, pins]).astype(np.float32)                 # (unreferenced vertices pin the bound through the refit)
     v.InitFromArrays(vb0, ib)
     v.Voxelize(N); v.Voxelize(N)
-    assert v.stats()["plan_bricks"] > 0
+    b0 = v.stats()["plan_bricks"]
+    assert b0 > 0
     vb1 = vb0.copy()
     vb1[:-2, 0] = (vb1[:-2, 0] - (lo[0] + hi[0]) / 2) * np.float32(0.8) + (lo[0] + hi[0]) / 2
-    v.UpdateVertices(vb1)                                               # refit: new lists at the next launch, the old plan is stale
+    v.UpdateVertices(vb1)
     w2 = orc.Scene(vb1, ib).voxelize(N)
-    seen = []
     for k in range(3):
         v.Voxelize(N)
-        seen.append(v.stats()["plan_bricks"] > 0)
+        assert 0 < v.stats()["plan_bricks"] < b0                         # (the squeezed mesh fills fewer bricks)
         assert np.array_equal(v.Grid(), w2), k
-    assert seen == [False, True, True]
+    assert v.plan_check()["violations"] == 0
     g_auto = v.Grid()
     v.set_option("plan", 0)
     v.Voxelize(N)
     assert np.array_equal(v.Grid(), g_auto)
-    # every region size and order of a plan, and launches without the library's two events (a caller timing its own loop)
-    v.set_option("plan", 2)
-    for region, order, events in ((6, 0, 1), (7, 1, 0), (8, 2, 1), (9, 3, 0), (8, 3, 1)):
-        v.set_option("planregion", region); v.set_option("planorder", order); v.set_option("events", events)
+    # launches without the library's events (a caller timing its own loop)
+    for plan, events in ((1, 0), (2, 0), (2, 1), (1, 1)):
+        v.set_option("plan", plan); v.set_option("events", events)
         for _ in range(2):
             v.Voxelize(N)
         st = v.stats()
         assert st["plan_bricks"] > 0 and (st["voxelize_ms"] > 0) == bool(events)
-        assert np.array_equal(v.Grid(), g_auto), (region, order, events)
+        if plan == 2 and events:
+            assert 0 < st["plan_ms"] < st["voxelize_ms"]
+        assert np.array_equal(v.Grid(), g_auto), (plan, events)
     v.close()

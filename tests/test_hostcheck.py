@@ -414,3 +414,55 @@ def test_parity_row_lists_give_the_oracle_grid(orc, hostcheck, bunny):
             L.hc_plists_build(h.h, R)
             got, _ = h.voxelize(N, mode=13)
             assert np.array_equal(got, want), (n_tris, Lt, N, R)
+
+
+def test_work_queue_brick_test_never_drops_a_live_ray(orc, hostcheck, bunny, dragon):
+    """The work queue of the lists kernel (traverse.hip: k_plan_bricks) keeps a 4^3-voxel brick iff dm_box_may_be_live says
+    a ray of it can be live -- decided from the brick's hull, three of its corners and a max-mip of the lists' far radii
+    (dxv_dirmap.h).  Replayed on the host against the per-voxel first-step decision the kernel makes (origin_leaves_root,
+    dm_ray_start: the same functions): no live voxel may sit in a dropped brick, on grids whose bricks straddle the centre
+    planes or hang over the grid's end, on slabs and block-cyclic partitions, on coarse and fine maps, on meshes through the
+    grid centre -- and the test must stay tight (it is what saves the launch its dead waves)."""
+    from test_fuzz import lattice_mesh
+    from dxrvoxelizer_amd import meshes
+    kept_total = live_total = 0
+    for (vb, ib, _), sizes in ((bunny, (64, 100, 50)), (dragon, (128, 66))):
+        s = orc.Scene(vb, ib)
+        h = hostcheck(vb, ib, s.bound)
+        for R in (128, 32):
+            h.lists(R)
+            # the mip is the maximum over the texels below a cell
+            cells = h.lists(R)[0]
+            key = np.where((cells[:, 1] & 0xffff) > 0, cells[:, 1] >> 16, 0).astype(np.uint16).reshape(6, R, R)
+            mip = h.mip(R)
+            off = 0
+            for l in range(R.bit_length()):
+                r = R >> l
+                want = key.reshape(6, r, 1 << l, r, 1 << l).max(axis=(2, 4))
+                assert np.array_equal(mip[off:off + 6 * r * r].reshape(6, r, r), want), (R, l)
+                off += 6 * r * r
+            for N in sizes:
+                parts = [(0, N, N, N)]
+                if N % 16 == 0:
+                    parts += [(N // 4, 10, 10, 10), (N - 6, 6, 6, 6), (4, N // 2, 4, 8), (1, N // 4, 1, 4), (2, N // 2, 2, 4)]
+                for z0, nz, zb, zp in parts:
+                    live, live_bricks, kept, bad = h.plan_check(N, z0, nz, zb, zp)
+                    assert bad == 0, (R, N, z0, nz, zb, zp)
+                    assert kept >= live_bricks
+                    if zb >= 4 and nz == N and R == 128:
+                        kept_total += kept; live_total += live_bricks
+    assert kept_total <= 1.35 * live_total, (kept_total, live_total)     # at most a third more bricks than hold a live ray
+    rng = np.random.default_rng(4)
+    for n_tris in (1, 3, 30, 200):
+        for N in (8, 16, 34):
+            vb, ib = lattice_mesh(rng, n_tris, N)
+            s = orc.Scene(vb, ib)
+            h = hostcheck(vb, ib, s.bound)
+            for R in (16, 128):
+                h.lists(R)
+                assert h.plan_check(N)[3] == 0, (n_tris, N, R)
+    vb, ib = meshes.torus(nu=60, nv=30)
+    h = hostcheck(vb, ib, orc.Scene(vb, ib).bound)
+    h.lists(64)
+    live, live_bricks, kept, bad = h.plan_check(96)
+    assert bad == 0 and 0 < live_bricks <= kept < (96 // 4) ** 3 // 2     # the torus leaves most of the grid dead

@@ -48,7 +48,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
     rng = np.random.default_rng(seed)
     v = dxv.Voxelizer(0)
-    t0, cases, grids, checked, classes = time.time(), 0, 0, 0, 0
+    t0, cases, grids, checked, classes, queued = time.time(), 0, 0, 0, 0, 0
     while time.time() - t0 < budget:
         (vb, ib), label = random_mesh(rng)
         T = len(ib) // 3
@@ -73,12 +73,12 @@ def main():
                     "subbox": int(rng.integers(0, 2)), "morton": int(rng.integers(0, 2)),
                     "lists": int(rng.integers(0, 3)), "listres": int(rng.choice([0, 0, 16, 64, 512, 2048])),
                     "plists": int(rng.integers(0, 3)), "plistres": int(rng.choice([0, 0, 16, 128, 1024])),
-                    "plan": int(rng.integers(0, 3)), "planorder": int(rng.integers(0, 4))}
+                    "plan": int(rng.integers(0, 3)), "queuesteal": int(rng.integers(0, 2)), "queuewaves": int(rng.choice([0, 0, 8, 64, 1000]))}
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))
             v.SetFrame(int(rng.integers(0, 3)))               # any of the context's frames in flight
-            again = int(rng.choice([1, 1, 2, 3]))             # the same launch again: kept memsets, dispatch plans from the second launch on
+            again = int(rng.choice([1, 1, 2, 3]))             # the same launch again: kept memsets and work queues from the second launch on
             try:
                 if part == 0:
                     for _ in range(again):
@@ -108,6 +108,13 @@ def main():
                                   "differ": int((got != ref).sum())}))
                 sys.exit(1)
             assert np.array_equal(v.GridBits(), np.packbits(got.reshape(-1), bitorder="little"))
+            if mode == 0 and v.stats()["plan_bricks"] > 0:
+                # the launch went through a work queue: no live ray in a brick that was not queued, no brick queued twice
+                chk = v.plan_check()
+                if chk["violations"] or chk["duplicates"] or chk["queued_bricks"] != v.stats()["plan_bricks"]:
+                    print(json.dumps({"FAIL": label, "plan_check": chk, "T": T, "N": N, "part": part, "opts": opts, "seed": seed}))
+                    sys.exit(1)
+                queued += chk["queued_bricks"]
             if mode == 0 and v.stats()["list_entries"] > 0 and T * N ** 3 < 2e9:
                 # the lists in use, exhaustively: every triangle the canonical step accepts for a ray is selectable from its list
                 accepted, violations, first = v.list_check(N)
@@ -130,7 +137,7 @@ def main():
                 b = v.Render(eye, vp, 96, 64)
                 v.set_option("skipempty", 1)
                 assert np.array_equal(a, b), (label, N)
-    print(json.dumps({"soak": "ok", "seconds": round(time.time() - t0, 1), "meshes": cases, "grids": grids, "list_pairs_checked": int(checked), "class_hits_checked": int(classes), "seed": seed}))
+    print(json.dumps({"soak": "ok", "seconds": round(time.time() - t0, 1), "meshes": cases, "grids": grids, "list_pairs_checked": int(checked), "class_hits_checked": int(classes), "queued_bricks_checked": int(queued), "seed": seed}))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic (library built with -DDXV_QUEUE_TIMES: python -c "from dxrvoxelizer_amd import build; build.build(defines=['DXV_QUEUE_TIMES'], name='qtimes')"):
+when do the persistent waves of a queue launch start and end?  usage: DXV_LIBRARY=.../libdxv_qtimes.so queue_times.py [mesh] [grid] [opts]"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import dxrvoxelizer_amd as dxv  # noqa: E402
+from bench import make_mesh  # noqa: E402
+
+mesh = sys.argv[1] if len(sys.argv) > 1 else "torus1m"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+v = dxv.Voxelizer(0)
+v.set_option("lists", 2)
+for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 else "").split(",")):
+    v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+vb, ib, _ = make_mesh(mesh)
+v.InitFromArrays(vb, ib)
+for _ in range(3):
+    v.Voxelize(N, 0)
+st = v.stats()
+raw = np.zeros(1 << 16, np.uint64)
+v._check(v._lib.dxv_debug_download(v._ctx, 100, raw.ctypes.data_as(C.c_void_p), raw.nbytes))
+w = st["plan_waves"]
+t = raw[:2 * w].reshape(w, 2).astype(np.int64)
+t0 = t[:, 0].min()
+start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0          # microseconds
+q = [0, 1, 5, 25, 50, 75, 95, 99, 100]
+print(json.dumps({"mesh": mesh, "N": N, "kernel_ms": round(st["voxelize_ms"], 4), "bricks": st["plan_bricks"], "waves": w,
+                  "start_us_pct": dict(zip(q, np.percentile(start, q).round(1).tolist())),
+                  "end_us_pct": dict(zip(q, np.percentile(end, q).round(1).tolist())),
+                  "end_by_xcd_us": [round(float(end[x::8].max()), 1) for x in range(8)],
+                  "first_end_by_xcd_us": [round(float(end[x::8].min()), 1) for x in range(8)]}))

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--set", default="")
     ap.add_argument("--tree", action="store_true")
     ap.add_argument("--frames", type=int, default=0, help="also the throughput with this many voxelizations in flight (frames of the one context)")
+    ap.add_argument("--fresh", action="store_true", help="also with queue and grid rebuilt on every launch (plan=2) and over the brick box (plan=0), and the queue's exhaustive check")
     a = ap.parse_args()
     v = dxv.Voxelizer(0)
     v.set_option("lists", 2)
@@ -41,8 +42,24 @@ def main():
             tag = "lists" if lists else "tree"
             out[f"{tag}_ms"] = round(float(np.median(ts)), 4)
             if lists:
-                out.update({"entries": st["list_entries"], "res": st["list_res"], "list_ms": round(st["list_ms"], 3)})
+                out.update({"entries": st["list_entries"], "res": st["list_res"], "list_ms": round(st["list_ms"], 3),
+                            "plan_bricks": st["plan_bricks"], "plan_waves": st["plan_waves"]})
             out[f"{tag}_solid"] = v.CountSolid()
+            if lists and a.fresh:
+                chk = v.plan_check()
+                out.update({"live_bricks": chk["live_bricks"], "live_voxels": chk["live_voxels"], "queue_violations": chk["violations"] + chk["duplicates"]})
+                for plan, name in ((2, "fresh"), (0, "box")):
+                    v.set_option("plan", plan)
+                    v.Voxelize(a.grid, 0)
+                    ts, ps = [], []
+                    for _ in range(a.reps):
+                        v.Voxelize(a.grid, 0)
+                        ts.append(v.stats()["voxelize_ms"]); ps.append(v.stats()["plan_ms"])
+                    out[f"{name}_ms"] = round(float(np.median(ts)), 4)
+                    if plan == 2:
+                        out["plan_ms"] = round(float(np.median(ps)), 4)
+                    out[f"{name}_solid"] = v.CountSolid()
+                v.set_option("plan", 1)
         v.set_option("lists", 2)
         if a.frames > 1:
             import time
