@@ -73,6 +73,20 @@ def build_bytes(T, passes=4):
     return T * 36 + T * 8 + passes * 16 * T + (2 * T - 1) * 32 + (T - 1) * 64
 
 
+def source_hash():
+    """sha256 over the sources libdxv.so is built from (csrc/ + include/dxv.h): what ties a committed PMC figure
+    (profiles/traffic.json) to the kernels this run executes."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "dxrvoxelizer_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "dxv.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(vb, ib, N, mode, budget_s=15.0):  # (N > 1: a shorter sample, the other ranks wait for rank 0)
     """The oracle's scalar BVH voxelizer ('port': the reference has no CPU path) on a bounded
     sample of the same workload: evenly spaced Z slices, all host cores (OpenMP over rows)."""
@@ -128,8 +142,8 @@ def launch_ranks(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=400)      # 0.35 s of timed steps on one GPU, 45 ms at 8 ranks (a region the driver's sampler sees)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--mesh", default="torus1m")
     ap.add_argument("--mode", default="reference", choices=["reference", "parity"])
@@ -209,7 +223,7 @@ def main():
 
     vb = ib = None
     label = args.mesh
-    bcast_ms = 0.0
+    bcast_ms, bcast = 0.0, {}
     if rank == 0:
         vb, ib, label = make_mesh(args.mesh)
         vox.InitFromArrays(vb, ib)               # upload + LBVH build (not part of a step)
@@ -219,10 +233,10 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        broadcast_scene(vox, dist, torch.device("cuda", local_rank))
+        broadcast_scene(vox, dist, torch.device("cuda", local_rank), info=bcast)
         torch.cuda.synchronize()
         dist.barrier()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
+        bcast_ms = (time.perf_counter() - t0) * 1e3          # export + broadcast + checksum all-gather + import, barrier to barrier
     st0 = vox.stats()
     T, V = st0["num_tris"], st0["num_verts"]
 
@@ -236,7 +250,7 @@ def main():
     if interleave:
         nz = N // world
 
-    prepared = set()                             # grid sizes whose lists and plan exist (two untimed launches each, before any warm-up)
+    prepared = set()                             # grid sizes launched once before any warm-up (that launch builds the scene's candidate lists)
 
     def timed_region(frames, steps, warmup, n=None, per_step=False):
         """`steps` steps with `frames` voxelizations in flight (frames of the one context, taking the steps in turn),
@@ -259,11 +273,10 @@ def main():
             elif nzn:
                 vox.Voxelize(n, mode, z0n, nzn, sync=False, frameIndex=f)
 
-        if n not in prepared:                    # the scene's launch structures, like the reference's acceleration structure part of
-            prepared.add(n)                      # Init, not of a step: the candidate lists are built by the first launch of a scene,
-            for _ in range(2):                   # the dispatch plan of this partition by the second (include/dxv.h, options lists / plan)
-                step()
-            vox.SyncAll()
+        if n not in prepared:                    # the scene's candidate lists, like the reference's acceleration structure part of Init,
+            prepared.add(n)                      # not of a step: built by the first launch of a scene (include/dxv.h, option lists).
+            step()                               # (The launch's work queue is built on the device inside every launch that needs one:
+            vox.SyncAll()                        # option plan, and config.fresh_step below.)
         for _ in range(max(warmup, frames)):     # every frame launches at least once before the clock starts
             step()
         vox.SyncAll()
@@ -298,6 +311,10 @@ def main():
         vox.SetFrame(0)
         return dt, k_ms, steps_ms
 
+    def st_probe():
+        vox.SyncAll()
+        return vox.stats()
+
     def reduce_max(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
         if use_dist:
@@ -320,6 +337,26 @@ def main():
     dt, kernel_ms, _ = timed_region(frames, args.steps, args.warmup)
     dt_max = reduce_max(dt)
     _, _, per_step = timed_region(1, args.steps, 1, per_step=True)      # the same steps once more with an event behind every one: their spread
+    # The headline's steps launch the same partition into the same frame again and again (the reference's own loop,
+    # Content/Voxelizer.cpp:108-113): from the second one on they keep the frame's work queue and the zeros of the bricks it does
+    # not run (option plan = 1).  The no-carried-state figure: the same steps with the queue rebuilt on the device and the whole
+    # grid cleared inside EVERY step (plan = 2) -- what a scene that changes every frame, or a caller's first launch, pays.
+    fresh = None
+    if mode == dxv.MODE_REFERENCE and st_probe()["plan_bricks"]:
+        vox.set_option("plan", 2)
+        dtf, kf, _ = timed_region(frames, args.steps, args.warmup)
+        dtf = reduce_max(dtf)
+        vox.set_option("events", 1)
+        pm = []
+        for _ in range(5):                                              # (a few launches with the library's events: the queue build alone)
+            if interleave:
+                vox.VoxelizeInterleaved(N, rank, world, zblock, mode)
+            elif nz:
+                vox.Voxelize(N, mode, z0, nz)
+            pm.append(vox.stats()["plan_ms"])
+        fresh = {"dt": dtf, "kernel_ms": kf, "plan_ms": float(np.median(pm)), "bricks": vox.stats()["plan_bricks"]}
+        vox.set_option("plan", 1)
+        timed_region(1, 2, 1)                                           # (back to the kept queue for what follows)
     rank_kernel_ms = gather(kernel_ms)           # every rank's mean launch duration: an imbalance of the partition shows here
     rank_wall_ms = gather(dt / max(args.steps, 1) * 1e3)
     kmax = max(rank_kernel_ms)
@@ -404,15 +441,39 @@ def main():
         value = (N ** 3) * args.steps / dt_max / 1e6
         bytes_launch = algorithmic_bytes(N, nz, T, V)
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC passes committed under profiles/ (collected and corrected as MI355X_MICROARCH.md
+        # prescribes; tools/collect_evidence.py) -- only when they were taken on THESE sources: the file carries the hash of
+        # csrc/ at the time, and a figure of other kernels is not reported as this run's
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.mesh}/{N}/{args.mode}/gpus{world}"    # (N > 1: one rank's launch, like `achieved`)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                ent = tj.get(key, {})
+                if ent.get("source_hash") == source_hash():
+                    traffic = ent.get("hbm_bytes_per_launch")
+                elif ent:
+                    traffic_note = (f"profiles/traffic.json holds {ent.get('hbm_bytes_per_launch')} B for this workload, measured on sources "
+                                    f"{ent.get('source_hash', '(round ' + str(ent.get('round')) + ', no hash)')}; this run's are {source_hash()}: not reported")
             except Exception:
                 traffic = None
+        bricks = st_run.get("plan_bricks", 0)
+        scene_bytes = bytes_launch - N * N * nz                  # the read side of the algorithmic bytes
+        stored_kept = 64 * bricks if bricks else N * N * nz       # a step with the kept queue stores its queued bricks only
+        fresh_out = None
+        if fresh:
+            f_ms = fresh["dt"] / args.steps * 1e3
+            f_stored = N * N * nz + 64 * fresh["bricks"]          # the grid's clear + the queued bricks' results
+            fresh_out = {"what": "the same steps with nothing carried from launch to launch (option plan = 2): the work queue rebuilt on the "
+                                 "device and the whole grid cleared inside every step",
+                         "plan": "rebuilt in the step", "grid": "cleared in the step",
+                         "ms_per_step": f_ms, "mvoxels_s": (N ** 3) * args.steps / fresh["dt"] / 1e6, "kernel_ms": fresh["kernel_ms"],
+                         "queue_build_ms": fresh["plan_ms"], "queued_bricks": fresh["bricks"],
+                         "roofline": {"bound": "hbm", "stored_bytes": f_stored, "read_bytes": scene_bytes,
+                                      "achieved": (f_stored + scene_bytes) / (fresh["kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "frac": (f_stored + scene_bytes) / (fresh["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                      "note": "bytes this step really stores (memset of the grid + 64 B per queued brick) + the scene read once"}}
         out = {
             "metric": "solid Mvoxels/s at 512^3 (1M-tri mesh)" if (N == 512 and args.mesh == "torus1m")
                       else f"solid Mvoxels/s at {N}^3 ({label})",
@@ -424,7 +485,8 @@ def main():
                                                            if interleave else f"Z-slab partition over {world} GPU(s)"),
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
                        "slab_slices_rank0": nz, "frames_in_flight": frames, "solid_voxels": int(tot.item()),
-                       "untimed_launches_before_warmup": 2,     # lists (first launch of a scene) and dispatch plan (second) are Init work
+                       "untimed_launches_before_warmup": 1,     # the scene's candidate lists (built by its first launch) are Init work
+                       "fresh_step": fresh_out,
                        "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": args.backend if use_dist else None,
                        "tree_height": st0["tree_height"], "stack_entries": st_run["stack_entries"],
                        "candidates": ({"structure": "direction-space lists", "texels_per_face_side": st_run["list_res"],
@@ -436,29 +498,39 @@ def main():
                                           "achieved": build_bytes(T) / (st0["build_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                           "frac": build_bytes(T) / (st0["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                           "note": "LBVH build of this mesh (keys, 4-pass radix sort, hierarchy, boxes, half-float node copy), "
-                                                  "B_build of SURVEY.md 8(d); the 10 M-triangle build of config 5: profiles/r03/build_soup10m.jsonl"},
+                                                  "B_build of SURVEY.md 8(d)"},
                        "upload_ms": st0["upload_ms"], "scene_broadcast_ms": bcast_ms,
+                       "scene_broadcast": ({"bytes": bcast.get("bytes"), "collective_ms": bcast.get("broadcast_ms"),
+                                            "checksum": f"{bcast.get('checksum', 0):#018x}", "ranks_equal": len(set(bcast.get("checksums", [0]))) == 1}
+                                           if bcast else None),
                        "kernel_ms_max_over_ranks": kmax, "rank_kernel_ms": rank_kernel_ms, "rank_ms_per_step": rank_wall_ms,
                        "rank_imbalance": max(rank_kernel_ms) / (sum(rank_kernel_ms) / len(rank_kernel_ms)) if min(rank_kernel_ms) > 0 else None,
                        "step_ms_rank0": stats_ms(per_step),
-                       "dispatch_plan": ({"live_bricks": st_run["plan_bricks"], "workgroups": st_run["plan_waves"], "build_ms": st_run["plan_ms"]}
-                                         if st_run.get("plan_bricks") else None),
+                       "work_queue": ({"queued_bricks": st_run["plan_bricks"], "persistent_waves": st_run["plan_waves"],
+                                       "built": "on the device inside the launch that needs it (option plan); the headline's steps keep it"}
+                                      if st_run.get("plan_bricks") else None),
                        **extras},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, **({"traffic_note": traffic_note} if traffic_note else {}),
+                         "stored_bytes_per_launch": stored_kept,
+                         "achieved_on_stored_bytes": (stored_kept + scene_bytes) / (kernel_ms * 1e-3) / 1e9,
                          "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); the kernel "
+                         "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); a step that keeps "
+                                 "its queue stores only its queued bricks (stored_bytes_per_launch; config.fresh_step stores all of it); the kernel "
                                  "is not bound by bandwidth: compulsory HBM bytes are a few per cent of what 8 TB/s moves in its "
                                  "run time (DESIGN.md section 4 names the measured limiter)"},
         }
-        if not args.no_cpu_baseline:                      # (N > 1: a shorter sample; the other ranks wait in the barrier below)
-            out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode, budget_s=15.0 if world == 1 else 6.0)
-        print(json.dumps(out), flush=True)
+    # The CPU baseline is rank 0's alone and runs AFTER the process group is gone: no rank sits in an RCCL barrier (where a watchdog
+    # bites first on a new node) while rank 0 runs the oracle for seconds.
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     vox.close()
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(vb, ib, N, mode, budget_s=15.0 if world == 1 else 6.0)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

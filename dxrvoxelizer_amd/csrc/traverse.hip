@@ -116,6 +116,7 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 //    launch's size does not depend on how many bricks are live.
 // Bricks that are not queued are zero by the launch's memset of the grid.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t kQueueNoPrefetch = 1024u;                           // slots from a queue's end on which a wave no longer asks for its next brick in advance
 constexpr uint32_t kPlanRegionBits = 8u;                               // regions of 256 consecutive bricks = one workgroup of k_plan_bricks
 // (header layout: queue_len_word / queue_head_word in dxv_device.h -- every queue's two words in a 256-byte line of its own:
 // returning atomics on ONE line serialise at ~90 per us for all eight queues together, 2.7 ms of a launch when first tried)
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t 
     const unsigned long long m = __ballot(live);
     if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
     __syncthreads();
-    // (dealing finer -- runs of 64 bricks -- or to the queue that is shortest at the moment was measured: no faster, the eight queues
-    // end within 2 % of each other as it is: profiles/r04/queue_wave_times.jsonl)
+    // (measured and dropped, profiles/r04/: dealing finer -- runs of 64 bricks -- or to the queue that is shortest at the moment: no
+    // faster, the eight queues end within 2 % of each other as it is; a second queue per XCD for the outermost shell of bricks, run
+    // last: +8 %, two streams through the grid instead of one)
     const uint32_t x = blockIdx.x & 7u;
     if (threadIdx.x == 0u) {
         const uint32_t n = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
@@ -256,14 +258,16 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ int32_t stack[16 * 64];
-    // Queue x is handed out through eight heads: head h counts the slots k = h (mod 8), so that the eight groups of an XCD's waves
+    // A queue is handed out through eight heads: head h counts the slots k = h (mod 8), so that the eight groups of an XCD's waves
     // (a wave's home head: its number among the XCD's waves mod 8) advance through the queue together, one brick per add -- the
     // bricks in flight on an XCD stay a compact window of its queue (what hardware dispatch of one workgroup per brick gave:
     // neighbouring bricks look into the same texels while they are in the caches; chunks of 8 consecutive bricks per wave
     // cost 7 %, of 16 15 %), and no head sees more than a few adds per microsecond (all bricks through ONE word: 2.7 ms).
+    // Order: the wave's own XCD's queue, then, one after the other, the other XCDs' (placement is for speed only).
     const uint32_t home = (blockIdx.x >> 3) & 7u;
 #if defined(DXV_QUEUE_TIMES)
     const uint64_t tStart = __builtin_amdgcn_s_memrealtime();
+    uint64_t tBrick = tStart, tLast = tStart, tMax = 0, nBricks = 0;
 #endif
     for (uint32_t turn = 0; turn < (p.queueSteal ? 64u : 8u); ++turn) {
         const uint32_t x = (blockIdx.x + (turn >> 3)) & 7u, h = (home + turn) & 7u;
@@ -271,20 +275,22 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
         if (len <= h) continue;
         uint32_t* head = p.queue + queue_head_word(x, h);
         // not the wave's first head: a look before the add (a load that may be stale, i.e. too small -- then the add below finds
-        // out), so that the waves of an emptied queue do not hammer 63 more heads with adds that fail
+        // out), so that the waves of an emptied queue do not hammer the other heads with adds that fail
         if (turn != 0u && 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + h >= len) continue;
         const uint32_t* slots = p.queue + kQueueHeaderWords + (size_t)x * p.queueCap;
         // One brick ahead: the add for the next brick is issued in front of the current one, and its answer is taken out of its
         // vector register as soon as the brick's first load (the rays' cells: all 64 lanes make that step together) has arrived --
         // by then it is there (memory operations return in order) -- so nothing of the queue lives in a vector register through
         // the scan and the triangle tests.
+        // (... except near a queue's end: a wave that holds a second brick there keeps it from the waves that have run out of work)
         uint32_t jv = 0;
         if (threadIdx.x == 0u) jv = atomicAdd(head, 1u);
         uint32_t next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);
         for (;;) {
             const uint32_t k = 8u * next + h;
             if (k >= len) break;
-            if (threadIdx.x == 0u) jv = atomicAdd(head, 1u);
+            const bool ahead = len - k > kQueueNoPrefetch;
+            if (ahead && threadIdx.x == 0u) jv = atomicAdd(head, 1u);
             uint32_t w;                                                 // through the scalar cache: one word per wave
             const uint32_t* slot = slots + k;
             asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
             ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
             const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
             DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
-            next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);    // the next brick's number
+            if (ahead) next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);    // the next brick's number
             if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) start.live = false;   // provably missMain
             Hit best;
             float bestDet = 1.0f;
@@ -343,11 +349,21 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
                     *reinterpret_cast<uint32_t*>(grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;   // bit i -> byte i
                 }
             }
+#if defined(DXV_QUEUE_TIMES)
+            { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tLast = tBrick; if (now - tBrick > tMax) tMax = now - tBrick; tBrick = now; ++nBricks; }
+#endif
+            if (!ahead) {
+                if (threadIdx.x == 0u) jv = atomicAdd(head, 1u);
+                next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);
+            }
         }
     }
 #if defined(DXV_QUEUE_TIMES)
     // (diagnostic build only, tools/queue_times.py: start and end of every wave in 100 MHz ticks, in the frame's unused redo list)
-    if (threadIdx.x == 0u && 2u * blockIdx.x + 1u < p.redoCap) { p.redo[2u * blockIdx.x] = tStart; p.redo[2u * blockIdx.x + 1u] = __builtin_amdgcn_s_memrealtime(); }
+    if (threadIdx.x == 0u && 4u * blockIdx.x + 3u < p.redoCap) {
+        p.redo[4u * blockIdx.x] = tStart; p.redo[4u * blockIdx.x + 1u] = __builtin_amdgcn_s_memrealtime();
+        p.redo[4u * blockIdx.x + 2u] = (nBricks << 32) | tMax; p.redo[4u * blockIdx.x + 3u] = tLast;      // bricks, longest brick, start of the last one
+    }
 #endif
 #else
     (void)p;

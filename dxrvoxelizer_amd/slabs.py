@@ -45,14 +45,20 @@ def scatter_interleaved(parts, N, world, block):
     return full
 
 
-def broadcast_scene(engine, dist, device, src=0, parity_lists=False):
+def broadcast_scene(engine, dist, device, src=0, parity_lists=False, info=None):
     """Broadcast the built scene from rank `src` to every rank of the default process group.
 
     engine: object with scene_bytes() / scene_export(ptr, n) / scene_import(ptr, n) working on
     memory of `device` (dxrvoxelizer_amd.Voxelizer for 'cuda', a host stand-in in the gloo tests).
-    dist: torch.distributed (initialised).  Returns the blob size in bytes."""
+    dist: torch.distributed (initialised).  Returns the blob size in bytes; with info (a dict) also
+    info["bytes"], info["broadcast_ms"] (this rank's wall time of the blob's broadcast, synchronised on both sides),
+    info["checksum"] (wrapping 64-bit sum of the blob's 8-byte words on this rank) and info["checksums"] (every rank's, one
+    8-byte all-gather): a rank whose blob differs from the source's raises before it imports anything.  Once per mesh."""
+    import time
+
     import torch
 
+    info = info if info is not None else {}
     rank = dist.get_rank()
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
@@ -69,10 +75,23 @@ def broadcast_scene(engine, dist, device, src=0, parity_lists=False):
         engine.scene_export(blob.data_ptr(), nbytes)
         if device != "cpu" and str(device) != "cpu":
             torch.cuda.synchronize()
+    t0 = time.perf_counter()
     dist.broadcast(blob, src=src)
+    if str(device) != "cpu":
+        torch.cuda.synchronize()
+    info["broadcast_ms"] = (time.perf_counter() - t0) * 1e3
+    info["bytes"] = nbytes
+    # what arrived is what was sent: wrapping sum of the blob's 64-bit words (its sections are 256-byte aligned), every rank's
+    # against the source's
+    words = blob[: nbytes - nbytes % 8].view(torch.int64)
+    mine = words.sum().reshape(1) if words.numel() else torch.zeros(1, dtype=torch.int64, device=device)
+    every = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    sums = [int(x.item()) & 0xFFFFFFFFFFFFFFFF for x in every]
+    info["checksum"], info["checksums"] = sums[rank], sums
+    if sums[rank] != sums[src]:
+        raise RuntimeError(f"broadcast_scene: rank {rank} received a blob whose checksum {sums[rank]:#x} differs from the source's {sums[src]:#x}")
     if rank != src:
-        if str(device) != "cpu":
-            torch.cuda.synchronize()
         engine.scene_import(blob.data_ptr(), nbytes)
     return nbytes
 

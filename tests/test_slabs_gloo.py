@@ -68,7 +68,12 @@ def _worker(rank, world, port, outdir):
     eng = HostEngine()
     if rank == 0:
         eng.set_mesh(*meshes.uv_sphere(32, 16))
-    nbytes = broadcast_scene(eng, dist, "cpu")
+    info = {}
+    nbytes = broadcast_scene(eng, dist, "cpu", info=info)
+    # the broadcast is timed and what arrived is checked against the source: one 8-byte all-gather per mesh
+    assert info["bytes"] == nbytes and info["broadcast_ms"] >= 0.0 and len(info["checksums"]) == world
+    assert len(set(info["checksums"])) == 1 and info["checksum"] == info["checksums"][0] != 0
+    assert info["checksum"] == int(eng.blob[: nbytes - nbytes % 8].view(np.uint64).sum(dtype=np.uint64))
     z0, nz = slab_range(32, rank, world)
     g = eng.voxelize(32, z0, nz)
     np.save(os.path.join(outdir, f"slab{rank}.npy"), g)

@@ -26,12 +26,15 @@ st = v.stats()
 raw = np.zeros(1 << 16, np.uint64)
 v._check(v._lib.dxv_debug_download(v._ctx, 100, raw.ctypes.data_as(C.c_void_p), raw.nbytes))
 w = st["plan_waves"]
-t = raw[:2 * w].reshape(w, 2).astype(np.int64)
+t = raw[:4 * w].reshape(w, 4).astype(np.int64)
 t0 = t[:, 0].min()
-start, end = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0          # microseconds
+start, end, last = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 3] - t0) / 100.0          # microseconds
+bricks, longest = t[:, 2] >> 32, (t[:, 2] & 0xffffffff) / 100.0
 q = [0, 1, 5, 25, 50, 75, 95, 99, 100]
+pct = lambda a: dict(zip(q, np.percentile(a, q).round(1).tolist()))                                 # noqa: E731
 print(json.dumps({"mesh": mesh, "N": N, "kernel_ms": round(st["voxelize_ms"], 4), "bricks": st["plan_bricks"], "waves": w,
-                  "start_us_pct": dict(zip(q, np.percentile(start, q).round(1).tolist())),
-                  "end_us_pct": dict(zip(q, np.percentile(end, q).round(1).tolist())),
-                  "end_by_xcd_us": [round(float(end[x::8].max()), 1) for x in range(8)],
-                  "first_end_by_xcd_us": [round(float(end[x::8].min()), 1) for x in range(8)]}))
+                  "start_us_pct": pct(start), "end_us_pct": pct(end), "bricks_per_wave_pct": pct(bricks),
+                  "longest_brick_us_pct": pct(longest), "last_brick_us_pct": pct(end - last),
+                  "mean_brick_us": round(float((end - start).sum() / max(bricks.sum(), 1)), 2),
+                  "idle_wave_us_at_end_mean": round(float((end.max() - end).mean()), 1),
+                  "end_by_xcd_us": [round(float(end[x::8].max()), 1) for x in range(8)]}))
