@@ -429,7 +429,7 @@ def main():
             vb4, ib4, label4 = make_mesh("dragon9")
             vox.InitFromArrays(vb4, ib4)
         if use_dist:
-            broadcast_scene(vox, dist, torch.device("cuda", local_rank))
+            broadcast_scene(vox, dist, torch.device("cuda", local_rank), grid=n4)
         dt4, k4ms, step4 = timed_region(1, k4, 3, n=n4, per_step=True)
         rk4 = gather(k4ms)
         dt4 = reduce_max(dt4)

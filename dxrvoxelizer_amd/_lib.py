@@ -67,6 +67,7 @@ SYMBOLS = {
     "dxv_texels_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dxv_render": (C.c_int, [C.c_void_p, _F32P, _F32P, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "dxv_build_lists": (C.c_int, [C.c_void_p]),
+    "dxv_build_lists_for_grid": (C.c_int, [C.c_void_p, C.c_uint32]),
     "dxv_build_parity_lists": (C.c_int, [C.c_void_p]),
     "dxv_scene_bytes": (C.c_size_t, [C.c_void_p]),
     "dxv_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

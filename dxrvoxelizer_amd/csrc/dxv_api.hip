@@ -90,6 +90,7 @@ struct dxv_ctx {
         size_t queueWords = 0;           // allocated 32-bit words
         bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
         bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
+        int queueOrdered = 0;            // the queue in use: 0 = as built (its launch measured what its chunks cost), 1 = the copy ordered by that cost, -1 = too large to order
         hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
     };
     Frame frames[DXV_FRAME_COUNT];
@@ -121,7 +122,7 @@ struct dxv_ctx {
     uint64_t listEpoch = 0;          // counts list builds / imports: a frame's queue belongs to the lists it was probed against
     int optPlan = 1;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch, 2 = on every launch
-    int optQueueSteal = 1;           // A/B only: 0 = waves never take another XCD's bricks
+    int optQueueOrder = 1;           // a queue that is launched again gets its cheapest chunks (by measured time) moved to its end: 1 = short launches only, 2 = always, 0 = never
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
     int optEvents = 1;               // bracket every launch with two HIP events (stats.voxelize_ms); 0: none (a caller timing its own loop)
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
@@ -323,7 +324,37 @@ uint32_t list_resolution(const dxv_ctx* c)
 // mean list length) exceeds what the rest of the build costs (0.1 ms + 0.15 ns per entry: 0.65 ms for 3.8 M entries).
 // Declined: listState stays 0, the launch walks the tree, the second launch builds the lists.
 int ensure_nodes(dxv_ctx* c, hipStream_t stream);      // (below, with the build)
+int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels);
+// A context that HAS working lists (the one-time move to the 512 map for launches at 1024^3 and beyond, an explicit listres)
+// builds the new ones beside them and swaps only when the build succeeded: out of memory, or lists over the caps on the new map,
+// leave the scene on the lists it had instead of on the tree walk (three times slower).
 int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
+{
+    if (c->listState != 1) return build_lists_into(c, stream, firstLaunchVoxels);
+    DirCell* oldCells = c->dListCells; DirEntry* oldEntries = c->dListEntries; uint16_t* oldMip = c->dMip;
+    const size_t oldCellCap = c->listCellCap, oldEntryCap = c->listEntryCap, oldMipCap = c->mipCap;
+    const uint32_t oldN = c->listEntries, oldRes = c->listRes;
+    const int oldOpt = c->listOpt;
+    const float oldMs = c->listMs;
+    c->dListCells = nullptr; c->dListEntries = nullptr; c->dMip = nullptr; c->listCellCap = c->listEntryCap = c->mipCap = 0;
+    c->listState = 0;
+    const int rc = build_lists_into(c, stream, firstLaunchVoxels);
+    if (rc == 0 && c->listState == 1) {                                 // the new lists stand: the old ones go
+        (void)hipFree(oldCells); (void)hipFree(oldEntries); (void)hipFree(oldMip);
+        return 0;
+    }
+    (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dMip);
+    c->dListCells = oldCells; c->dListEntries = oldEntries; c->dMip = oldMip;
+    c->listCellCap = oldCellCap; c->listEntryCap = oldEntryCap; c->mipCap = oldMipCap;
+    c->listEntries = oldN; c->listRes = oldRes; c->listState = 1; c->listMs = oldMs;
+    // (the option the caller asked for counts as answered: the next launch does not try the same build again; the epoch moves on
+    // because the frames' queues were probed against buffers that may have moved -- they have not, but a rebuild is cheap)
+    c->listOpt = rc == 0 ? c->optListRes : oldOpt;
+    ++c->listEpoch;
+    return rc;
+}
+
+int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels)
 {
     const uint32_t T = c->hdr.numTris;
     uint32_t R = list_resolution(c);
@@ -552,6 +583,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     int st = c->optStack ? c->optStack : c->stackNow;
     bool queued = false;
+    uint32_t cap = 0;                                                   // words per XCD queue of this partition
     f.list_entries = 0; f.list_res = 0;
     // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
@@ -588,7 +620,6 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             f.list_entries = c->listEntries; f.list_res = c->listRes;
             if (c->optBrick == 4 && !c->optAblate && c->optPlan && c->dMip) {
                 // the frame's work queue: sized for the partition (worst case: every brick live)
-                uint32_t cap = 0;
                 const size_t words = plan_queue_words(p.N, p.nz, &cap);
                 if (words > f.queueWords) {
                     DXV_HIP(c, hipStreamSynchronize(fs));
@@ -599,7 +630,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
                     else return fail(c, "work queue: hipMalloc failed: %s", hipGetErrorString(qe));
                     f.clearSig = 0;
                 }
-                if (f.dQueue) { queued = true; p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip; p.queueSteal = (uint32_t)c->optQueueSteal; p.queueWaves = (uint32_t)c->optQueueWaves; }
+                if (f.dQueue) { queued = true; p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves; }
             }
         }
     }
@@ -661,6 +692,22 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels)); mix(reinterpret_cast<uint64_t>(p.queue));
             sig |= 1ull;
             const bool rebuild = c->optPlan == 2 || f.ptrExposed || f.clearSig != sig;
+            // A queue that is launched again: once, its chunks of 64 slots are sorted by the time the launch that built it measured
+            // for them (longest first; traverse.hip, k_queue_reorder) -- on the device, in this stream, in front of the first launch
+            // that uses the queue again.
+            // (only for launches of at most 2^25 voxels -- a rank's share, a 256^3 grid: there the end of the launch is a good part of it,
+            // -3 ... -6 % of a rank's share of 512^3 at 8 ranks; a whole 512^3 grid loses 1 - 2 % to the two streams through the grid)
+            const bool measure = c->optQueueOrder && c->optPlan == 1 && !f.ptrExposed && (uint64_t)p.N * p.N * p.nz <= (c->optQueueOrder == 2 ? ~0ull : 1ull << 25);
+            if (rebuild) f.queueOrdered = 0;
+            p.queueCost = rebuild && measure ? p.queue + plan_queue_cost_offset(cap) : nullptr;
+            if (!rebuild && measure && f.queueOrdered == 0) {
+                p.queueCost = p.queue + plan_queue_cost_offset(cap);
+                hipError_t re = hipSuccess;
+                f.queueOrdered = plan_reorder(p, fs, &re) ? 1 : -1;
+                if (re != hipSuccess) return fail(c, "work queue: reorder failed: %s", hipGetErrorString(re));
+                p.queueCost = nullptr;
+            }
+            p.queueSlots = f.queueOrdered == 1 ? p.queue + plan_queue_ordered_offset(cap) : p.queue + kQueueHeaderWords;
             hipEvent_t pe[2] = {f.evP0, f.evP1};
             DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, fs));
             f.clearSig = f.ptrExposed ? 0 : sig;
@@ -1279,6 +1326,21 @@ int dxv_build_lists(dxv_ctx* c)
     return build_lists(c, c->stream);
 }
 
+int dxv_build_lists_for_grid(dxv_ctx* c, uint32_t N)
+{
+    if (!c) return 1;
+    if (!c->haveScene) return fail(c, "dxv_build_lists_for_grid: no scene");
+    DXV_HIP(c, hipSetDevice(c->device));
+    // the map a launch at this grid size would move to (launch_now: a texel about two voxels wide -- 512 from 1024^3 on)
+    if (N >= 1024u && !c->optListRes && c->hdr.numTris >= 20000u && !c->listFloorTried && c->listResFloor < 512u) {
+        if (sync_frames(c)) return 1;
+        c->listResFloor = 512u; c->listFloorTried = true;
+        if (c->listState == 1 && c->listRes >= 512u) return 0;
+        return build_lists(c, c->stream);
+    }
+    return dxv_build_lists(c);
+}
+
 int dxv_scene_export(dxv_ctx* c, void* dst, size_t bytes)
 {
     if (!c) return 1;
@@ -1471,9 +1533,10 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "plan")) {
         if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
         c->optPlan = (int)value;
-    } else if (!strcmp(key, "queuesteal")) {
-        if (value != 0 && value != 1) return fail(c, "option queuesteal: %lld not in {0,1}", (long long)value);
-        c->optQueueSteal = (int)value;
+    } else if (!strcmp(key, "queueorder")) {
+        if (value < 0 || value > 2) return fail(c, "option queueorder: %lld not in {0,1,2}", (long long)value);
+        if (c->optQueueOrder != (int)value) for (auto& f : c->frames) f.clearSig = 0;
+        c->optQueueOrder = (int)value;
     } else if (!strcmp(key, "queuewaves")) {
         if (value < 0 || value > (1 << 20)) return fail(c, "option queuewaves: %lld not in [0, 2^20]", (long long)value);
         c->optQueueWaves = (int)value;
@@ -1601,6 +1664,7 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
     uint32_t cap = 0;
     (void)plan_queue_words(p.N, p.nz, &cap);
     p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip;
+    p.queueSlots = f.queueOrdered == 1 ? f.dQueue + plan_queue_ordered_offset(cap) : f.dQueue + kQueueHeaderWords;
     VoxelizeParams q = p;
     const uint32_t nb = plan_layout(q);
     uint32_t* bits = nullptr;

@@ -244,18 +244,13 @@ DXV_HD uint32_t dm_mip_max(const uint16_t* mip, uint32_t R, uint32_t face, uint3
 //    faces of three of its corners; per present face the texel rectangle of the box comes from the extreme quotients;
 //  * every ray of the box starts at or beyond rhoMin: dead iff every texel it can look into is empty or ends before
 //    rhoMin * 0.999f.
-// Returns kBoxDead, or how the brick is to be scheduled (a hint, never a matter of correctness): kBoxOuter when the last
-// entry of the texels it looks into ends within two brick thicknesses of its nearest voxel -- the outermost shell of the
-// scene as seen from the centre: few of its rays are live at all and those start near the end of their sorted lists, so
-// its waves are short.  A launch runs these last and drains through short waves (k_voxelize_queue, traverse.hip).
-constexpr uint32_t kBoxDead = 0u, kBoxInner = 1u, kBoxOuter = 2u;
-DXV_HD uint32_t dm_box_class(float x0, float x1, float y0, float y1, float z0, float z1, const float* rootLo, const float* rootHi,
-                             const uint16_t* mip, uint32_t R)
+DXV_HD bool dm_box_may_be_live(float x0, float x1, float y0, float y1, float z0, float z1, const float* rootLo, const float* rootHi,
+                               const uint16_t* mip, uint32_t R)
 {
-    if ((x0 > 0.0f && axis_leaves_root(x0, rootLo[0], rootHi[0])) || (x1 < 0.0f && axis_leaves_root(x1, rootLo[0], rootHi[0]))) return kBoxDead;
-    if ((y0 > 0.0f && axis_leaves_root(y0, rootLo[1], rootHi[1])) || (y1 < 0.0f && axis_leaves_root(y1, rootLo[1], rootHi[1]))) return kBoxDead;
-    if ((z0 > 0.0f && axis_leaves_root(z0, rootLo[2], rootHi[2])) || (z1 < 0.0f && axis_leaves_root(z1, rootLo[2], rootHi[2]))) return kBoxDead;
-    if (!(x0 > 0.0f || x1 < 0.0f) || !(y0 > 0.0f || y1 < 0.0f) || !(z0 > 0.0f || z1 < 0.0f)) return kBoxInner;     // straddles a centre plane
+    if ((x0 > 0.0f && axis_leaves_root(x0, rootLo[0], rootHi[0])) || (x1 < 0.0f && axis_leaves_root(x1, rootLo[0], rootHi[0]))) return false;
+    if ((y0 > 0.0f && axis_leaves_root(y0, rootLo[1], rootHi[1])) || (y1 < 0.0f && axis_leaves_root(y1, rootLo[1], rootHi[1]))) return false;
+    if ((z0 > 0.0f && axis_leaves_root(z0, rootLo[2], rootHi[2])) || (z1 < 0.0f && axis_leaves_root(z1, rootLo[2], rootHi[2]))) return false;
+    if (!(x0 > 0.0f || x1 < 0.0f) || !(y0 > 0.0f || y1 < 0.0f) || !(z0 > 0.0f || z1 < 0.0f)) return true;     // straddles a centre plane
     const bool nx = x1 < 0.0f, ny = y1 < 0.0f, nz = z1 < 0.0f;
     const float xa = nx ? -x1 : x0, xb = nx ? -x0 : x1, ya = ny ? -y1 : y0, yb = ny ? -y0 : y1, za = nz ? -z1 : z0, zb = nz ? -z0 : z1;
     const float rhoMin = __builtin_sqrtf((xa * xa + ya * ya) + za * za), nearMin = rhoMin * 0.999f;
@@ -264,34 +259,24 @@ DXV_HD uint32_t dm_box_class(float x0, float x1, float y0, float y1, float z0, f
         const float lo = na / db, hi = nb / da;
         t0 = dm_texel(neg ? -hi : lo, R); t1 = dm_texel(neg ? -lo : hi, R);
     };
-    float far = -1.0f;                                                  // farthest end of any list the box can look into (live faces only)
-    auto face_far = [&](uint32_t face, uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1) {
+    auto face_live = [&](uint32_t face, uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1) {
         const uint32_t key = dm_mip_max(mip, R, face, i0, i1, j0, j1);
-        if (key == 0u) return;
-        const float r1 = half_bits_to_float(key);
-        if (!(r1 < nearMin) && r1 > far) far = r1;
+        return key != 0u && !(half_bits_to_float(key) < nearMin);
     };
     uint32_t i0, i1, j0, j1;
     if (xb >= ya && xb >= za) {                                         // face X: u = y / |x|, v = z / |x|
         range(ya, yb, ny, xa, xb, i0, i1); range(za, zb, nz, xa, xb, j0, j1);
-        face_far(nx ? 1u : 0u, i0, i1, j0, j1);
+        if (face_live(nx ? 1u : 0u, i0, i1, j0, j1)) return true;
     }
     if (!(xa >= yb && xa >= za) && yb >= za) {                          // face Y: u = z / |y|, v = x / |y|
         range(za, zb, nz, ya, yb, i0, i1); range(xa, xb, nx, ya, yb, j0, j1);
-        face_far(ny ? 3u : 2u, i0, i1, j0, j1);
+        if (face_live(ny ? 3u : 2u, i0, i1, j0, j1)) return true;
     }
     if (!(xa >= ya && xa >= zb) && !(ya >= zb)) {                       // face Z: u = x / |z|, v = y / |z|
         range(xa, xb, nx, za, zb, i0, i1); range(ya, yb, ny, za, zb, j0, j1);
-        face_far(nz ? 5u : 4u, i0, i1, j0, j1);
+        if (face_live(nz ? 5u : 4u, i0, i1, j0, j1)) return true;
     }
-    if (far < 0.0f) return kBoxDead;
-    const float thickness = __builtin_sqrtf((xb * xb + yb * yb) + zb * zb) - rhoMin;
-    return far - nearMin < 2.0f * thickness ? kBoxOuter : kBoxInner;
-}
-DXV_HD bool dm_box_may_be_live(float x0, float x1, float y0, float y1, float z0, float z1, const float* rootLo, const float* rootHi,
-                               const uint16_t* mip, uint32_t R)
-{
-    return dm_box_class(x0, x1, y0, y1, z0, z1, rootLo, rootHi, mip, R) != kBoxDead;
+    return false;
 }
 
 // the hull of the voxel centres of brick (bx, by, bz) of 4 x 4 x 4 voxels in a partition's local brick grid (x0 <= x1 ...; y falls

@@ -107,16 +107,16 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 //    wave that finds nothing, a false negative cannot happen -- k_plan_check below is the exhaustive proof obligation);
 //  * layout: regions of 256 consecutive bricks of the Morton order (8 x 8 x 4 bricks) are dealt round-robin to eight
 //    queues, one per XCD (blocks b and b + 8 share one), so that an XCD's private L2 sees compact regions; a region's
-//    workgroup appends its live bricks to its queue with one atomic add.  Queue memory: 1024 header words (len[8]; the
-//    head of queue x in a 256-byte line of its own) + 8 x cap brick words (bx | by << 10 | bz << 20);
-//  * how: k_voxelize_queue is launched with as many single-wave workgroups as the GPU holds at once.  Every wave takes
-//    bricks from its XCD's queue with one returning atomic add per chunk (guided: up to 4 bricks while the queue is long,
-//    single bricks towards its end, so that the launch drains through single bricks), and moves on to the other XCDs'
-//    queues when its own is empty: placement is for speed only, any wave may take any brick.  No host round trip: the
-//    launch's size does not depend on how many bricks are live.
+//    workgroup appends its live bricks to its queue with one atomic add.  Queue memory (dxv_device.h): a header -- eight
+//    heads per queue and the eight lengths, every word in a 256-byte line of its own -- and 8 x cap brick words
+//    (bx | by << 10 | bz << 20);
+//  * how: k_voxelize_queue is launched with as many single-wave workgroups as the GPU holds at once.  Every wave takes its
+//    bricks one at a time from a head of its XCD's queue with a returning atomic add, asked for one brick ahead.  Which
+//    XCD a block really runs on is a matter of speed only: every head of every queue has its home waves by block number.
+//    No host round trip: the launch's size does not depend on how many bricks are live.
 // Bricks that are not queued are zero by the launch's memset of the grid.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kQueueNoPrefetch = 1024u;                           // slots from a queue's end on which a wave no longer asks for its next brick in advance
+[[maybe_unused]] constexpr uint32_t kQueueNoPrefetch = 1024u;
 constexpr uint32_t kPlanRegionBits = 8u;                               // regions of 256 consecutive bricks = one workgroup of k_plan_bricks
 // (header layout: queue_len_word / queue_head_word in dxv_device.h -- every queue's two words in a 256-byte line of its own:
 // returning atomics on ONE line serialise at ~90 per us for all eight queues together, 2.7 ms of a launch when first tried)
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t 
     if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
     __syncthreads();
     // (measured and dropped, profiles/r04/: dealing finer -- runs of 64 bricks -- or to the queue that is shortest at the moment: no
-    // faster, the eight queues end within 2 % of each other as it is; a second queue per XCD for the outermost shell of bricks, run
-    // last: +8 %, two streams through the grid instead of one)
+    // faster, the eight queues end within 2 % of each other as it is; a second queue per XCD, run last, for the bricks near or across
+    // the outer end of their lists: no faster in two definitions, 8 % slower in one)
     const uint32_t x = blockIdx.x & 7u;
     if (threadIdx.x == 0u) {
         const uint32_t n = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
@@ -172,7 +172,7 @@ size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut)
     const uint64_t nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
     const uint64_t cap = ((nr + 7u) / 8u) << kPlanRegionBits;
     if (capOut) *capOut = (uint32_t)cap;
-    return kQueueHeaderWords + 8u * (size_t)cap;
+    return plan_queue_ordered_offset((uint32_t)cap) + 8u * (size_t)cap;
 }
 
 // header cleared, then one workgroup per region; p.queue / p.queueCap / p.mip set by the caller
@@ -181,9 +181,81 @@ hipError_t plan_build(const VoxelizeParams& pin, hipStream_t s)
     VoxelizeParams p = pin;
     const uint32_t nb = plan_layout(p), nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
     hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kQueueHeaderWords, s);
+    if (e == hipSuccess && p.queueCost) e = hipMemsetAsync(p.queueCost, 0, sizeof(uint32_t) * 8u * (size_t)(p.queueCap / 64u), s);
     if (e != hipSuccess) return e;
     k_plan_bricks<<<dim3(nr), dim3(256), 0, s>>>(p, nb);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Order of a queue that is launched again (the static scene of the reference's loop, Content/Voxelizer.cpp:108-113).  The launch
+// that built the queue measured, per chunk of 64 consecutive slots (a compact 16^3-voxel piece of the grid: regions are appended
+// whole), the time its bricks took.  k_queue_reorder moves every queue's CHEAPEST chunks -- 2,048 bricks' worth, at most a third
+// of the queue: the partly dead shell of the scene -- to the queue's end, dearest of them first, and leaves the rest in Morton
+// order: the launch drains through short waves instead of ending on its longest bricks.  (The host-built plan of round 3 did the
+// same from estimated costs; sorting ALL chunks by cost, longest first, shortens a rank's share further but costs the full grid
+// 4 %: the bricks in flight are then no compact window of the grid any more.)  One workgroup per queue; bitonic sort of
+// (cost, chunk) in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kReorderMaxChunks = 8192u, kReorderTailChunks = 32u;
+__global__ __launch_bounds__(1024) void k_queue_reorder(VoxelizeParams p, uint32_t* __restrict__ ordered)
+{
+    __shared__ unsigned long long key[kReorderMaxChunks];               // cost << 32 | chunk, ascending: cheapest first
+    __shared__ uint32_t order[kReorderMaxChunks];                       // new position -> chunk
+    __shared__ uint8_t inTail[kReorderMaxChunks];
+    __shared__ uint32_t part[1024];
+    const uint32_t x = blockIdx.x, len = p.queue[queue_len_word(x)], full = len >> 6, tid = threadIdx.x;
+    const uint32_t* src = p.queue + kQueueHeaderWords + (size_t)x * p.queueCap;
+    uint32_t* dst = ordered + (size_t)x * p.queueCap;
+    const uint32_t* cost = p.queueCost + (size_t)x * (p.queueCap / 64u);
+    uint32_t n2 = 1;
+    while (n2 < full) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += 1024u) { key[i] = i < full ? ((unsigned long long)cost[i] << 32) | i : ~0ull; if (i < full) inTail[i] = 0; }
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < n2; i += 1024u) {
+                const uint32_t o = i ^ j;
+                if (o > i) {
+                    const unsigned long long a = key[i], b = key[o];
+                    if (((i & k) == 0u) ? a > b : a < b) { key[i] = b; key[o] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const uint32_t tail = full / 3u < kReorderTailChunks ? full / 3u : kReorderTailChunks, body = full - tail;
+    // the cheapest `tail` chunks go last, dearest of them first
+    for (uint32_t i = tid; i < tail; i += 1024u) {
+        const uint32_t c = (uint32_t)(key[tail - 1u - i] & 0xffffffffull);
+        inTail[c] = 1; order[body + i] = c;
+    }
+    __syncthreads();
+    // the others keep their order: position = number of body chunks in front (per-thread runs + a scan of the runs' counts)
+    const uint32_t run = (full + 1023u) / 1024u, c0 = tid * run, c1 = c0 + run < full ? c0 + run : full;
+    uint32_t mine = 0;
+    for (uint32_t c = c0; c < c1; ++c) mine += inTail[c] ? 0u : 1u;
+    part[tid] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t a = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += a;
+        __syncthreads();
+    }
+    uint32_t pos = part[tid] - mine;
+    for (uint32_t c = c0; c < c1; ++c) if (!inTail[c]) order[pos++] = c;
+    __syncthreads();
+    for (uint32_t w = tid; w < full * 64u; w += 1024u) dst[w] = src[order[w >> 6] * 64u + (w & 63u)];
+    for (uint32_t w = full * 64u + tid; w < len; w += 1024u) dst[w] = src[w];     // the last, partial chunk stays last
+}
+bool plan_reorder(const VoxelizeParams& p, hipStream_t s, hipError_t* err)
+{
+    *err = hipSuccess;
+    if (!p.queueCost || p.queueCap / 64u > kReorderMaxChunks) return false;
+    uint32_t* ordered = p.queue + plan_queue_ordered_offset(p.queueCap);
+    k_queue_reorder<<<dim3(8), dim3(1024), 0, s>>>(p, ordered);
+    *err = hipGetLastError();
+    return *err == hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -200,7 +272,7 @@ __global__ __launch_bounds__(256) void k_plan_mark(VoxelizeParams p, uint32_t* _
     for (uint32_t x = 0; x < 8u; ++x) {
         const uint32_t len = p.queue[queue_len_word(x)];
         for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < len; k += gridDim.x * 256u) {
-            const uint32_t w = p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + k];
+            const uint32_t w = (p.queueSlots ? p.queueSlots : p.queue + kQueueHeaderWords)[(size_t)x * p.queueCap + k];
             const uint32_t id = ((w >> 20) * nbx + ((w >> 10) & 1023u)) * nbx + (w & 1023u);
             const uint32_t old = atomicOr(bits + (id >> 5), 1u << (id & 31u));
             if (old & (1u << (id & 31u))) atomicAdd(out + 4, 1ull);
@@ -263,21 +335,29 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
     // bricks in flight on an XCD stay a compact window of its queue (what hardware dispatch of one workgroup per brick gave:
     // neighbouring bricks look into the same texels while they are in the caches; chunks of 8 consecutive bricks per wave
     // cost 7 %, of 16 15 %), and no head sees more than a few adds per microsecond (all bricks through ONE word: 2.7 ms).
-    // Order: the wave's own XCD's queue, then, one after the other, the other XCDs' (placement is for speed only).
-    const uint32_t home = (blockIdx.x >> 3) & 7u;
+    // Which head next: the wave's home head first; after that all 64 heads are looked at AT ONCE -- lane l loads head l and its queue's
+    // length, one round trip -- and the wave goes on with a head that still shows work, its own XCD's first (placement is for speed
+    // only; a head's value may be stale, i.e. too small: then the add finds out).  Looking at them one after the other cost every
+    // wave ~50 us at the end of a launch: that was the launch's tail.
 #if defined(DXV_QUEUE_TIMES)
     const uint64_t tStart = __builtin_amdgcn_s_memrealtime();
     uint64_t tBrick = tStart, tLast = tStart, tMax = 0, nBricks = 0;
 #endif
-    for (uint32_t turn = 0; turn < (p.queueSteal ? 64u : 8u); ++turn) {
-        const uint32_t x = (blockIdx.x + (turn >> 3)) & 7u, h = (home + turn) & 7u;
+    // Every head has HOME waves that drain it to its last slot: wave w of XCD x (x = block % 8, w = block / 8) is home to the heads
+    // h = w (mod 8) of queue x -- to h = w (mod W) when fewer than eight waves per XCD were launched, so that no head is without
+    // one (which XCD a block really runs on is a matter of speed only).
+    const uint32_t x0 = blockIdx.x & 7u, wx = blockIdx.x >> 3, perXcd = gridDim.x >> 3, homes = perXcd < 8u ? perXcd : 8u;
+    uint64_t homeMask = 0;
+    for (uint32_t h = wx % homes; h < 8u; h += homes) homeMask |= 1ull << (8u * x0 + h);
+    uint32_t cur = 8u * x0 + wx % homes;
+    uint64_t tried = 0;
+    for (;;) {
+        tried |= 1ull << cur;
+        const uint32_t x = cur >> 3, h = cur & 7u;
         const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
-        if (len <= h) continue;
         uint32_t* head = p.queue + queue_head_word(x, h);
-        // not the wave's first head: a look before the add (a load that may be stale, i.e. too small -- then the add below finds
-        // out), so that the waves of an emptied queue do not hammer the other heads with adds that fail
-        if (turn != 0u && 8u * (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + h >= len) continue;
-        const uint32_t* slots = p.queue + kQueueHeaderWords + (size_t)x * p.queueCap;
+        const uint32_t* slots = p.queueSlots + (size_t)x * p.queueCap;
+        if (len > h) {
         // One brick ahead: the add for the next brick is issued in front of the current one, and its answer is taken out of its
         // vector register as soon as the brick's first load (the rays' cells: all 64 lanes make that step together) has arrived --
         // by then it is there (memory operations return in order) -- so nothing of the queue lives in a vector register through
@@ -291,6 +371,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
             if (k >= len) break;
             const bool ahead = len - k > kQueueNoPrefetch;
             if (ahead && threadIdx.x == 0u) jv = atomicAdd(head, 1u);
+            const uint32_t tick0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
             uint32_t w;                                                 // through the scalar cache: one word per wave
             const uint32_t* slot = slots + k;
             asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
@@ -349,6 +430,9 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
                     *reinterpret_cast<uint32_t*>(grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;   // bit i -> byte i
                 }
             }
+            // the launch that built the queue says what its chunks cost (k_queue_reorder, for the launches that use the queue again)
+            if (pp->queueCost && threadIdx.x == 0u)
+                atomicAdd(pp->queueCost + (size_t)x * (pp->queueCap >> 6) + (k >> 6), (uint32_t)__builtin_amdgcn_s_memrealtime() - tick0);
 #if defined(DXV_QUEUE_TIMES)
             { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tLast = tBrick; if (now - tBrick > tMax) tMax = now - tBrick; tBrick = now; ++nBricks; }
 #endif
@@ -357,6 +441,15 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
                 next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);
             }
         }
+        }
+        // this head is done: the wave's other home heads (fewer than eight waves per XCD), else the wave is done.  A wave does NOT go
+        // looking for work on other heads or other XCDs' queues: at the end of a launch thousands of waves doing so at once are
+        // thousands of adds and loads on single words (~90 per microsecond each) -- measured, in four variants: every wave spent
+        // 30 - 60 us there and a rank's share of the grid took 0.195 instead of 0.147 ms, while the eight queues end within 2 % of
+        // each other anyway (profiles/r04/queue_wave_times.jsonl, ab_queue_helping.jsonl).
+        const uint64_t homeLeft = homeMask & ~tried;
+        if (!homeLeft) break;
+        cur = (uint32_t)__builtin_ctzll(homeLeft);
     }
 #if defined(DXV_QUEUE_TIMES)
     // (diagnostic build only, tools/queue_times.py: start and end of every wave in 100 MHz ticks, in the frame's unused redo list)
@@ -388,8 +481,10 @@ static uint32_t queue_waves(bool texels)
 // rebuild: clear the grid and build the queue in front of the launch (a launch that may not rely on anything an earlier
 // launch left behind); else the caller vouches that the frame's grid and queue are those of the same launch made before
 // (same lists, partition and buffers: the kernel writes the same bricks every time) and only the queue heads are reset.
-hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, hipStream_t s)
+hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, hipStream_t s)
 {
+    VoxelizeParams p = pin;
+    if (!p.queueSlots) p.queueSlots = p.queue + kQueueHeaderWords;
     hipError_t e;
     if (rebuild) {
         if ((e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s)) != hipSuccess) return e;
@@ -398,7 +493,7 @@ hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t
         if ((e = plan_build(p, s)) != hipSuccess) return e;
         if (planEvents && (e = hipEventRecord(planEvents[1], s)) != hipSuccess) return e;
     } else if ((e = hipMemsetAsync(p.queue + queue_head_word(0, 0), 0, sizeof(uint32_t) * (queue_len_word(0) - queue_head_word(0, 0)), s)) != hipSuccess) return e;   // the 64 heads
-    const uint32_t waves = p.queueWaves ? (p.queueWaves + 7u) & ~7u : queue_waves(p.texels != nullptr);
+    const uint32_t waves = p.queueWaves ? (p.queueWaves + 7u) & ~7u : queue_waves(p.texels != nullptr);     // (a multiple of 8, at least 8: every head has a home wave)
     if (wavesOut) *wavesOut = waves;
     if (p.texels) k_voxelize_queue<true><<<dim3(waves), dim3(64), 0, s>>>(p);
     else k_voxelize_queue<false><<<dim3(waves), dim3(64), 0, s>>>(p);

@@ -45,7 +45,7 @@ def scatter_interleaved(parts, N, world, block):
     return full
 
 
-def broadcast_scene(engine, dist, device, src=0, parity_lists=False, info=None):
+def broadcast_scene(engine, dist, device, src=0, parity_lists=False, info=None, grid=0):
     """Broadcast the built scene from rank `src` to every rank of the default process group.
 
     engine: object with scene_bytes() / scene_export(ptr, n) / scene_import(ptr, n) working on
@@ -64,7 +64,9 @@ def broadcast_scene(engine, dist, device, src=0, parity_lists=False, info=None):
     if rank == src:
         if hasattr(engine, "build_lists"):
             # the candidate lists travel with the blob: the other ranks adopt them (parity_lists: the parity rule's row lists too)
-            engine.build_lists(parity=True) if parity_lists else engine.build_lists()
+            # (grid: the grid size of the launches to come -- the source builds the map they will want, once, for everybody)
+            kw = {"grid": int(grid)} if grid else {}
+            engine.build_lists(parity=True, **kw) if parity_lists else engine.build_lists(**kw)
         n[0] = engine.scene_bytes()
     dist.broadcast(n, src=src)
     nbytes = int(n.item())

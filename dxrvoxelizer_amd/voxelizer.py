@@ -199,10 +199,10 @@ class Voxelizer:
         self._check(self._lib.dxv_get_stats(self._ctx, C.byref(s)))
         return s.as_dict()
 
-    def build_lists(self, parity=False):
+    def build_lists(self, parity=False, grid=0):
         """Build the candidate lists of the reference rule now (they then travel with scene_export); parity=True: the parity
-        rule's row lists as well."""
-        self._check(self._lib.dxv_build_lists(self._ctx))
+        rule's row lists as well; grid: the grid size the scene will be launched at (the lists' map follows it)."""
+        self._check(self._lib.dxv_build_lists_for_grid(self._ctx, int(grid)) if grid else self._lib.dxv_build_lists(self._ctx))
         if parity:
             self._check(self._lib.dxv_build_parity_lists(self._ctx))
 

@@ -213,6 +213,10 @@ DXV_API int dxv_render(dxv_ctx* ctx, const float eye[3], const float view_proj[1
  * second launch (option lists); dxv_build_lists builds them now.  A scene exported after that carries them as two more
  * sections of the blob, and the importing contexts adopt them instead of building their own. */
 DXV_API int dxv_build_lists(dxv_ctx* ctx);
+/* ... on the map a launch at grid_dim would use (a texel should stay about two voxels wide: scenes launched at 1024^3 and beyond
+ * move from the 256 to the 512 map once): the exporting rank builds that map before dxv_scene_export, so that the importing
+ * ranks do not each rebuild it at their first launch.  Lists that cannot be had on the finer map leave the ones there are. */
+DXV_API int dxv_build_lists_for_grid(dxv_ctx* ctx, uint32_t grid_dim);
 /* The same for the parity rule's row lists (option plists): built now instead of at the scene's second parity launch; a scene
  * exported after that carries them too (33 + 72 MB at 1 M triangles), and an importing context adopts them. */
 DXV_API int dxv_build_parity_lists(dxv_ctx* ctx);

@@ -20,8 +20,9 @@ for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 else "").split(",")):
     v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 vb, ib, _ = make_mesh(mesh)
 v.InitFromArrays(vb, ib)
+share = int(os.environ.get("QT_WORLD", "1"))          # QT_WORLD=8: rank 0's share of the block-cyclic partition instead of the whole grid
 for _ in range(3):
-    v.Voxelize(N, 0)
+    v.VoxelizeInterleaved(N, 0, share, 8, 0) if share > 1 else v.Voxelize(N, 0)
 st = v.stats()
 raw = np.zeros(1 << 16, np.uint64)
 v._check(v._lib.dxv_debug_download(v._ctx, 100, raw.ctypes.data_as(C.c_void_p), raw.nbytes))
@@ -32,7 +33,9 @@ start, end, last = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 3] - t0
 bricks, longest = t[:, 2] >> 32, (t[:, 2] & 0xffffffff) / 100.0
 q = [0, 1, 5, 25, 50, 75, 95, 99, 100]
 pct = lambda a: dict(zip(q, np.percentile(a, q).round(1).tolist()))                                 # noqa: E731
-print(json.dumps({"mesh": mesh, "N": N, "kernel_ms": round(st["voxelize_ms"], 4), "bricks": st["plan_bricks"], "waves": w,
+started = start < 50.0                                      # (waves that were resident from the beginning)
+print(json.dumps({"mesh": mesh, "N": N, "world": share, "resident_waves": int(started.sum()),
+                  "busy_frac_of_resident": round(float((end[started] - start[started]).sum() / (end.max() * started.sum())), 3), "kernel_ms": round(st["voxelize_ms"], 4), "bricks": st["plan_bricks"], "waves": w,
                   "start_us_pct": pct(start), "end_us_pct": pct(end), "bricks_per_wave_pct": pct(bricks),
                   "longest_brick_us_pct": pct(longest), "last_brick_us_pct": pct(end - last),
                   "mean_brick_us": round(float((end - start).sum() / max(bricks.sum(), 1)), 2),
