@@ -72,6 +72,7 @@ SYMBOLS = {
     "dxv_scene_bytes": (C.c_size_t, [C.c_void_p]),
     "dxv_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dxv_scene_import": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dxv_scene_checksum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "dxv_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "dxv_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "dxv_debug_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),

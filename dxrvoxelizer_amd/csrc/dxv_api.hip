@@ -1371,6 +1371,19 @@ int dxv_scene_export(dxv_ctx* c, void* dst, size_t bytes)
     return 0;
 }
 
+int dxv_scene_checksum(dxv_ctx* c, const void* device_blob, size_t bytes, uint64_t* sum)
+{
+    if (!c || !sum) return 1;
+    if (!device_blob || bytes < 8) return fail(c, "dxv_scene_checksum: no blob");
+    DXV_HIP(c, hipSetDevice(c->device));
+    DXV_HIP(c, launch_checksum(device_blob, bytes, c->dCount, c->stream));
+    unsigned long long v = 0;
+    DXV_HIP(c, hipMemcpyAsync(&v, c->dCount, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    DXV_HIP(c, hipStreamSynchronize(c->stream));
+    *sum = v;
+    return 0;
+}
+
 int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
 {
     if (!c) return 1;

@@ -126,6 +126,7 @@ hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t
 hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);   // test hook: superset claim of the lists (slices [p.z0, p.z0 + p.nz))
 hipError_t launch_class_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);  // test hook: per-triangle class of the normal test against the predicate
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
+hipError_t launch_checksum(const void* buf, size_t bytes, unsigned long long* out, hipStream_t s);   // wrapping sum of the buffer's 64-bit words
 hipError_t launch_pack_bits(const uint8_t* grid, size_t n, uint8_t* packed, hipStream_t s);
 int num_brick_shapes();
 

@@ -1121,6 +1121,25 @@ hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEnt
     }
 }
 
+// Wrapping 64-bit sum of the 8-byte words of a device buffer (dxv_scene_checksum: what arrived after a broadcast is what was sent)
+__global__ __launch_bounds__(256) void k_checksum(const unsigned long long* __restrict__ words, size_t n, unsigned long long* out)
+{
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += words[i];
+    for (int off = 32; off; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, c);
+}
+hipError_t launch_checksum(const void* buf, size_t bytes, unsigned long long* out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    const size_t n = bytes / 8;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks) k_checksum<<<(uint32_t)blocks, 256, 0, s>>>(static_cast<const unsigned long long*>(buf), n, out);
+    return hipGetLastError();
+}
+
 // Solid-voxel count: 16 B per lane streaming reduction, one atomic per workgroup.
 __global__ __launch_bounds__(256) void k_count(const uint8_t* __restrict__ grid, size_t n, unsigned long long* out)
 {

@@ -223,6 +223,9 @@ DXV_API int dxv_build_parity_lists(dxv_ctx* ctx);
 DXV_API size_t dxv_scene_bytes(const dxv_ctx* ctx);
 DXV_API int dxv_scene_export(dxv_ctx* ctx, void* device_dst, size_t bytes);
 DXV_API int dxv_scene_import(dxv_ctx* ctx, const void* device_src, size_t bytes);
+/* Wrapping 64-bit sum of the 8-byte words of a blob in DEVICE memory of this context's GPU: a host that moves blobs between GPUs
+ * compares the receivers' sums with the sender's before it imports anything (once per mesh; include/dxv_multi.hpp, slabs.py). */
+DXV_API int dxv_scene_checksum(dxv_ctx* ctx, const void* device_blob, size_t bytes, uint64_t* sum);
 
 DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
 

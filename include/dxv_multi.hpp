@@ -20,6 +20,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -57,7 +58,8 @@ public:
 		if (m_devices.empty()) return setError("empty device set");
 		if (!m_ready && !create()) return false;
 		dxv_ctx* root = m_ctx[0];
-		if (dxv_set_mesh(root, vb, numVerts, ib, numTris) || dxv_build(root) || dxv_build_lists(root)) return ctxError(0);
+		if (dxv_set_mesh(root, vb, numVerts, ib, numTris) || dxv_build(root) ||
+			(m_gridHint ? dxv_build_lists_for_grid(root, m_gridHint) : dxv_build_lists(root))) return ctxError(0);
 		const size_t bytes = dxv_scene_bytes(root);
 		if (!bytes) return setError("no scene to broadcast");
 		// one blob buffer per device; the root exports into its own
@@ -70,15 +72,23 @@ public:
 			m_blobBytes[i] = bytes;
 		}
 		if (dxv_scene_export(root, m_blob[0], bytes)) return ctxError(0);
-		// the only collective of the whole path, once per mesh
+		// the only collective of the whole path, once per mesh (timed: host clock from the group call to the last stream's end)
+		const auto t0 = std::chrono::steady_clock::now();
 		if (!ncclOk(ncclGroupStart(), "ncclGroupStart")) return false;
 		for (size_t i = 0; i < m_devices.size(); ++i)
 			if (!ncclOk(ncclBroadcast(m_blob[0], m_blob[i], bytes, ncclUint8, 0, m_comm[i], m_stream[i]), "ncclBroadcast")) { (void)ncclGroupEnd(); return false; }
 		if (!ncclOk(ncclGroupEnd(), "ncclGroupEnd")) return false;
-		for (size_t i = 0; i < m_devices.size(); ++i) {
+		for (size_t i = 0; i < m_devices.size(); ++i)
 			if (!hipOk(hipSetDevice(m_devices[i]), "hipSetDevice") || !hipOk(hipStreamSynchronize(m_stream[i]), "hipStreamSynchronize")) return false;
-			if (i && dxv_scene_import(m_ctx[i], m_blob[i], bytes)) return ctxError(i);
-		}
+		m_broadcastMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		// what arrived is what was sent: every device sums its copy, nobody imports a blob that differs from the root's
+		m_checksums.assign(m_devices.size(), 0);
+		for (size_t i = 0; i < m_devices.size(); ++i)
+			if (dxv_scene_checksum(m_ctx[i], m_blob[i], bytes, &m_checksums[i])) return ctxError(i);
+		for (size_t i = 1; i < m_devices.size(); ++i)
+			if (m_checksums[i] != m_checksums[0]) return setError(("device " + std::to_string(m_devices[i]) + ": the broadcast blob's checksum differs from the root's").c_str());
+		for (size_t i = 1; i < m_devices.size(); ++i)
+			if (dxv_scene_import(m_ctx[i], m_blob[i], bytes)) return ctxError(i);
 		m_sceneBytes = bytes;
 		return true;
 	}
@@ -123,10 +133,8 @@ public:
 			if (dxv_grid_download(m_ctx[g], part.data(), part.size())) return ctxError(g);
 			if (!m_cyclic) { memcpy(grid.data() + plane * m_z0[g], part.data(), part.size()); continue; }
 			const uint32_t nzLocal = N / G;
-			for (uint32_t lz = 0; lz < nzLocal; ++lz) {			// local slice -> global slice (dxv.h, dxv_voxelize_interleaved)
-				const uint32_t z = (lz / m_zblock * G + g) * m_zblock + lz % m_zblock;
-				memcpy(grid.data() + plane * z, part.data() + plane * lz, plane);
-			}
+			for (uint32_t lz = 0; lz < nzLocal; ++lz)			// local slice -> global slice (dxv.h, dxv_voxelize_interleaved)
+				memcpy(grid.data() + plane * GlobalSlice(lz, g, G, m_zblock), part.data() + plane * lz, plane);
 		}
 		return true;
 	}
@@ -150,6 +158,13 @@ public:
 		return true;
 	}
 	bool GetStats(size_t device, dxv_stats& s) const { return device < m_ctx.size() && dxv_get_stats(m_ctx[device], &s) == 0; }
+	// the grid size the scene will be launched at (before Init): the root builds the lists' map those launches want (dxv.h,
+	// dxv_build_lists_for_grid), so that the other devices do not each rebuild it
+	void SetGridHint(uint32_t gridDim) { m_gridHint = gridDim; }
+	double BroadcastMs() const { return m_broadcastMs; }				// the scene broadcast of the last Init, host clock
+	uint64_t SceneChecksum() const { return m_checksums.empty() ? 0 : m_checksums[0]; }	// ... and the blob's checksum (equal on every device, or Init failed)
+	// global slice of local slice lz of share g in the block-cyclic partition (blocks of zblock slices dealt round-robin over G shares)
+	static uint32_t GlobalSlice(uint32_t lz, uint32_t g, uint32_t G, uint32_t zblock) { return (lz / zblock * G + g) * zblock + lz % zblock; }
 	size_t DeviceCount() const { return m_devices.size(); }
 	size_t SceneBytes() const { return m_sceneBytes; }
 	const char* LastError() const { return m_err.c_str(); }
@@ -201,6 +216,9 @@ protected:
 	std::vector<void*>			m_blob;
 	std::vector<size_t>			m_blobBytes;
 	std::vector<uint32_t>		m_z0, m_nz;
+	std::vector<uint64_t>		m_checksums;
+	double						m_broadcastMs = 0.0;
+	uint32_t					m_gridHint = 0;
 	size_t						m_sceneBytes = 0;
 	uint32_t					m_gridDim = 0, m_zblock = 8;
 	bool						m_cyclic = false, m_ready = false;

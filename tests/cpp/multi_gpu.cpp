@@ -44,6 +44,23 @@ int main(int argc, char** argv)
 	if (!o) return 1;
 	fwrite(cyclic.data(), 1, cyclic.size(), o);
 	fclose(o);
-	printf("%llu %zu %zu\n", static_cast<unsigned long long>(solidCyclic), vox.DeviceCount(), vox.SceneBytes());
+	// the partition arithmetic of EIGHT shares, played by the first context alone (a box with one GPU cannot hold eight contexts'
+	// worth of devices, but the index arithmetic is the shares'): blocks of 4 slices dealt round-robin, what bench.py --gpus 8 runs
+	if (argc > 5) {
+		struct Probe : MultiVoxelizer { using MultiVoxelizer::MultiVoxelizer; dxv_ctx* first() { return m_ctx[0]; } } ;
+		const uint32_t G = 8, zb = 4;
+		if (N % (G * zb) == 0) {
+			dxv_ctx* ctx = static_cast<Probe&>(vox).first();
+			std::vector<uint8_t> whole(static_cast<size_t>(N) * N * N), part(static_cast<size_t>(N) * N * (N / G));
+			const size_t plane = static_cast<size_t>(N) * N;
+			for (uint32_t g = 0; g < G; ++g) {
+				if (dxv_voxelize_interleaved(ctx, N, DXV_MODE_REFERENCE, g, G, zb) || dxv_grid_download(ctx, part.data(), part.size())) { fprintf(stderr, "share %u: %s\n", g, dxv_last_error(ctx)); return 1; }
+				for (uint32_t lz = 0; lz < N / G; ++lz) memcpy(whole.data() + plane * MultiVoxelizer::GlobalSlice(lz, g, G, zb), part.data() + plane * lz, plane);
+			}
+			if (whole != cyclic) { fprintf(stderr, "eight shares of 4-slice blocks do not reassemble to the grid\n"); return 1; }
+		}
+	}
+	printf("%llu %zu %zu %.3f %016llx\n", static_cast<unsigned long long>(solidCyclic), vox.DeviceCount(), vox.SceneBytes(), vox.BroadcastMs(),
+		static_cast<unsigned long long>(vox.SceneChecksum()));
 	return 0;
 }

@@ -446,7 +446,9 @@ static bool scells_any(const bool* b) { for (int t = 0; t < 64; ++t) if (b[t]) r
 // ended by the texel's far radius, [3] waves without a scanning lane, [4] distinct texels of the scanning lanes (sum over
 // waves), [5] their lists' lengths together, [6] entries scanned (start search to early stop), [7] sum over waves of the
 // longest lane scan, [8] entries whose byte box contains the ray, [9] ... that also pass the edge = triangles selected,
-// [10] sum over waves of the most selections of a lane (= triangle-step rounds), [11] lanes with a hit
+// [10] sum over waves of the most selections of a lane (= triangle-step rounds), [11] lanes with a hit,
+// [12] DISTINCT triangles among a wave's selections (sum over waves: [9] - [12] fetches of a 48-byte record are repeats),
+// [13] hits whose triangle answers the normal test by its class (no 48-byte normal record fetched)
 __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, uint32_t bstep, uint64_t* out)
 {
     HcScene* s = static_cast<HcScene*>(p);
@@ -456,12 +458,12 @@ __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, u
         for (int a = 0; a < 3; ++a) { rootLo[a] = min_(w[a], w[6 + a]); rootHi[a] = max_(w[3 + a], w[9 + a]); }
     }
     const uint32_t nb = N / 4, R = s->dmR;
-    uint64_t o[12] = {0};
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : o[:12])
+    uint64_t o[14] = {0};
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : o[:14])
     for (int64_t bzi = 0; bzi < (int64_t)nb; bzi += bstep) {
         for (uint32_t byi = 0; byi < nb; ++byi) for (uint32_t bxi = 0; bxi < nb; ++bxi) {
             int nlive = 0;
-            std::vector<uint32_t> cellsSeen;
+            std::vector<uint32_t> cellsSeen, trisSel;
             uint64_t mScan = 0, mSel = 0;
             for (int t = 0; t < 64; ++t) {
                 const uint32_t ix = bxi * 4 + t % 4, iy = byi * 4 + (t / 4) % 4, iz = (uint32_t)bzi * 4 + t / 16;
@@ -492,12 +494,12 @@ __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, u
                     DirEntry boxOnly = en; boxOnly.edge = 0u;
                     const uint32_t rc = dm_radial_word(near, bound);
                     if (dm_local_pass(boxOnly, loc, rc)) o[8]++;
-                    if (dm_local_pass(en, loc, rc)) { sel++; leaf_reference(r, s->triPos.data(), (int32_t)dm_entry_tri(en), best); }
+                    if (dm_local_pass(en, loc, rc)) { sel++; trisSel.push_back(dm_entry_tri(en)); leaf_reference(r, s->triPos.data(), (int32_t)dm_entry_tri(en), best); }
                 }
                 o[6] += scan; o[9] += sel;
                 if (scan > mScan) mScan = scan;
                 if (sel > mSel) mSel = sel;
-                if (best.k != 0xffffffffu) o[11]++;
+                if (best.k != 0xffffffffu) { o[11]++; if (__builtin_bit_cast(uint32_t, s->triPos[best.leaf].v1.w) >> kClassShift) o[13]++; }
             }
             if (!nlive) continue;
             o[0]++; o[1] += nlive; o[7] += mScan; o[10] += mSel;
@@ -505,10 +507,12 @@ __attribute__((visibility("default"))) void hc_list_stats(void* p, uint32_t N, u
             std::sort(cellsSeen.begin(), cellsSeen.end());
             cellsSeen.erase(std::unique(cellsSeen.begin(), cellsSeen.end()), cellsSeen.end());
             o[4] += cellsSeen.size();
+            std::sort(trisSel.begin(), trisSel.end());
+            o[12] += std::unique(trisSel.begin(), trisSel.end()) - trisSel.begin();
             for (uint32_t ci : cellsSeen) o[5] += s->dmCells[ci].count;
         }
     }
-    for (int i = 0; i < 12; ++i) out[i] = o[i];
+    for (int i = 0; i < 14; ++i) out[i] = o[i];
 }
 
 static uint64_t g_uniform = 0, g_distinct = 0;

@@ -617,11 +617,14 @@ def test_cpp_multi_gpu_host(orc, bunny, grids_json, tmp_path):
     out = tmp_path / "grid.bin"
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([str(exe), str(mesh), "128", str(out)], capture_output=True, text=True, env=env, timeout=600)
+    ndev_here = 0                                                       # ("all devices of the box" + the eight-share arithmetic on the first one)
+    r = subprocess.run([str(exe), str(mesh), "128", str(out), str(ndev_here or 64), "shares8"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    solid, ndev, blob = (int(x) for x in r.stdout.strip().splitlines()[-1].split())   # (RCCL may print its version banner first)
+    f = r.stdout.strip().splitlines()[-1].split()                       # (RCCL may print its version banner first)
+    solid, ndev, blob, bcast_ms, checksum = int(f[0]), int(f[1]), int(f[2]), float(f[3]), int(f[4], 16)
     want = grids_json["bunny/128/reference"]
     assert solid == want["solid"] and ndev >= 1 and blob > 0
+    assert bcast_ms > 0.0 and checksum != 0                             # the broadcast was timed and every device's copy summed
     g = np.fromfile(out, np.uint8).reshape(128, 128, 128)
     assert sha(g) == want["sha256"]
     assert np.array_equal(g, orc.Scene(vb, ib).voxelize(128))

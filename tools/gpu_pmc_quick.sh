@@ -16,4 +16,6 @@ run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum GRBM_GU
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+# (queued bricks of the launch, for the per-brick figures of the persistent kernel: from the driver's own stats line)
+export PMC_BRICKS=$(grep -o "'plan_bricks': [0-9]*" $OUT/sq1.log | tail -1 | grep -o "[0-9]*$")
 cd $GRAFT_REPO_ROOT && python3 tools/pmc_summary.py $OUT

@@ -32,10 +32,10 @@ def main():
     _, b = orc.bound(vb)
     h = L.hc_scene_create(np.ascontiguousarray(vb, np.float32), len(vb), np.ascontiguousarray(ib, np.uint32), len(ib) // 3, b)
     n = L.hc_dirmap_build(h, R)
-    out = np.zeros(12, np.uint64)
+    out = np.zeros(14, np.uint64)
     L.hc_list_stats(h, N, bstep, out.ctypes.data_as(C.c_void_p))
     names = ["waves", "live_lanes", "lanes_ended_by_far_radius", "waves_without_scanning_lane", "distinct_texels", "their_list_entries",
-             "entries_scanned", "longest_lane_scan", "box_passes", "selected", "triangle_rounds", "hits"]
+             "entries_scanned", "longest_lane_scan", "box_passes", "selected", "triangle_rounds", "hits", "distinct_selected", "hits_answered_by_class"]
     w = float(out[0])
     print(json.dumps({"mesh": name, "N": N, "R": R, "entries": int(n), "every_nth_brick_layer": bstep,
                       "per_wave": {k: round(float(out[i]) / w, 2) for i, k in enumerate(names) if i}, "waves": int(out[0])}))

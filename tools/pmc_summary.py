@@ -9,8 +9,8 @@ from collections import defaultdict
 
 
 def kind(name):
-    """k_voxelize launched through a dispatch plan (last template argument true) and over the brick box are different kernels"""
-    return "k_voxelize_plan" if name.rstrip().endswith("true>(dxv::VoxelizeParams)") or ", true>" in name.split("(")[0][-12:] else "k_voxelize"
+    """the lists kernel through the work queue (persistent waves) and the kernels launched over a brick box are different kernels"""
+    return "k_voxelize_queue" if "k_voxelize_queue" in name else "k_voxelize"
 
 
 def main():
@@ -44,12 +44,18 @@ def main():
             for n in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 if n in m:
                     m["per_wave"][n + "_frac"] = round(m[n] / m["SQ_WAVE_CYCLES"], 3)
+        # persistent waves: per BRICK is the figure that compares with a wave of the brick-box launch (PMC_BRICKS: queued bricks of the launch)
+        bricks = float(os.environ.get("PMC_BRICKS", "0") or 0)
+        if k == "k_voxelize_queue" and bricks:
+            m["bricks"] = bricks
+            m["per_brick"] = {n: round(m[n] / bricks, 1) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS",
+                                                                    "TCP_TOTAL_CACHE_ACCESSES_sum") if n in m}
         if dur.get(k):
             m["profiled_ms_mean"] = sum(dur[k]) / len(dur[k])
         out[k] = m
     with open(os.path.join(d, "summary.json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps({k: {"per_wave": v.get("per_wave"), "ms": v.get("profiled_ms_mean"), "TA_BUSY": v.get("TA_TA_BUSY_sum"),
+    print(json.dumps({k: {"per_wave": v.get("per_wave"), "per_brick": v.get("per_brick"), "ms": v.get("profiled_ms_mean"), "TA_BUSY": v.get("TA_TA_BUSY_sum"),
                           "GRBM": v.get("GRBM_GUI_ACTIVE"), "waves": v.get("SQ_WAVES")} for k, v in out.items()}, indent=1))
 
 
