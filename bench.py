@@ -185,14 +185,15 @@ def main():
         if use_dist:
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks = dist.get_world_size() if use_dist else 1
+        if use_dist:                                      # (the same order as the real run: the group goes away first, then rank 0's CPU baseline
+            dist.barrier()                                # and the line -- no rank waits in a collective while rank 0 computes)
+            dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "unit": "Mvoxels/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                              "config": {"rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": args.backend,
-                                         "rank_sum": float(t.item())}}), flush=True)
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
+                              "config": {"rccl_ranks": ranks, "backend": args.backend, "rank_sum": float(t.item()),
+                                         "process_group_alive_when_rank0_finishes": bool(use_dist and dist.is_initialized())}}), flush=True)
         return
 
     import dxrvoxelizer_amd as dxv

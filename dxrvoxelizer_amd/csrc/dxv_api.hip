@@ -90,7 +90,6 @@ struct dxv_ctx {
         size_t queueWords = 0;           // allocated 32-bit words
         bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
         bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
-        int queueOrdered = 0;            // the queue in use: 0 = as built (its launch measured what its chunks cost), 1 = the copy ordered by that cost, -1 = too large to order
         hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
     };
     Frame frames[DXV_FRAME_COUNT];
@@ -122,7 +121,6 @@ struct dxv_ctx {
     uint64_t listEpoch = 0;          // counts list builds / imports: a frame's queue belongs to the lists it was probed against
     int optPlan = 1;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch, 2 = on every launch
-    int optQueueOrder = 1;           // a queue that is launched again gets its cheapest chunks (by measured time) moved to its end: 1 = short launches only, 2 = always, 0 = never
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
     int optEvents = 1;               // bracket every launch with two HIP events (stats.voxelize_ms); 0: none (a caller timing its own loop)
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
@@ -692,22 +690,6 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels)); mix(reinterpret_cast<uint64_t>(p.queue));
             sig |= 1ull;
             const bool rebuild = c->optPlan == 2 || f.ptrExposed || f.clearSig != sig;
-            // A queue that is launched again: once, its chunks of 64 slots are sorted by the time the launch that built it measured
-            // for them (longest first; traverse.hip, k_queue_reorder) -- on the device, in this stream, in front of the first launch
-            // that uses the queue again.
-            // (only for launches of at most 2^25 voxels -- a rank's share, a 256^3 grid: there the end of the launch is a good part of it,
-            // -3 ... -6 % of a rank's share of 512^3 at 8 ranks; a whole 512^3 grid loses 1 - 2 % to the two streams through the grid)
-            const bool measure = c->optQueueOrder && c->optPlan == 1 && !f.ptrExposed && (uint64_t)p.N * p.N * p.nz <= (c->optQueueOrder == 2 ? ~0ull : 1ull << 25);
-            if (rebuild) f.queueOrdered = 0;
-            p.queueCost = rebuild && measure ? p.queue + plan_queue_cost_offset(cap) : nullptr;
-            if (!rebuild && measure && f.queueOrdered == 0) {
-                p.queueCost = p.queue + plan_queue_cost_offset(cap);
-                hipError_t re = hipSuccess;
-                f.queueOrdered = plan_reorder(p, fs, &re) ? 1 : -1;
-                if (re != hipSuccess) return fail(c, "work queue: reorder failed: %s", hipGetErrorString(re));
-                p.queueCost = nullptr;
-            }
-            p.queueSlots = f.queueOrdered == 1 ? p.queue + plan_queue_ordered_offset(cap) : p.queue + kQueueHeaderWords;
             hipEvent_t pe[2] = {f.evP0, f.evP1};
             DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, fs));
             f.clearSig = f.ptrExposed ? 0 : sig;
@@ -1546,10 +1528,6 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "plan")) {
         if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
         c->optPlan = (int)value;
-    } else if (!strcmp(key, "queueorder")) {
-        if (value < 0 || value > 2) return fail(c, "option queueorder: %lld not in {0,1,2}", (long long)value);
-        if (c->optQueueOrder != (int)value) for (auto& f : c->frames) f.clearSig = 0;
-        c->optQueueOrder = (int)value;
     } else if (!strcmp(key, "queuewaves")) {
         if (value < 0 || value > (1 << 20)) return fail(c, "option queuewaves: %lld not in [0, 2^20]", (long long)value);
         c->optQueueWaves = (int)value;
@@ -1677,7 +1655,6 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
     uint32_t cap = 0;
     (void)plan_queue_words(p.N, p.nz, &cap);
     p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip;
-    p.queueSlots = f.queueOrdered == 1 ? f.dQueue + plan_queue_ordered_offset(cap) : f.dQueue + kQueueHeaderWords;
     VoxelizeParams q = p;
     const uint32_t nb = plan_layout(q);
     uint32_t* bits = nullptr;

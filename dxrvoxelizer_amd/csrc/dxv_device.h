@@ -94,8 +94,6 @@ struct VoxelizeParams {
     uint32_t* queue;        // work queue of the lists kernel (traverse.hip): len[8], head[8], spare header words, then 8 x queueCap brick words
     uint32_t queueCap;
     uint32_t queueWaves;    // persistent waves to launch; 0 = what the device holds at once
-    const uint32_t* queueSlots; // the eight slot arrays the kernel reads: as k_plan_bricks wrote them, or the copy k_queue_reorder made
-    uint32_t* queueCost;    // measured time per chunk of 64 slots (8 x queueCap / 64 words, 100 MHz ticks), or NULL: not measured
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
@@ -107,12 +105,6 @@ DXV_HD constexpr uint32_t queue_len_word(uint32_t x) { return 64u * (65u + x); }
 // work queue of the lists kernel with 4 x 4 x 4 bricks (traverse.hip): built on the device in front of the launch
 uint32_t plan_layout(VoxelizeParams& p);           // fills the brick-order fields for the whole partition, returns its bricks
 size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut);     // 32-bit words of queue memory for a partition; *capOut = words per XCD queue
-// queue memory: header | slots (8 x cap) | cost (8 x cap / 64) | ordered copy of the slots (8 x cap)
-inline size_t plan_queue_cost_offset(uint32_t cap) { return kQueueHeaderWords + 8u * (size_t)cap; }
-inline size_t plan_queue_ordered_offset(uint32_t cap) { return plan_queue_cost_offset(cap) + 8u * (size_t)(cap / 64u); }
-// chunks of 64 consecutive slots of every queue sorted by the time they took (p.queueCost), longest first, into the ordered copy;
-// false: too many chunks for the one-workgroup sort (grids beyond ~800^3), the order stays
-bool plan_reorder(const VoxelizeParams& p, hipStream_t s, hipError_t* err);
 hipError_t plan_build(const VoxelizeParams& p, hipStream_t s);          // header cleared + k_plan_bricks (p.queue, p.queueCap, p.mip set)
 // rebuild: grid cleared + queue built in front of the kernel; else only the queue heads are reset (same launch as before into the same buffers)
 // (planEvents: two events recorded around the queue build of a rebuilding launch, or NULL)

@@ -114,6 +114,11 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 //    bricks one at a time from a head of its XCD's queue with a returning atomic add, asked for one brick ahead.  Which
 //    XCD a block really runs on is a matter of speed only: every head of every queue has its home waves by block number.
 //    No host round trip: the launch's size does not depend on how many bricks are live.
+//  * order: as built -- Morton order, regions dealt round-robin.  Measured and dropped (profiles/r04/ab_queue_*): dealing finer or to
+//    the shortest queue; a second queue per XCD, run last, for the bricks near or across the outer end of their lists (three
+//    definitions); and, for queues that are launched again, orders made on the device from MEASURED times -- the cheapest chunks of
+//    64 slots last (-3 % of a rank's share, +1 % on a whole grid), all chunks by cost (-6 % / +4 %), the bricks that took over three
+//    times the mean first and the shortest last (nothing): none earns a second copy of the queue.
 // Bricks that are not queued are zero by the launch's memset of the grid.
 // ---------------------------------------------------------------------------------------------
 [[maybe_unused]] constexpr uint32_t kQueueNoPrefetch = 1024u;
@@ -172,7 +177,7 @@ size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut)
     const uint64_t nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
     const uint64_t cap = ((nr + 7u) / 8u) << kPlanRegionBits;
     if (capOut) *capOut = (uint32_t)cap;
-    return plan_queue_ordered_offset((uint32_t)cap) + 8u * (size_t)cap;
+    return kQueueHeaderWords + 8u * (size_t)cap;
 }
 
 // header cleared, then one workgroup per region; p.queue / p.queueCap / p.mip set by the caller
@@ -181,81 +186,9 @@ hipError_t plan_build(const VoxelizeParams& pin, hipStream_t s)
     VoxelizeParams p = pin;
     const uint32_t nb = plan_layout(p), nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
     hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kQueueHeaderWords, s);
-    if (e == hipSuccess && p.queueCost) e = hipMemsetAsync(p.queueCost, 0, sizeof(uint32_t) * 8u * (size_t)(p.queueCap / 64u), s);
     if (e != hipSuccess) return e;
     k_plan_bricks<<<dim3(nr), dim3(256), 0, s>>>(p, nb);
     return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Order of a queue that is launched again (the static scene of the reference's loop, Content/Voxelizer.cpp:108-113).  The launch
-// that built the queue measured, per chunk of 64 consecutive slots (a compact 16^3-voxel piece of the grid: regions are appended
-// whole), the time its bricks took.  k_queue_reorder moves every queue's CHEAPEST chunks -- 2,048 bricks' worth, at most a third
-// of the queue: the partly dead shell of the scene -- to the queue's end, dearest of them first, and leaves the rest in Morton
-// order: the launch drains through short waves instead of ending on its longest bricks.  (The host-built plan of round 3 did the
-// same from estimated costs; sorting ALL chunks by cost, longest first, shortens a rank's share further but costs the full grid
-// 4 %: the bricks in flight are then no compact window of the grid any more.)  One workgroup per queue; bitonic sort of
-// (cost, chunk) in LDS.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kReorderMaxChunks = 8192u, kReorderTailChunks = 32u;
-__global__ __launch_bounds__(1024) void k_queue_reorder(VoxelizeParams p, uint32_t* __restrict__ ordered)
-{
-    __shared__ unsigned long long key[kReorderMaxChunks];               // cost << 32 | chunk, ascending: cheapest first
-    __shared__ uint32_t order[kReorderMaxChunks];                       // new position -> chunk
-    __shared__ uint8_t inTail[kReorderMaxChunks];
-    __shared__ uint32_t part[1024];
-    const uint32_t x = blockIdx.x, len = p.queue[queue_len_word(x)], full = len >> 6, tid = threadIdx.x;
-    const uint32_t* src = p.queue + kQueueHeaderWords + (size_t)x * p.queueCap;
-    uint32_t* dst = ordered + (size_t)x * p.queueCap;
-    const uint32_t* cost = p.queueCost + (size_t)x * (p.queueCap / 64u);
-    uint32_t n2 = 1;
-    while (n2 < full) n2 <<= 1;
-    for (uint32_t i = tid; i < n2; i += 1024u) { key[i] = i < full ? ((unsigned long long)cost[i] << 32) | i : ~0ull; if (i < full) inTail[i] = 0; }
-    __syncthreads();
-    for (uint32_t k = 2; k <= n2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < n2; i += 1024u) {
-                const uint32_t o = i ^ j;
-                if (o > i) {
-                    const unsigned long long a = key[i], b = key[o];
-                    if (((i & k) == 0u) ? a > b : a < b) { key[i] = b; key[o] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    const uint32_t tail = full / 3u < kReorderTailChunks ? full / 3u : kReorderTailChunks, body = full - tail;
-    // the cheapest `tail` chunks go last, dearest of them first
-    for (uint32_t i = tid; i < tail; i += 1024u) {
-        const uint32_t c = (uint32_t)(key[tail - 1u - i] & 0xffffffffull);
-        inTail[c] = 1; order[body + i] = c;
-    }
-    __syncthreads();
-    // the others keep their order: position = number of body chunks in front (per-thread runs + a scan of the runs' counts)
-    const uint32_t run = (full + 1023u) / 1024u, c0 = tid * run, c1 = c0 + run < full ? c0 + run : full;
-    uint32_t mine = 0;
-    for (uint32_t c = c0; c < c1; ++c) mine += inTail[c] ? 0u : 1u;
-    part[tid] = mine;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t a = tid >= off ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += a;
-        __syncthreads();
-    }
-    uint32_t pos = part[tid] - mine;
-    for (uint32_t c = c0; c < c1; ++c) if (!inTail[c]) order[pos++] = c;
-    __syncthreads();
-    for (uint32_t w = tid; w < full * 64u; w += 1024u) dst[w] = src[order[w >> 6] * 64u + (w & 63u)];
-    for (uint32_t w = full * 64u + tid; w < len; w += 1024u) dst[w] = src[w];     // the last, partial chunk stays last
-}
-bool plan_reorder(const VoxelizeParams& p, hipStream_t s, hipError_t* err)
-{
-    *err = hipSuccess;
-    if (!p.queueCost || p.queueCap / 64u > kReorderMaxChunks) return false;
-    uint32_t* ordered = p.queue + plan_queue_ordered_offset(p.queueCap);
-    k_queue_reorder<<<dim3(8), dim3(1024), 0, s>>>(p, ordered);
-    *err = hipGetLastError();
-    return *err == hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,7 +205,7 @@ __global__ __launch_bounds__(256) void k_plan_mark(VoxelizeParams p, uint32_t* _
     for (uint32_t x = 0; x < 8u; ++x) {
         const uint32_t len = p.queue[queue_len_word(x)];
         for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < len; k += gridDim.x * 256u) {
-            const uint32_t w = (p.queueSlots ? p.queueSlots : p.queue + kQueueHeaderWords)[(size_t)x * p.queueCap + k];
+            const uint32_t w = p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + k];
             const uint32_t id = ((w >> 20) * nbx + ((w >> 10) & 1023u)) * nbx + (w & 1023u);
             const uint32_t old = atomicOr(bits + (id >> 5), 1u << (id & 31u));
             if (old & (1u << (id & 31u))) atomicAdd(out + 4, 1ull);
@@ -356,7 +289,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
         const uint32_t x = cur >> 3, h = cur & 7u;
         const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
         uint32_t* head = p.queue + queue_head_word(x, h);
-        const uint32_t* slots = p.queueSlots + (size_t)x * p.queueCap;
+        const uint32_t* slots = p.queue + kQueueHeaderWords + (size_t)x * p.queueCap;
         if (len > h) {
         // One brick ahead: the add for the next brick is issued in front of the current one, and its answer is taken out of its
         // vector register as soon as the brick's first load (the rays' cells: all 64 lanes make that step together) has arrived --
@@ -371,7 +304,6 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
             if (k >= len) break;
             const bool ahead = len - k > kQueueNoPrefetch;
             if (ahead && threadIdx.x == 0u) jv = atomicAdd(head, 1u);
-            const uint32_t tick0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
             uint32_t w;                                                 // through the scalar cache: one word per wave
             const uint32_t* slot = slots + k;
             asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
@@ -430,9 +362,6 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
                     *reinterpret_cast<uint32_t*>(grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;   // bit i -> byte i
                 }
             }
-            // the launch that built the queue says what its chunks cost (k_queue_reorder, for the launches that use the queue again)
-            if (pp->queueCost && threadIdx.x == 0u)
-                atomicAdd(pp->queueCost + (size_t)x * (pp->queueCap >> 6) + (k >> 6), (uint32_t)__builtin_amdgcn_s_memrealtime() - tick0);
 #if defined(DXV_QUEUE_TIMES)
             { const uint64_t now = __builtin_amdgcn_s_memrealtime(); tLast = tBrick; if (now - tBrick > tMax) tMax = now - tBrick; tBrick = now; ++nBricks; }
 #endif
@@ -483,8 +412,7 @@ static uint32_t queue_waves(bool texels)
 // (same lists, partition and buffers: the kernel writes the same bricks every time) and only the queue heads are reset.
 hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, hipStream_t s)
 {
-    VoxelizeParams p = pin;
-    if (!p.queueSlots) p.queueSlots = p.queue + kQueueHeaderWords;
+    const VoxelizeParams& p = pin;
     hipError_t e;
     if (rebuild) {
         if ((e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s)) != hipSuccess) return e;

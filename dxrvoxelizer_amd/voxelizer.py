@@ -42,6 +42,11 @@ class Voxelizer:
         self.device = int(device)
         self._frame = 0
         self._lasts = {}
+        # DXV_OPTIONS="key=value,...": options for every context of a process (A/B runs of the tools without touching them)
+        import os
+        for kv in filter(None, os.environ.get("DXV_OPTIONS", "").split(",")):
+            k, val = kv.split("=")
+            self.set_option(k.strip(), int(val))
 
     # ---- lifetime ---------------------------------------------------------------------------
     def close(self):

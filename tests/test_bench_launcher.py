@@ -26,6 +26,11 @@ def test_self_launch_two_ranks_gloo_dry_run():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
     assert out["config"]["rccl_ranks"] == 2                # dist.get_world_size() inside the ranks
     assert out["config"]["rank_sum"] == 3.0                # the all-reduce saw both ranks
+    # rank 0's own work behind the steps (the CPU baseline in a real run) happens after the process group is gone: no rank sits
+    # in a collective meanwhile
+    assert out["config"]["process_group_alive_when_rank0_finishes"] is False
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("dist.destroy_process_group()", src.index("The CPU baseline is rank 0's alone")) < src.index('out["cpu_baseline"] = cpu_baseline(')
 
 
 def test_single_rank_needs_no_launcher():
@@ -68,3 +73,9 @@ def test_two_real_ranks_on_one_gpu_through_the_launcher(grids_json):
     assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["slab_slices_rank0"] == 64
     assert out["config"]["solid_voxels"] == grids_json["bunny/128/reference"]["solid"]
     assert out["config"]["candidates"]["structure"] == "direction-space lists" and out["value"] > 0
+    # the broadcast was timed and every rank's copy of the blob checked against the source's; the no-carried-state step is in the line
+    b = out["config"]["scene_broadcast"]
+    assert b["bytes"] > 0 and b["collective_ms"] > 0 and b["ranks_equal"] is True and int(b["checksum"], 16) != 0
+    f = out["config"]["fresh_step"]
+    assert f["plan"] == "rebuilt in the step" and f["grid"] == "cleared in the step" and f["ms_per_step"] > 0 and f["queued_bricks"] > 0
+    assert out["config"]["work_queue"]["queued_bricks"] == f["queued_bricks"]
