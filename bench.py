@@ -156,6 +156,7 @@ def main():
                     help="voxelizations in flight per GPU in the headline region (frames of ONE context, dxv_set_frame; the "
                          "reference keeps FrameCount = 3 grids in flight).  Default 1 at every N, so that values at different "
                          "N compare like for like; the two-in-flight figure is reported beside it")
+    ap.add_argument("--spin-ms", type=float, default=100.0, help="untimed launches for this long before the warm-up steps (GPU clocks out of idle); 0: none")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -252,6 +253,7 @@ def main():
         nz = N // world
 
     prepared = set()                             # grid sizes launched once before any warm-up (that launch builds the scene's candidate lists)
+    untimed = [0]                                # launches made before the first warm-up step (lists + clock spin-up)
 
     def timed_region(frames, steps, warmup, n=None, per_step=False):
         """`steps` steps with `frames` voxelizations in flight (frames of the one context, taking the steps in turn),
@@ -278,6 +280,14 @@ def main():
             prepared.add(n)                      # not of a step: built by the first launch of a scene (include/dxv.h, option lists).
             step()                               # (The launch's work queue is built on the device inside every launch that needs one:
             vox.SyncAll()                        # option plan, and config.fresh_step below.)
+            # ... and the GPU out of its idle clocks: the same launch for ~0.1 s before anything is timed (a timed region of 20
+            # steps is 16 ms: on a GPU that has just woken up it measured 4 % less than the same steps a second later)
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < args.spin_ms * 1e-3:
+                for _ in range(8):
+                    step()
+                vox.SyncAll()
+            untimed[0] += turn[0]
         for _ in range(max(warmup, frames)):     # every frame launches at least once before the clock starts
             step()
         vox.SyncAll()
@@ -486,7 +496,7 @@ def main():
                                                            if interleave else f"Z-slab partition over {world} GPU(s)"),
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
                        "slab_slices_rank0": nz, "frames_in_flight": frames, "solid_voxels": int(tot.item()),
-                       "untimed_launches_before_warmup": 1,     # the scene's candidate lists (built by its first launch) are Init work
+                       "untimed_launches_before_warmup": untimed[0],     # one builds the scene's candidate lists (Init work), the others spin the clocks up (--spin-ms)
                        "fresh_step": fresh_out,
                        "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": args.backend if use_dist else None,
                        "tree_height": st0["tree_height"], "stack_entries": st_run["stack_entries"],
