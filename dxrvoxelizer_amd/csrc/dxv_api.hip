@@ -91,6 +91,9 @@ struct dxv_ctx {
         bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
         bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
         hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
+        hipEvent_t evEnd = nullptr;      // behind the frame's last launch, always recorded: what a refit on another stream waits for on the device
+        bool usedLists = false;          // the frame's last launch went through the direction-space lists ...
+        uint64_t listEpochUsed = 0;      // ... of this build (a build whose deferred check fails is withdrawn: settle_lists, sync_frame)
     };
     Frame frames[DXV_FRAME_COUNT];
     uint32_t cur = 0;                    // dxv_set_frame
@@ -114,6 +117,27 @@ struct dxv_ctx {
     float listMs = 0.0f;
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
+    // The dynamic case (a mesh refitted every frame, XUSGRayTracing.h:13-22) with ONE host round trip per frame instead of four:
+    //  * dxv_refit queues the lists' counting pass behind its own kernels when the scene had lists (specRes: the map it counted
+    //    on) and reads root box and entry total in one synchronisation;
+    //  * a build made inside a launch does not wait for its own end: the launch is queued behind it, and the one thing the host
+    //    must still look at -- a texel with more entries than its 16-bit count holds -- is looked at when the frame is
+    //    synchronised (settle_lists); lists that fail there are withdrawn and the frame is launched again through the tree.
+    // Everything the device reports goes through page-locked words (a copy into pageable memory blocks the host until the
+    // stream has drained: 30 us of idle GPU per copy in the refit loop's trace).
+    struct Pinned {
+        uint32_t rootInfo[16];
+        unsigned long long listTotal;
+        uint32_t listLongest, pad;
+        uint32_t status[DXV_FRAME_COUNT][4];
+        uint32_t queueHeader[DXV_FRAME_COUNT][kQueueHeaderWords];
+    };
+    Pinned* pin = nullptr;
+    hipEvent_t evList[4] = {};       // around the counting pass, around the rest of the build
+    uint32_t specRes = 0;            // the counting pass for the current scene has run on this map (records, counts, total in place)
+    bool listCheckPending = false;   // lists in use whose longest texel has not been looked at yet
+    hipStream_t listCheckStream = nullptr;
+    uint64_t withdrawnEpoch = 0;     // listEpoch of the last build that failed its deferred check
     uint32_t launchesOfScene = 0;    // reference-rule launches since the scene last changed (build / refit / import)
     // max-mip of the lists' far radii (dxv_dirmap.h): made with the lists, what a launch's work queue is probed against
     uint16_t* dMip = nullptr;
@@ -198,6 +222,7 @@ int frame_prepare(dxv_ctx* c, uint32_t i)
     if (!f.ev1) DXV_HIP(c, hipEventCreate(&f.ev1));
     if (!f.evP0) DXV_HIP(c, hipEventCreate(&f.evP0));
     if (!f.evP1) DXV_HIP(c, hipEventCreate(&f.evP1));
+    if (!f.evEnd) DXV_HIP(c, hipEventCreateWithFlags(&f.evEnd, hipEventDisableTiming));
     if (!f.dStatus) DXV_HIP(c, hipMalloc(&f.dStatus, 256));
     if (!f.dRedo) DXV_HIP(c, hipMalloc(&f.dRedo, sizeof(uint64_t) * kRedoCap));
     // on the frame's own stream, and finished before anything reads the words: the streams are non-blocking, a memset on the
@@ -210,6 +235,7 @@ int frame_prepare(dxv_ctx* c, uint32_t i)
 }
 
 int sync_frame(dxv_ctx* c, uint32_t i);
+int settle_lists(dxv_ctx* c);
 
 // Everything that changes what the frames read (mesh, scene, lists, options that rebuild) first lets every
 // frame finish -- including the status check and, if a launch asked for it, the relaunch against the OLD scene.
@@ -217,7 +243,7 @@ int sync_frames(dxv_ctx* c)
 {
     for (uint32_t i = 0; i < DXV_FRAME_COUNT; ++i)
         if (c->frames[i].ready && sync_frame(c, i)) return 1;
-    return 0;
+    return settle_lists(c);
 }
 
 Node* scene_nodes(dxv_ctx* c) { return reinterpret_cast<Node*>(c->dScene + c->hdr.offNodes); }
@@ -322,13 +348,17 @@ uint32_t list_resolution(const dxv_ctx* c)
 // mean list length) exceeds what the rest of the build costs (0.1 ms + 0.15 ns per entry: 0.65 ms for 3.8 M entries).
 // Declined: listState stays 0, the launch walks the tree, the second launch builds the lists.
 int ensure_nodes(dxv_ctx* c, hipStream_t stream);      // (below, with the build)
-int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels);
+int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels, bool defer);
+int settle_lists(dxv_ctx* c);
 // A context that HAS working lists (the one-time move to the 512 map for launches at 1024^3 and beyond, an explicit listres)
 // builds the new ones beside them and swaps only when the build succeeded: out of memory, or lists over the caps on the new map,
 // leave the scene on the lists it had instead of on the tree walk (three times slower).
-int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
+// defer: the caller queues its launch behind the build and lets the frame's synchronisation look at the build's verdict
+// (settle_lists); otherwise the build is finished and checked when this returns.
+int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0, bool defer = false)
 {
-    if (c->listState != 1) return build_lists_into(c, stream, firstLaunchVoxels);
+    if (settle_lists(c)) return 1;
+    if (c->listState != 1) return build_lists_into(c, stream, firstLaunchVoxels, defer);
     DirCell* oldCells = c->dListCells; DirEntry* oldEntries = c->dListEntries; uint16_t* oldMip = c->dMip;
     const size_t oldCellCap = c->listCellCap, oldEntryCap = c->listEntryCap, oldMipCap = c->mipCap;
     const uint32_t oldN = c->listEntries, oldRes = c->listRes;
@@ -336,7 +366,7 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     const float oldMs = c->listMs;
     c->dListCells = nullptr; c->dListEntries = nullptr; c->dMip = nullptr; c->listCellCap = c->listEntryCap = c->mipCap = 0;
     c->listState = 0;
-    const int rc = build_lists_into(c, stream, firstLaunchVoxels);
+    const int rc = build_lists_into(c, stream, firstLaunchVoxels, false);
     if (rc == 0 && c->listState == 1) {                                 // the new lists stand: the old ones go
         (void)hipFree(oldCells); (void)hipFree(oldEntries); (void)hipFree(oldMip);
         return 0;
@@ -352,13 +382,43 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0)
     return rc;
 }
 
-int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels)
+// scratch of the counting pass (records, counts, offsets, block sums, total), kept with the context up to 16 GiB: an allocation
+// costs ~0.1 ms, as much as a pass of the build -- and hundreds of ms for the gigabytes of a 10 M-triangle scene
+struct ListScratchA { DirRecord* rec; uint32_t *counts, *offsets, *sums; unsigned long long* total; size_t bytes; };
+ListScratchA list_scratch_a(uint8_t* base, uint32_t T)
+{
+    const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
+    const size_t offCounts = align256(n6 * sizeof(DirRecord)), offOffsets = offCounts + align256(n6 * 4),
+                 offSums = offOffsets + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
+    return {reinterpret_cast<DirRecord*>(base), reinterpret_cast<uint32_t*>(base + offCounts), reinterpret_cast<uint32_t*>(base + offOffsets),
+            reinterpret_cast<uint32_t*>(base + offSums), reinterpret_cast<unsigned long long*>(base + offTotal), offTotal + 256};
+}
+
+// The verdict of a build whose caller did not wait for it: time, and the one thing only the host can act on -- a texel with
+// more entries than its 16-bit count holds.  Such lists are withdrawn (tree walk for this scene); frames launched with them
+// are launched again when they are synchronised (sync_frame).
+int settle_lists(dxv_ctx* c)
+{
+    if (!c->listCheckPending) return 0;
+    DXV_HIP(c, hipEventSynchronize(c->evList[3]));
+    c->listCheckPending = false;
+    c->listMs = elapsed(c->evList[0], c->evList[1]) + elapsed(c->evList[2], c->evList[3]);
+    if (c->pin->listLongest > 0xffffu) {
+        c->withdrawnEpoch = c->listEpoch;
+        c->listState = -1; c->listEntries = 0; c->listOpt = c->optListRes;
+    }
+    return 0;
+}
+
+int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels, bool defer)
 {
     const uint32_t T = c->hdr.numTris;
     uint32_t R = list_resolution(c);
     if (!c->optListRes && c->listResFloor > R) R = c->listResFloor;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (hipEventCreate(&t0) == hipSuccess && hipEventCreate(&t1) == hipSuccess) (void)hipEventRecord(t0, stream);
+    // dxv_refit has run the counting pass already (and read its total with the root box)?
+    const bool counted = c->specRes != 0 && c->dListScratchA && (c->optListRes ? (uint32_t)c->optListRes == c->specRes : c->listResFloor <= c->specRes);
+    if (counted) R = c->specRes;
+    c->specRes = 0;
     const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
     // scratch in two allocations (an allocation costs ~0.1 ms, as much as a pass): per-(triangle, face)
     // arrays now, the key buffers once the number of entries is known
@@ -376,9 +436,6 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels)
         if (scratchA != c->dListScratchA) (void)hipFree(scratchA);
         if (scratchB != c->dListScratchB) (void)hipFree(scratchB);
         scratchA = scratchB = nullptr;
-        if (t0) (void)hipEventDestroy(t0);
-        if (t1) (void)hipEventDestroy(t1);
-        t0 = t1 = nullptr;
     };
     // The lists are an optional accelerator: when their memory cannot be had the scene keeps the tree walk
     // (listState = -1, like a scene whose lists would be too long); only launch and sync errors are errors.
@@ -392,25 +449,28 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels)
         return fail(c, "lists: %s failed: %s", what, hipGetErrorString(e));
     };
     hipError_t e;
-    const size_t offCounts = align256(n6 * sizeof(DirRecord)), offOffsets = offCounts + align256(n6 * 4),
-                 offSums = offOffsets + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
-    if ((e = scratch(c->dListScratchA, c->listScratchACap, offTotal + 256, scratchA)) != hipSuccess) return bail(e, "hipMalloc");
-    DirRecord* rec = reinterpret_cast<DirRecord*>(scratchA);
-    uint32_t* counts = reinterpret_cast<uint32_t*>(scratchA + offCounts);
-    uint32_t* offsets = reinterpret_cast<uint32_t*>(scratchA + offOffsets);
-    uint32_t* sums = reinterpret_cast<uint32_t*>(scratchA + offSums);
-    unsigned long long* dTotal = reinterpret_cast<unsigned long long*>(scratchA + offTotal);
-    if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
+    (void)nb;
+    if (counted) scratchA = c->dListScratchA;
+    else if ((e = scratch(c->dListScratchA, c->listScratchACap, list_scratch_a(nullptr, T).bytes, scratchA)) != hipSuccess) return bail(e, "hipMalloc");
+    const ListScratchA sa = list_scratch_a(scratchA, T);
+    DirRecord* rec = sa.rec;
+    uint32_t *counts = sa.counts, *offsets = sa.offsets, *sums = sa.sums;
+    unsigned long long* dTotal = sa.total;
     unsigned long long total = 0;
-    if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     auto recount = [&](uint32_t res) -> int {
         R = res;
         if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
-        if ((e = hipMemcpyAsync(&total, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
+        (void)hipEventRecord(c->evList[1], stream);
+        if ((e = hipMemcpyAsync(&c->pin->listTotal, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+        total = c->pin->listTotal;
         return 0;
     };
+    if (counted) total = c->pin->listTotal;
+    else {
+        (void)hipEventRecord(c->evList[0], stream);
+        if (recount(R)) return 1;
+    }
     // automatic resolution, from the mean list length A = entries per texel (it hardly depends on the map: it is the
     // number of triangles a direction meets, at any depth):
     //  * 10 < A <= 32 on the 256 map: the 512 map is faster for some scenes (bunny x16 1.49 -> 1.42 ms; dragon x9 0.79 ->
@@ -457,8 +517,9 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels)
     uint64_t* keys = reinterpret_cast<uint64_t*>(scratchB);
     uint64_t* keysTmp = reinterpret_cast<uint64_t*>(scratchB + keyBytes);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratchB + 2 * keyBytes);
-    uint32_t longest = 0;
-    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, &longest, stream)) != hipSuccess)
+    (void)hipEventRecord(c->evList[2], stream);
+    c->pin->listLongest = 0;
+    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, &c->pin->listLongest, stream)) != hipSuccess)
         return bail(e, "dirmap_fill");
 
     // the max-mip of the texels' far radii goes with the lists (a launch's work queue is probed against it)
@@ -468,20 +529,18 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels)
         c->mipCap = dm_mip_words(R);
     }
     if ((e = dirmap_mip(c->dListCells, R, c->dMip, stream)) != hipSuccess) return bail(e, "dirmap_mip");
-    if (t1) (void)hipEventRecord(t1, stream);
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
-    if (t0 && t1) c->listMs = elapsed(t0, t1);
+    if ((e = hipEventRecord(c->evList[3], stream)) != hipSuccess) return bail(e, "hipEventRecord");
+    // scratch that is not kept (over 16 GiB) is freed here: hipFree waits for the device
     release();
-    if (longest > 0xffffu) {                              // a texel with more entries than its 16-bit count holds: tree walk
-        c->listState = -1; c->listEntries = 0; c->listOpt = c->optListRes;
-        return 0;
-    }
     c->listEntries = n;
     c->listRes = R;
     c->listState = 1;
     c->listOpt = c->optListRes;
     ++c->listEpoch;                                       // (work queues probed against older lists are stale)
-    return 0;
+    // a texel with more entries than its 16-bit count holds: tree walk -- decided by settle_lists, now or when the frame
+    // that is launched behind this build is synchronised
+    c->listCheckPending = true; c->listCheckStream = stream;
+    return defer ? 0 : settle_lists(c);
 }
 
 // Row lists of the parity rule (dirmap.hip).  Resolution: the finest grid, from 512 (below 20 k triangles), 2048 (up to 3 M) or
@@ -583,6 +642,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
     bool queued = false;
     uint32_t cap = 0;                                                   // words per XCD queue of this partition
     f.list_entries = 0; f.list_res = 0;
+    f.usedLists = false;
     // The lists cost 0.3-2.7 ms to build: a scene pays for them on its second launch (lists=1), so a
     // mesh that is refitted every frame and voxelized once per refit stays on the tree walk; lists=2
     // builds them at the first launch.
@@ -591,7 +651,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
     const uint64_t voxels = (uint64_t)p.N * p.N * p.nz;
     if (!relaunch && p.mode == DXV_MODE_REFERENCE && c->optLists == 1 && c->launchesOfScene == 0 && c->listState == 0 && voxels >= (1ull << 26)) {
         if (sync_frames(c)) return 1;
-        if (build_lists(c, fs, voxels)) return 1;
+        if (build_lists(c, fs, voxels, true)) return 1;
     }
     // A scene that has lists on the 256 map and is now launched (again) at 1024^3 or beyond: once, the 512 map instead -- the
     // map that suits a grid keeps a texel about two voxels wide (measured: 128^3 -> R 128, 256^3 and 512^3 -> 256, 1024^3 -> 512;
@@ -607,9 +667,12 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
     if (p.mode == DXV_MODE_REFERENCE && !relaunch) ++c->launchesOfScene;
     if (wantLists) {
         if (c->listState == 0 || (c->listState != 0 && c->listOpt != c->optListRes)) {
-            if (build_lists(c, fs)) return 1;
+            if (build_lists(c, fs, 0, true)) return 1;              // (this launch queues behind the build; its verdict: sync_frame)
         }
         if (c->listState == 1) {
+            // lists built on another frame's stream whose end nobody has waited for yet: this stream waits for it on the device
+            if (c->listCheckPending && c->listCheckStream != fs) DXV_HIP(c, hipStreamWaitEvent(fs, c->evList[3], 0));
+            f.usedLists = true; f.listEpochUsed = c->listEpoch;
             p.lists = 1u;
             p.ablate = (uint32_t)c->optAblate;
             p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
@@ -703,6 +766,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
         }
     }
     if (c->optEvents) DXV_HIP(c, hipEventRecord(f.ev1, fs));
+    DXV_HIP(c, hipEventRecord(f.evEnd, fs));
     f.timed = c->optEvents != 0;
     f.pending = true;
     return 0;
@@ -732,6 +796,15 @@ int dxv_create(dxv_ctx** out, int device)
     for (auto& ev : c->ev) {
         if (hipEventCreate(&ev) != hipSuccess) { delete c; return fail(nullptr, "dxv_create: hipEventCreate failed"); }
     }
+    for (auto& ev : c->evList) {
+        if (hipEventCreate(&ev) != hipSuccess) { dxv_destroy(c); return fail(nullptr, "dxv_create: hipEventCreate failed"); }
+    }
+    if (hipHostMalloc(reinterpret_cast<void**>(&c->pin), sizeof(dxv_ctx::Pinned), hipHostMallocDefault) != hipSuccess) {
+        c->pin = nullptr;
+        dxv_destroy(c);
+        return fail(nullptr, "dxv_create: hipHostMalloc failed");
+    }
+    memset(c->pin, 0, sizeof(dxv_ctx::Pinned));
     if (hipMalloc(&c->dCount, 256) != hipSuccess || hipMalloc(&c->dRootInfo, 256) != hipSuccess || frame_prepare(c, 0)) {
         dxv_destroy(c);
         return fail(nullptr, "dxv_create: hipMalloc failed");
@@ -752,6 +825,7 @@ void dxv_destroy(dxv_ctx* c)
         if (f.ev1) (void)hipEventDestroy(f.ev1);
         if (f.evP0) (void)hipEventDestroy(f.evP0);
         if (f.evP1) (void)hipEventDestroy(f.evP1);
+        if (f.evEnd) (void)hipEventDestroy(f.evEnd);
         if (f.ownStream) (void)hipStreamDestroy(f.ownStream);
     }
     free_scratch(c);
@@ -760,6 +834,8 @@ void dxv_destroy(dxv_ctx* c)
     (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dPlCells); (void)hipFree(c->dPlEntries); (void)hipFree(c->dPlScratch); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
     (void)hipFree(c->dCount); (void)hipFree(c->dPacked); (void)hipFree(c->dRootInfo);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->evList) if (ev) (void)hipEventDestroy(ev);
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -775,6 +851,7 @@ int dxv_trim(dxv_ctx* c)
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
     c->dListScratchA = c->dListScratchB = nullptr; c->listScratchACap = c->listScratchBCap = 0;
+    c->specRes = 0;
     if (!c->haveHierarchy) free_scratch(c);                             // (a built scene keeps keys and links: dxv_refit reads them)
     return 0;
 }
@@ -836,7 +913,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     c->vbCopyQueued = false;
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
+    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -888,8 +965,8 @@ int alloc_pyramid(dxv_ctx* c)
 // arguments, an export writes the blob's header from the host's copy): dxv_build keeps it current, a refit saves the round trip
 int finish_build(dxv_ctx* c, const char* who, bool headerToDevice = true)
 {
-    uint32_t rootInfo[16];
-    DXV_HIP(c, hipMemcpyAsync(rootInfo, c->dRootInfo, sizeof(rootInfo), hipMemcpyDeviceToHost, c->stream));
+    uint32_t* rootInfo = c->pin->rootInfo;
+    DXV_HIP(c, hipMemcpyAsync(rootInfo, c->dRootInfo, sizeof(c->pin->rootInfo), hipMemcpyDeviceToHost, c->stream));
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->vbCopyQueued = false;
     if (rootInfo[7] != 1) return fail(c, "%s: did not complete", who);
@@ -942,7 +1019,8 @@ int dxv_update_vertices_device(dxv_ctx* c, const void* dvb, uint32_t V)
     if (!c->haveMesh || !c->dVb) return fail(c, "dxv_update_vertices_device: no mesh resident on this context");
     if (!dvb || V != c->V) return fail(c, "dxv_update_vertices_device: vertex count must stay %u, got %u", c->V, V);
     DXV_HIP(c, hipSetDevice(c->device));
-    if (sync_frames(c)) return 1;
+    // No wait for the frames (as in dxv_update_vertices): their launches never read the vertex buffer, and its readers --
+    // dxv_build, dxv_refit -- run on this same stream.
     DXV_HIP(c, hipMemcpyAsync(c->dVb, dvb, sizeof(float) * 6 * (size_t)V, hipMemcpyDeviceToDevice, c->stream));
     c->vbCopyQueued = true;
     return 0;                                                          // (dxv_refit, on the same stream, comes next)
@@ -954,8 +1032,21 @@ int dxv_refit(dxv_ctx* c)
     if (!c->haveMesh || !c->haveHierarchy || c->scratchT != c->T || !c->T)
         return fail(c, "dxv_refit: needs a scene built on this context by dxv_build (imported scenes carry no build state)");
     DXV_HIP(c, hipSetDevice(c->device));
-    if (sync_frames(c)) return 1;
+    // The frames' launches read what the refit is about to write.  A launch that may still have something to say (a tree walk whose
+    // column can run out; lists that failed their deferred check) is synchronised on the host and, if need be, run again against
+    // the OLD scene; every other launch is waited for ON THE DEVICE -- frame 0 shares this stream, the other frames' end events
+    // are waited for by it -- so that the refit's kernels, the lists' counting pass and the host's one synchronisation of the
+    // frame (finish_build) queue up behind a launch that is still running.
+    if (settle_lists(c)) return 1;                                     // (waits for a build's end, not for the launch behind it)
+    for (uint32_t i = 0; i < DXV_FRAME_COUNT; ++i) {
+        Frame& f = c->frames[i];
+        if (!f.ready || !f.pending) continue;
+        if (f.lastCanFail || (f.usedLists && f.listEpochUsed == c->withdrawnEpoch)) { if (sync_frame(c, i)) return 1; }
+        else if (frame_stream(c, i) != c->stream) DXV_HIP(c, hipStreamWaitEvent(c->stream, f.evEnd, 0));
+    }
+    const uint32_t hadListsOn = c->listState == 1 ? c->listRes : 0u;
     c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0;
+    c->specRes = 0;
     if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
     fill_build_buffers(c, b);
@@ -969,7 +1060,19 @@ int dxv_refit(dxv_ctx* c)
     b.deferBoxes = c->optLists != 0 && c->optDeferBoxes && b.pyramid && c->T > 1;
     DXV_HIP(c, lbvh_refit(b, c->optRefit, c->hdr.treeHeight, c->stream, c->ev + 3));
     c->nodesStale = b.deferBoxes ? 2 : b.deferCopies ? 1 : 0;
+    // A scene that had lists (or asks for them from its first launch) will have them rebuilt by its next launch: their counting
+    // pass needs the new triangle records only, so it runs here, behind the refit, and its total comes back with the root box.
+    uint32_t spec = 0;
+    if (c->optLists && (hadListsOn || c->optLists == 2) && c->dListScratchA && c->listScratchACap >= list_scratch_a(nullptr, c->hdr.numTris).bytes) {
+        spec = c->optListRes ? (uint32_t)c->optListRes : hadListsOn ? hadListsOn : list_resolution(c);
+        const ListScratchA sa = list_scratch_a(c->dListScratchA, c->hdr.numTris);
+        DXV_HIP(c, hipEventRecord(c->evList[0], c->stream));
+        DXV_HIP(c, dirmap_count(scene_tripos(c), c->hdr.numTris, spec, sa.rec, sa.counts, sa.total, c->stream));
+        DXV_HIP(c, hipEventRecord(c->evList[1], c->stream));
+        DXV_HIP(c, hipMemcpyAsync(&c->pin->listTotal, sa.total, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    }
     if (finish_build(c, "dxv_refit", false)) return 1;
+    c->specRes = spec;
     c->stats.refit_ms = elapsed(c->ev[3], c->ev[4]);
     return 0;
 }
@@ -980,7 +1083,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
+    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -1044,17 +1147,25 @@ int sync_frame(dxv_ctx* c, uint32_t i)
     Frame& f = c->frames[i];
     const hipStream_t fs = frame_stream(c, i);
     for (int attempt = 0; attempt < 8; ++attempt) {
-        uint32_t words[3] = {0, 0, 0};
-        DXV_HIP(c, hipMemcpyAsync(words, f.dStatus, sizeof(words), hipMemcpyDeviceToHost, fs));
+        // status words and the queue's header in one round trip, into page-locked words
+        uint32_t* words = c->pin->status[i];
+        const uint32_t* hdr = c->pin->queueHeader[i];
+        const bool readQueue = f.pending && f.lastQueued;
+        DXV_HIP(c, hipMemcpyAsync(words, f.dStatus, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, fs));
+        if (readQueue) DXV_HIP(c, hipMemcpyAsync(c->pin->queueHeader[i], f.dQueue, sizeof(uint32_t) * kQueueHeaderWords, hipMemcpyDeviceToHost, fs));
         DXV_HIP(c, hipStreamSynchronize(fs));
+        // lists this launch was queued behind without waiting for their verdict: withdrawn -> the launch again, through the tree
+        if (settle_lists(c)) return 1;
+        if (f.pending && f.usedLists && f.listEpochUsed == c->withdrawnEpoch && c->haveScene && f.grid_dim) {
+            f.usedLists = false;
+            if (launch_now(c, i, true)) return 1;
+            continue;
+        }
         const uint32_t status = words[0];
         if (f.pending) {
             f.voxelize_ms = f.timed ? elapsed(f.ev0, f.ev1) : 0.0f;
             f.redo_rays = f.lastRedoParity < 0 ? 0u : words[1 + f.lastRedoParity];
-            if (f.lastQueued) {
-                uint32_t hdr[kQueueHeaderWords];
-                DXV_HIP(c, hipMemcpyAsync(hdr, f.dQueue, sizeof(hdr), hipMemcpyDeviceToHost, fs));
-                DXV_HIP(c, hipStreamSynchronize(fs));
+            if (readQueue) {
                 f.plan_bricks = 0;
                 for (uint32_t x = 0; x < 8u; ++x) f.plan_bricks += hdr[queue_len_word(x)];
                 if (f.lastRebuilt) f.plan_ms = f.timed ? elapsed(f.evP0, f.evP1) : 0.0f;
@@ -1303,6 +1414,7 @@ int dxv_build_lists(dxv_ctx* c)
     if (!c) return 1;
     if (!c->haveScene) return fail(c, "dxv_build_lists: no scene");
     DXV_HIP(c, hipSetDevice(c->device));
+    if (settle_lists(c)) return 1;
     if (c->listState != 0 && c->listOpt == c->optListRes) return 0;
     if (sync_frames(c)) return 1;
     return build_lists(c, c->stream);
@@ -1327,6 +1439,7 @@ int dxv_scene_export(dxv_ctx* c, void* dst, size_t bytes)
 {
     if (!c) return 1;
     if (!c->haveScene) return fail(c, "dxv_scene_export: no scene");
+    if (settle_lists(c)) return 1;
     const bool withLists = lists_exportable(c), withPl = plists_exportable(c);
     const BlobLayout b = export_layout(c);
     if (!dst || bytes != b.total) return fail(c, "dxv_scene_export: expected %zu bytes, got %zu", b.total, bytes);
@@ -1390,7 +1503,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         (withPl && (h.offPlCells != b.offPlCells || h.offPlEntries != b.offPlEntries)) || (!withPl && (h.offPlCells || h.offPlEntries || h.plCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
+    c->haveScene = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
     // triangle count over the old, smaller buffers.
@@ -1641,6 +1754,7 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
 {
     if (!c || !out) return 1;
     Frame& f = cur_frame(c);
+    if (settle_lists(c)) return 1;
     if (!c->haveScene || c->listState != 1 || !f.lastQueued || !f.dQueue || !f.grid_dim)
         return fail(c, "dxv_debug_plan_check: the current frame's last launch did not go through a work queue");
     DXV_HIP(c, hipSetDevice(c->device));
@@ -1675,6 +1789,7 @@ int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
     const void* src = nullptr;
     size_t want = 0;
     const size_t T = c->T;
+    if (settle_lists(c)) return 1;
     if ((what == DXV_DBG_NODES || what == DXV_DBG_NODES32 || what == DXV_DBG_NODES64) && c->haveScene && ensure_nodes(c, c->stream)) return 1;
     switch (what) {
     case DXV_DBG_SORTED_KEYS: src = c->dKeys; want = sizeof(uint64_t) * T; if (c->scratchT != c->T) src = nullptr; break;

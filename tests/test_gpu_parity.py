@@ -1289,3 +1289,88 @@ def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, host
             assert 0 < st["plan_ms"] < st["voxelize_ms"]
         assert np.array_equal(v.Grid(), g_auto), (plan, events)
     v.close()
+
+
+@pytest.mark.gpu
+def test_deferred_list_verdict_and_queued_refit_frames(dxv, orc, bunny):
+    """The dynamic case with one host round trip per frame (XUSGRayTracing.h:13-22): a launch is queued behind the build of its
+    lists without waiting for the build's verdict, a refit waits for the frames' launches on the device and runs the lists'
+    counting pass behind its own kernels.
+    (a) The verdict the host must act on -- a texel with more entries than its 16-bit count holds -- arrives after the launch
+        was queued: the lists are withdrawn and the frame is launched again through the tree, synchronously or not.
+    (b) Frames of a refit-per-frame loop that nothing waits for give the grids of the same meshes voxelized one by one; a
+        launch of ANOTHER frame that is still running when the refit comes reads the old scene to its end."""
+    import torch
+    # (a) 2 x 70,000 small plates stacked along the x axis through the grid centre: the texels around it hold 70,000 entries each
+    K = 70000
+    r = np.linspace(0.05, 1.0, K, dtype=np.float32)
+    h = np.float32(0.04) * r                                           # (the same few texels for every plate; wide enough for the rays next to the axis)
+    one = np.stack([np.stack([r, -h, -h], 1), np.stack([r, h, -h], 1), np.stack([r, np.zeros_like(r), h], 1)], 1).reshape(-1, 3)
+    pos = np.concatenate([one, one * np.array([-1, 1, 1], np.float32)])
+    vbp = np.ascontiguousarray(np.hstack([pos, np.tile(np.array([[1, 0, 0]], np.float32), (len(pos), 1))]), np.float32)
+    ibp = np.arange(len(pos), dtype=np.uint32)
+    t = dxv.Voxelizer(0)
+    t.set_option("lists", 0)
+    t.InitFromArrays(vbp, ibp)
+    t.Voxelize(64)
+    want = t.Grid().copy()
+    assert want.any()
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 2)
+    v.InitFromArrays(vbp, ibp)
+    v.Voxelize(64)
+    st = v.stats()
+    assert np.array_equal(v.Grid(), want) and st["list_entries"] == 0 and st["list_ms"] > 0      # (built, then withdrawn)
+    v.InitFromArrays(vbp, ibp)
+    for f in (0, 1, 0):
+        v.Voxelize(64, sync=False, frameIndex=f)                       # queued behind the build, and behind each other
+    v.SyncAll()
+    for f in (0, 1):
+        v.SetFrame(f)
+        assert np.array_equal(v.Grid(), want) and v.stats()["list_entries"] == 0, f
+    v.SetFrame(0)
+    t.close()
+    # (b)
+    vb, ib, _ = bunny
+    base = np.ascontiguousarray(vb, np.float32)
+
+    def pose(k):
+        m = base.copy()
+        m[:, 1] *= np.float32(1.0 - 0.04 * k)
+        m[:, 0] += np.float32(0.05) * np.sin(np.float32(5.0 + k) * m[:, 2])
+        return m
+
+    v.InitFromArrays(base, ib)
+    v.Voxelize(128)
+    e0 = v.stats()["list_entries"]
+    assert e0 > 0
+    dev = [torch.from_numpy(pose(k)).cuda() for k in range(5)]
+    torch.cuda.synchronize()
+    old = v.Grid().copy()
+    for k in range(5):
+        if k == 3:
+            v.Voxelize(256, sync=False, frameIndex=1)                  # still running (pose 2) when the next refit is queued
+        v.UpdateVerticesDevice(dev[k].data_ptr(), len(base))
+        v.Voxelize(128, sync=False, frameIndex=0)
+    v.SyncAll()
+    w = dxv.Voxelizer(0)
+    w.set_option("lists", 0)
+    w.InitFromArrays(base, ib)
+    w.UpdateVertices(pose(4))
+    w.Voxelize(128)
+    v.SetFrame(0)
+    assert np.array_equal(v.Grid(), w.Grid()) and not np.array_equal(v.Grid(), old)
+    st = v.stats()
+    assert st["list_entries"] > 0 and st["list_ms"] > 0 and st["plan_bricks"] > 0
+    w.UpdateVertices(pose(2))
+    w.Voxelize(256)
+    v.SetFrame(1)
+    assert np.array_equal(v.Grid(), w.Grid())
+    # the same loop with the host waiting for every frame, and the lists checked exhaustively against the refitted scene
+    v.SetFrame(0)
+    for k in (1, 4):
+        v.UpdateVerticesDevice(dev[k].data_ptr(), len(base))
+        v.Voxelize(128)
+    assert np.array_equal(v.Grid(), (w.UpdateVertices(pose(4)), w.Voxelize(128), w.Grid())[2])
+    assert v.list_check(128)[1] == 0
+    v.close(); w.close()

@@ -31,11 +31,11 @@ def main():
     solid = {}
     hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
     hip.hipHostUnregister.argtypes = [C.c_void_p]
-    for lists, device in ((0, False), (2, False), (2, "overlap"), (2, "overlap, pinned"), (2, True)):
+    for lists, device in ((0, False), (2, False), (2, "overlap"), (2, "overlap, pinned"), (2, True), (2, "device, queued")):
         v.set_option("lists", lists)
 
         def update():
-            v.UpdateVerticesDevice(dvb.value, len(vb)) if device is True else v.UpdateVertices(vb)
+            v.UpdateVerticesDevice(dvb.value, len(vb)) if device in (True, "device, queued") else v.UpdateVertices(vb)
 
         for _ in range(3):
             update()
@@ -52,6 +52,13 @@ def main():
                 v.UpdateVertices(vb, refit=False)
                 v.Refit()
             v.Voxelize(N)
+        elif device == "device, queued":
+            # the application's loop when the grid is consumed on the GPU: nothing waits for a launch -- the copy, the refit and the
+            # lists' counting pass queue up behind it, and the host's one wait per frame (root box and entry total) is dxv_refit's
+            for _ in range(frames):
+                update()
+                v.Voxelize(N, sync=False)
+            v.Sync()
         else:
             for _ in range(frames):
                 update()
@@ -62,7 +69,7 @@ def main():
             hip.hipHostUnregister(vb.ctypes.data_as(C.c_void_p))
         st = v.stats()
         solid[(lists, device)] = v.CountSolid()
-        where = {False: "host array (12 MB over PCIe per frame at 1 M triangles)", True: "device buffer",
+        where = {False: "host array (12 MB over PCIe per frame at 1 M triangles)", True: "device buffer", "device, queued": "device buffer, launches not waited for",
                  "overlap": "host array, uploaded while the previous frame's launch runs",
                  "overlap, pinned": "page-locked host array, uploaded while the previous frame's launch runs"}[device]
         print(json.dumps({"mesh": mesh, "N": N, "lists": lists, "vertices_from": where,
