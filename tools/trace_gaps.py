@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 d = sys.argv[1]
@@ -13,7 +14,8 @@ anchor = sys.argv[3] if len(sys.argv) > 3 else "k_voxelize_queue"
 f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[-1]
 rows = []
 for r in csv.DictReader(open(f)):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dxv::", "")))
+    m = re.search(r"(k_\w+|__amd_rocclr_\w+)", r["Kernel_Name"])
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else r["Kernel_Name"][:40]))
 rows.sort()
 idx = [i for i, r in enumerate(rows) if anchor in r[2]]
 sel = idx[-frames - 1:]
