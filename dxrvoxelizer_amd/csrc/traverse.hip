@@ -268,10 +268,6 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
     // bricks in flight on an XCD stay a compact window of its queue (what hardware dispatch of one workgroup per brick gave:
     // neighbouring bricks look into the same texels while they are in the caches; chunks of 8 consecutive bricks per wave
     // cost 7 %, of 16 15 %), and no head sees more than a few adds per microsecond (all bricks through ONE word: 2.7 ms).
-    // Which head next: the wave's home head first; after that all 64 heads are looked at AT ONCE -- lane l loads head l and its queue's
-    // length, one round trip -- and the wave goes on with a head that still shows work, its own XCD's first (placement is for speed
-    // only; a head's value may be stale, i.e. too small: then the add finds out).  Looking at them one after the other cost every
-    // wave ~50 us at the end of a launch: that was the launch's tail.
 #if defined(DXV_QUEUE_TIMES)
     const uint64_t tStart = __builtin_amdgcn_s_memrealtime();
     uint64_t tBrick = tStart, tLast = tStart, tMax = 0, nBricks = 0;
