@@ -38,6 +38,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_build -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_refit_loop -- python3 $GRAFT_REPO_ROOT/tools/refit_loop.py torus1m 512 20 > $OUT/prof_refit_loop.log 2>&1
 cd $GRAFT_REPO_ROOT
 for d in prof_bench prof_build prof_refit_loop; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${d}_kernel_stats.csv; done
+# where a frame of the refit loop goes (kernels of the last frames in order, idle time in front of each): the loop's last variant, nothing waited for
+python3 tools/trace_gaps.py $OUT/prof_refit_loop 3 > $OUT/refit_loop_trace_gaps.jsonl 2>&1
+find $OUT/prof_bench $OUT/prof_build $OUT/prof_refit_loop -name "*.csv" -size +4M -delete
 # counter passes (each in its own run, --kernel-trace only beside --pmc)
 export PMC_LAUNCHES=5
 bash tools/gpu_pmc_quick.sh torus1m torus1m 512 > $OUT/pmc_torus1m.log 2>&1
