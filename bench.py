@@ -525,7 +525,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, **({"traffic_note": traffic_note} if traffic_note else {}),
                          "stored_bytes_per_launch": stored_kept,
                          "achieved_on_stored_bytes": (stored_kept + scene_bytes) / (kernel_ms * 1e-3) / 1e9,
-                         "kernel": "k_voxelize" if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
+                         "kernel": ("k_voxelize_queue" if st_run.get("plan_bricks") else "k_voxelize") if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); a step that keeps "
                                  "its queue stores only its queued bricks (stored_bytes_per_launch; config.fresh_step stores all of it); the kernel "

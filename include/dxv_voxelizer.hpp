@@ -80,7 +80,8 @@ public:
 
 	// The two halves on their own, for a loop that hides the upload: VoxelizeAsync(frame i); UploadVertices(frame i + 1) --
 	// dxv_update_vertices does not wait for launches in flight, they read the scene and not the vertex buffer --;
-	// Refit() (waits for the launch, then refits); VoxelizeAsync(frame i + 1); ...
+	// Refit() (the frame's one host round trip: its kernels and the lists' counting pass queue up behind the launch);
+	// VoxelizeAsync(frame i + 1) (queued behind the list build); ...  From a pose already on the GPU: UpdateVerticesDevice.
 	bool UploadVertices(const float* vb, uint32_t numVerts)
 	{
 		if (!m_ctx) return setError("UploadVertices before Init");
