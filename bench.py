@@ -517,7 +517,10 @@ def main():
                        "kernel_ms_max_over_ranks": kmax, "rank_kernel_ms": rank_kernel_ms, "rank_ms_per_step": rank_wall_ms,
                        "rank_imbalance": max(rank_kernel_ms) / (sum(rank_kernel_ms) / len(rank_kernel_ms)) if min(rank_kernel_ms) > 0 else None,
                        "step_ms_rank0": stats_ms(per_step),
-                       "work_queue": ({"queued_bricks": st_run["plan_bricks"], "persistent_waves": st_run["plan_waves"],
+                       "work_queue": ({"queued_bricks": st_run["plan_bricks"], "workgroups_launched": st_run["plan_waves"],
+                                       "launch": ("one workgroup per slot of the kept queue, dealt out by the hardware (its lengths were read by a "
+                                                  "dxv_sync before the timed region; option dispatch)" if st_run["plan_waves"] >= st_run["plan_bricks"]
+                                                  else "persistent waves taking bricks from the queue's heads"),
                                        "built": "on the device inside the launch that needs it (option plan); the headline's steps keep it"}
                                       if st_run.get("plan_bricks") else None),
                        **extras},
@@ -525,7 +528,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, **({"traffic_note": traffic_note} if traffic_note else {}),
                          "stored_bytes_per_launch": stored_kept,
                          "achieved_on_stored_bytes": (stored_kept + scene_bytes) / (kernel_ms * 1e-3) / 1e9,
-                         "kernel": ("k_voxelize_queue" if st_run.get("plan_bricks") else "k_voxelize") if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
+                         "kernel": (("k_voxelize_listed" if st_run["plan_waves"] >= st_run["plan_bricks"] else "k_voxelize_queue") if st_run.get("plan_bricks") else "k_voxelize")
+                                   if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); a step that keeps "
                                  "its queue stores only its queued bricks (stored_bytes_per_launch; config.fresh_step stores all of it); the kernel "

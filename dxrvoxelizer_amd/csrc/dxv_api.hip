@@ -91,6 +91,8 @@ struct dxv_ctx {
         bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
         bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
         hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
+        uint32_t queueLenMax = 0;        // longest of the frame's eight queues, as last read by dxv_sync ...
+        uint64_t queueLenSig = 0;        // ... for the queue of this signature (clearSig); 0: not known
         hipEvent_t evEnd = nullptr;      // behind the frame's last launch, always recorded: what a refit on another stream waits for on the device
         bool usedLists = false;          // the frame's last launch went through the direction-space lists ...
         uint64_t listEpochUsed = 0;      // ... of this build (a build whose deferred check fails is withdrawn: settle_lists, sync_frame)
@@ -146,6 +148,9 @@ struct dxv_ctx {
     int optPlan = 1;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch, 2 = on every launch
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
+    int optDispatch = 1;             // a kept queue whose lengths the host knows: 0 = persistent waves all the same, 1 = one workgroup per
+                                     // queued brick dealt out by the hardware (-1 ... -10 % per launch, and back-to-back launches overlap
+                                     // their ends: profiles/r04/ab_dispatch_kept_queue.jsonl), 2 = that for partitions of up to 2^25 voxels only
     int optEvents = 1;               // bracket every launch with two HIP events (stats.voxelize_ms); 0: none (a caller timing its own loop)
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
@@ -754,8 +759,13 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             sig |= 1ull;
             const bool rebuild = c->optPlan == 2 || f.ptrExposed || f.clearSig != sig;
             hipEvent_t pe[2] = {f.evP0, f.evP1};
-            DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, fs));
+            // a queue launched again whose lengths an earlier dxv_sync has read: its size is known, the hardware can deal it out
+            // (option dispatch: 1 = whenever known, 2 = for partitions of up to 2^25 voxels)
+            uint32_t listed = 0;
+            if (!rebuild && f.queueLenSig == sig && (c->optDispatch == 1 || (c->optDispatch == 2 && voxels <= (1ull << 25)))) listed = f.queueLenMax;
+            DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, listed, fs));
             f.clearSig = f.ptrExposed ? 0 : sig;
+            if (rebuild) f.queueLenSig = 0;
             f.lastQueued = true; f.lastRebuilt = rebuild;
         } else DXV_HIP(c, launch_voxelize(p, c->optBrick, st, fs));
         if (p.lists) f.lastRedoParity = -1;                        // no column to run out of, nothing to redo
@@ -1167,7 +1177,12 @@ int sync_frame(dxv_ctx* c, uint32_t i)
             f.redo_rays = f.lastRedoParity < 0 ? 0u : words[1 + f.lastRedoParity];
             if (readQueue) {
                 f.plan_bricks = 0;
-                for (uint32_t x = 0; x < 8u; ++x) f.plan_bricks += hdr[queue_len_word(x)];
+                f.queueLenMax = 0;
+                for (uint32_t x = 0; x < 8u; ++x) {
+                    f.plan_bricks += hdr[queue_len_word(x)];
+                    if (hdr[queue_len_word(x)] > f.queueLenMax) f.queueLenMax = hdr[queue_len_word(x)];
+                }
+                f.queueLenSig = f.clearSig;                             // (the queue of this signature: 0 = none kept)
                 if (f.lastRebuilt) f.plan_ms = f.timed ? elapsed(f.evP0, f.evP1) : 0.0f;
             }
         }
@@ -1658,6 +1673,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
         if (value != 0 && (value < 16 || value > 4096 || (value & (value - 1)))) return fail(c, "option listres: %lld is not 0 or a power of two in [16, 4096]", (long long)value);
         if (c->optListRes != (int)value && sync_frames(c)) return 1;     // the next launch rebuilds the lists: nothing may still read them
         c->optListRes = (int)value;
+    } else if (!strcmp(key, "dispatch")) {
+        if (value < 0 || value > 2) return fail(c, "option dispatch: %lld not in {0,1,2}", (long long)value);
+        c->optDispatch = (int)value;
     } else if (!strcmp(key, "ablate")) {
 #if defined(DXV_ABLATE)
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8 && value != 16 && value != 18) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8,16,18}", (long long)value);

@@ -108,7 +108,7 @@ size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut);     // 32-bi
 hipError_t plan_build(const VoxelizeParams& p, hipStream_t s);          // header cleared + k_plan_bricks (p.queue, p.queueCap, p.mip set)
 // rebuild: grid cleared + queue built in front of the kernel; else only the queue heads are reset (same launch as before into the same buffers)
 // (planEvents: two events recorded around the queue build of a rebuilding launch, or NULL)
-hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, hipStream_t s);
+hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, uint32_t listedLen, hipStream_t s);
 // test hook: every voxel's first-step decision against the queue; bits: one per brick of the partition, out: 16 words
 hipError_t launch_plan_check(const VoxelizeParams& p, uint32_t* bits, unsigned long long* out, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack

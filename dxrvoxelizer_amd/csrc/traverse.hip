@@ -388,6 +388,59 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
 #endif
 }
 
+// The same brick body with one workgroup per queued brick, dispatched by the hardware: for a queue that is launched AGAIN and whose
+// eight lengths the host has read meanwhile (dxv_sync of an earlier launch of the same queue) -- the launch's size is then
+// known without a round trip of its own.  Workgroup b takes slot b / 8 of queue b % 8 (workgroups b and b + 8 share an XCD);
+// no heads, no adds, parameters in scalar registers from the start.  What it is for: short launches (a 256^3 grid, a rank's
+// share), whose few bricks per persistent wave leave the end of the launch ragged (option dispatch).
+template <bool TEXELS>
+__global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int32_t stack[16 * 64];
+    const uint32_t x = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
+    if (k >= len) return;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + k]);
+    const SceneView& sc = p.scene;
+    const uint32_t N = p.N, nz = p.nz;
+    const uint32_t bx = w & 1023u, by = (w >> 10) & 1023u, bz = w >> 20;
+    const uint32_t tid = threadIdx.x;
+    uint32_t ix = bx * 4u + (tid & 3u), iy = by * 4u + ((tid >> 2) & 3u), lz = bz * 4u + (tid >> 4);
+    const bool inside = ix < N && iy < N && lz < nz;
+    ix = ix < N ? ix : N - 1u; iy = iy < N ? iy : N - 1u; lz = lz < nz ? lz : nz - 1u;
+    const uint32_t iz = p.zBlock == nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
+    DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
+    if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) start.live = false;
+    Hit best;
+    float bestDet = 1.0f;
+    const StridedStack stk{stack + tid, 64};
+    trace_reference_dm_from<StridedStack, 0>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
+    uint32_t texel = 0;
+    const uint8_t occ = shade_reference<4, 0>(sc, r, best, bestDet, TEXELS ? &texel : nullptr);
+    if (TEXELS || (N & 3u) != 0u) {
+        if (inside) {
+            const size_t id = ((size_t)lz * N + iy) * N + ix;
+            if (TEXELS) p.texels[id] = texel;
+            if ((N & 3u) != 0u) p.grid[id] = occ;
+        }
+    }
+    if ((N & 3u) == 0u) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(occ != 0);
+        const uint32_t ry = by * 4u + (tid & 3u), rz = bz * 4u + ((tid >> 2) & 3u);
+        if (tid < 16u && rz < nz) {
+            const uint32_t nib = (uint32_t)(m >> (4u * tid)) & 15u;
+            *reinterpret_cast<uint32_t*>(p.grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;
+        }
+    }
+#else
+    (void)p;
+#endif
+}
+
 // persistent waves the device holds at once (occupancy of the kernel x compute units), a multiple of 8
 static uint32_t queue_waves(bool texels)
 {
@@ -406,10 +459,17 @@ static uint32_t queue_waves(bool texels)
 // rebuild: clear the grid and build the queue in front of the launch (a launch that may not rely on anything an earlier
 // launch left behind); else the caller vouches that the frame's grid and queue are those of the same launch made before
 // (same lists, partition and buffers: the kernel writes the same bricks every time) and only the queue heads are reset.
-hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, hipStream_t s)
+hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, uint32_t listedLen, hipStream_t s)
 {
     const VoxelizeParams& p = pin;
     hipError_t e;
+    if (!rebuild && listedLen) {
+        // the queue as it stands, one workgroup per slot of the longest of the eight queues and per queue
+        if (wavesOut) *wavesOut = 8u * listedLen;
+        if (p.texels) k_voxelize_listed<true><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p);
+        else k_voxelize_listed<false><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p);
+        return hipGetLastError();
+    }
     if (rebuild) {
         if ((e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s)) != hipSuccess) return e;
         if (p.texels && (e = hipMemsetAsync(p.texels, 0, (size_t)p.N * p.N * p.nz * 4, s)) != hipSuccess) return e;

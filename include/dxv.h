@@ -266,6 +266,10 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 counting pass says so (1, default: a mesh refitted every frame takes whichever is faster), or
  *                 always at the first (2); scenes whose lists would exceed 256 entries per triangle + 64 M or
  *                 65,535 entries in one texel keep the tree walk (stats.list_entries = 0)
+ *   dispatch 0|1|2  a launch through a KEPT work queue (plan = 1, same lists / partition / buffers as the frame's last launch)
+ *                 whose eight lengths a dxv_sync has read since it was built: one workgroup per queued brick dealt out by the
+ *                 hardware (1, default; 2: only for partitions of up to 2^25 voxels) instead of persistent waves (0).  The first
+ *                 launch of a queue, and every launch under plan = 2, does not know its size and uses the persistent waves.
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
  *   plists 0|1|2    parity rule through row lists of the (y, z) plane: 1 (default) from a scene's second parity launch,
  *                 2 from the first, 0 = always walk the tree; plistres 0|16..4096: texels per side of their grid

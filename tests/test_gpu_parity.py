@@ -1185,6 +1185,21 @@ def test_kept_memset_of_partial_launches(dxv, orc):
     v.close()
 
 
+def waves_persistent(v):
+    """persistent waves of a queue launch on this device (stats of a launch that cannot know its size: plan = 2)"""
+    w = v.__class__(0)
+    try:
+        w.set_option("lists", 2)
+        w.set_option("plan", 2)
+        import numpy as _np
+        tri = _np.array([[-.5, -.5, 0, 0, 0, 1], [.5, -.5, 0, 0, 0, 1], [0, .5, .1, 0, 0, 1]], _np.float32)
+        w.InitFromArrays(tri, _np.arange(3, dtype=_np.uint32))
+        w.Voxelize(32)
+        return w.stats()["plan_waves"]
+    finally:
+        w.close()
+
+
 @pytest.mark.gpu
 def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, hostcheck):
     """Lists kernel through the work queue (option plan: only bricks that can hold a live ray are run, decided per brick on
@@ -1198,6 +1213,7 @@ def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, host
     hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     v = dxv.Voxelizer(0)
     v.set_option("lists", 2)
+    exposed, grid_cap = False, 0
     for (vb, ib, _), sizes in ((bunny, (64, 50, 100, 256)), (dragon, (66, 128))):
         s = orc.Scene(vb, ib)
         v.InitFromArrays(vb, ib)
@@ -1206,17 +1222,29 @@ def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, host
             v.set_option("plan", 0)
             v.Voxelize(N)
             assert np.array_equal(v.Grid(), want) and v.stats()["plan_bricks"] == 0
-            for plan in (1, 2):
+            for plan, dispatch in ((1, 1), (1, 0), (2, 1)):
                 v.set_option("plan", plan)
+                v.set_option("dispatch", dispatch)
+                v.InitFromArrays(vb, ib)                                # (a new queue: its first launch does not know its size)
+                waves = []
                 for again in range(3):
                     v.Voxelize(N)
                     st = v.stats()
                     assert st["plan_bricks"] > 0 and st["plan_waves"] % 8 == 0 and st["plan_waves"] > 0
-                    assert np.array_equal(v.Grid(), want), (N, plan, again)
+                    assert np.array_equal(v.Grid(), want), (N, plan, dispatch, again)
+                    waves.append(st["plan_waves"])
+                # a kept queue whose lengths a sync has read is dealt out by the hardware, one workgroup per slot of the longest of
+                # the eight queues and per queue; a first launch, plan = 2 and dispatch = 0 use the persistent waves
+                # (a grid whose pointer the caller holds is cleared, and its queue rebuilt, in every launch: until it is reallocated)
+                if plan == 1 and dispatch == 1 and not (exposed and N ** 3 <= grid_cap):
+                    assert waves[0] == waves_persistent(v) and waves[1] == waves[2] != waves[0] and st["plan_bricks"] <= waves[1] <= 8 * st["plan_bricks"]
+                else:
+                    assert len(set(waves)) == 1
                 chk = v.plan_check()
                 assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == st["plan_bricks"], (N, chk)
                 assert chk["live_bricks"] <= chk["queued_bricks"]
             v.set_option("plan", 1)
+            exposed, grid_cap = True, max(grid_cap, N ** 3)
             assert hip.hipMemset(C.c_void_p(v.grid_device_ptr()), 1, N ** 3) == 0 and hip.hipDeviceSynchronize() == 0
             v.Voxelize(N)
             assert np.array_equal(v.Grid(), want), "the caller's bytes in bricks that are not queued"

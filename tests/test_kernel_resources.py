@@ -24,13 +24,14 @@ def test_default_kernels_do_not_spill_and_keep_full_occupancy(dxvlib):
     # through the work queue (k_voxelize_queue: the same brick body inside a loop)
     lists_box = [v for k, v in res.items() if "k_voxelizeINS_5BrickILi4ELi4ELi4EEELi16ELi0ELb0ELi4ELi0EEE" in k]
     lists_queue = [v for k, v in res.items() if "k_voxelize_queueILb0EEE" in k]
+    lists_listed = [v for k, v in res.items() if "k_voxelize_listedILb0EEE" in k]       # the same body, one workgroup per queued brick
     # (round 3: the scan loop loads its four entries from one address with immediate offsets -- 70 registers, seven waves per
     # SIMD, and 7 - 17 % faster than the 62-register loop that computed four clamped addresses; held to 64 registers the same
     # loop spills 20 bytes and loses: profiles/r03/ab_scan_loop_offsets_old_new_new64.txt.  Round 4: the persistent form keeps the
     # seven waves only because its loop holds nothing in vector registers through the body and reads the launch's parameters
     # anew for every brick -- written the obvious way it took 80 registers, 8 bytes of scratch and six waves)
-    assert len(lists_box) == 1 and len(lists_queue) == 1
-    for r in lists_box + lists_queue:
+    assert len(lists_box) == 1 and len(lists_queue) == 1 and len(lists_listed) == 1
+    for r in lists_box + lists_queue + lists_listed:
         assert r["scratch"] == 0 and r["vgprs"] <= 72 and r["occupancy"] >= 7 and r["lds"] == 16 * 64 * 4
     assert len(default_ref) == 1 and len(binary_ref) == 1 and len(default_par) == 1 and len(block_par) == 1
     assert block_par[0]["scratch"] == 0 and block_par[0]["occupancy"] >= 6

@@ -29,7 +29,9 @@ def main():
         if not os.path.exists(p):
             continue
         s = json.load(open(p))
-        k = s.get("k_voxelize_queue") or s.get("k_voxelize")
+        k = s.get("k_voxelize_listed") or s.get("k_voxelize_queue") or s.get("k_voxelize")
+        name = "k_voxelize_listed<false> (direction-space lists, one workgroup per brick of the kept work queue)" if "k_voxelize_listed" in s else \
+               "k_voxelize_queue<false> (direction-space lists, persistent waves over the work queue)"
         if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
             continue
         fetch_kb, write_kb = k["FETCH_SIZE"], k["WRITE_SIZE"]
@@ -39,7 +41,7 @@ def main():
                       "lists kernel over its work queue (kept queue: the steps bench.py times)" + ("" if tag == "torus1m" else f" on rank 0's share of the block-cyclic partition ({tag[4:]} ranks, one GPU)") +
                       "; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B; an upper estimate for gathers); "
                       f"uncorrected total = {int((fetch_kb + write_kb) * 1024)} B",
-            "kernel": "k_voxelize_queue<false> (direction-space lists, persistent waves over the work queue)", "round": 4,
+            "kernel": name, "round": 4,
             "source_hash": source_hash()}
     with open(tj, "w") as fh:
         json.dump(traffic, fh, indent=1)

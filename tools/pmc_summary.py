@@ -9,8 +9,9 @@ from collections import defaultdict
 
 
 def kind(name):
-    """the lists kernel through the work queue (persistent waves) and the kernels launched over a brick box are different kernels"""
-    return "k_voxelize_queue" if "k_voxelize_queue" in name else "k_voxelize"
+    """the lists kernel through the work queue -- persistent waves (a queue's first launch, plan = 2) or one workgroup per queued brick
+    (a kept queue of known size) -- and the kernels launched over a brick box are different kernels"""
+    return "k_voxelize_queue" if "k_voxelize_queue" in name else "k_voxelize_listed" if "k_voxelize_listed" in name else "k_voxelize"
 
 
 def main():
@@ -46,7 +47,7 @@ def main():
                     m["per_wave"][n + "_frac"] = round(m[n] / m["SQ_WAVE_CYCLES"], 3)
         # persistent waves: per BRICK is the figure that compares with a wave of the brick-box launch (PMC_BRICKS: queued bricks of the launch)
         bricks = float(os.environ.get("PMC_BRICKS", "0") or 0)
-        if k == "k_voxelize_queue" and bricks:
+        if k in ("k_voxelize_queue", "k_voxelize_listed") and bricks:
             m["bricks"] = bricks
             m["per_brick"] = {n: round(m[n] / bricks, 1) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS",
                                                                     "TCP_TOTAL_CACHE_ACCESSES_sum") if n in m}

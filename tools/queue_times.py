@@ -16,6 +16,7 @@ mesh = sys.argv[1] if len(sys.argv) > 1 else "torus1m"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 v = dxv.Voxelizer(0)
 v.set_option("lists", 2)
+v.set_option("dispatch", 0)                               # (the stamps are the persistent waves')
 for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 else "").split(",")):
     v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 vb, ib, _ = make_mesh(mesh)
