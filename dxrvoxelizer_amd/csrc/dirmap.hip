@@ -32,10 +32,11 @@ __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restric
             DirFootprint f;
             uint32_t c = 0;
             if (dm_footprint(tp, face, f)) {
-                const DirRecord e = dm_record(f);
-                rec[i] = e;
+                DirRecord e = dm_record(f);
                 uint32_t i0, i1, j0, j1;
                 if (dm_rect(e, R, i0, i1, j0, j1)) c = (i1 - i0 + 1u) * (j1 - j0 + 1u);
+                dm_record_on_map(e, c);
+                rec[i] = e;
             }
             counts[i] = c;
             n += c;
@@ -119,15 +120,42 @@ __global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restric
                                                       const uint32_t* __restrict__ offsets, uint32_t T, uint32_t R, uint64_t* __restrict__ keys)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= 6u * T || counts[i] == 0u) return;                        // (no record behind a count of 0)
-    const uint32_t tri = i / 6u, face = i % 6u;
-    uint32_t i0, i1, j0, j1;
-    if (!dm_rect(rec[i], R, i0, i1, j0, j1)) return;
-    uint64_t* out = keys + offsets[i];
     const DirKeyLayout lay = dm_key_layout(R);
-    const uint16_t r1 = (uint16_t)rec[i].r1;
-    for (uint32_t j = j0; j <= j1; ++j)
-        for (uint32_t x = i0; x <= i1; ++x) *out++ = dm_key(lay, (face * R + j) * R + x, r1, tri);
+    uint32_t i0 = 0, i1 = 0, j0 = 0, j1 = 0;
+    const bool valid = i < 6u * T && counts[i] != 0u && dm_rect(rec[i], R, i0, i1, j0, j1);     // (no record behind a count of 0)
+    const uint32_t area = valid ? (i1 - i0 + 1u) * (j1 - j0 + 1u) : 0u;
+    // footprints of many texels (a triangle near the centre, the triangles of a coarse mesh) are written by the whole wave, 64
+    // texels at a time: one thread walking thousands of texels, each with its own radial range, was the build's tail
+    const bool big = area > 32u;
+    if (valid && !big) {
+        const uint32_t tri = i / 6u, face = i % 6u;
+        uint64_t* out = keys + offsets[i];
+        const DirRecord rc = rec[i];
+        for (uint32_t j = j0; j <= j1; ++j)
+            for (uint32_t x = i0; x <= i1; ++x) {
+                uint32_t r0h, r1h;                                      // (the entry's own far radius: the record cut to this texel)
+                dm_local_radial(rc, R, x, j, r0h, r1h);
+                *out++ = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
+            }
+    }
+    unsigned long long m = __ballot(big);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)i, src);
+        const DirRecord rc = rec[k];
+        uint32_t a0, a1, b0, b1;
+        (void)dm_rect(rc, R, a0, a1, b0, b1);
+        const uint32_t w = a1 - a0 + 1u, n = w * (b1 - b0 + 1u), tri = k / 6u, face = k % 6u;
+        uint64_t* out = keys + offsets[k];
+        for (uint32_t idx = lane; idx < n; idx += 64u) {
+            const uint32_t x = a0 + idx % w, j = b0 + idx / w;
+            uint32_t r0h, r1h;
+            dm_local_radial(rc, R, x, j, r0h, r1h);
+            out[idx] = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
+        }
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restrict__ keys, uint32_t n, const DirRecord* __restrict__ rec,

@@ -50,11 +50,11 @@ constexpr uint32_t kDmCells = 128u;                 // cells per texel side (7 b
 // the per-texel entries are cut.
 struct alignas(16) DirRecord {
     float u0, u1, v0, v1;      // footprint box in face coordinates, rounded outward; u0 > u1: no footprint
-    uint32_t r0, r1;           // radial range, halfs rounded outward
-    uint32_t hasTri;           // 1: px / py hold the projected triangle (all three vertices in front of the face plane)
+    uint32_t rr;               // radial range of the whole footprint, halfs rounded outward: r0 | r1 << 16
+    uint32_t hasTri;           // bit 0: px / py / pw hold the projected triangle (all three vertices in front of the face plane); bit 1: dm_record_on_map
     float pad;                 // dilation of the projected triangle in face coordinates
     float px[3], py[3];        // projected vertices
-    uint32_t spare[2];
+    float pw[3];               // 1 / depth of the vertices along the face axis: linear over the projected triangle's plane (dm_local_radial)
 };
 static_assert(sizeof(DirRecord) == 64, "record layout");
 
@@ -305,7 +305,7 @@ DXV_HD float dm_down(float x) { return -dm_up(-x); }
 // Footprint of triangle tp on one face, or false when it cannot be seen through that face.
 // Builder side only (one call per triangle and face): double precision, nothing canonical here --
 // the result only has to be a superset.
-struct DirFootprint { float u0, u1, v0, v1, r0, r1, pad, px[3], py[3]; bool hasTri; };
+struct DirFootprint { float u0, u1, v0, v1, r0, r1, pad, px[3], py[3], pw[3]; bool hasTri; };
 
 // The polygon a face sees of a triangle (its vertices in the face's own coordinates b, c, +-a) -> footprint.  FIXED = 3: the
 // triangle itself, whole inside the face's frustum -- by far the common case; all loops have constant bounds then and the
@@ -325,7 +325,7 @@ DXV_HD void dm_footprint_finish(const double (*poly)[3], int n, const double (*t
     const double full = kDmFrustum + 1.0 / 256.0;
     double u0 = -full, u1 = full, v0 = -full, v1 = full;
     out.hasTri = false; out.pad = 0.0f;
-    for (int i = 0; i < 3; ++i) out.px[i] = out.py[i] = 0.0f;
+    for (int i = 0; i < 3; ++i) out.px[i] = out.py[i] = out.pw[i] = 0.0f;
     if (dmin >= 64.0 * delta) {
         u0 = v0 = 1e300; u1 = v1 = -1e300;
         for (int i = 0; i < m; ++i) {
@@ -345,7 +345,7 @@ DXV_HD void dm_footprint_finish(const double (*poly)[3], int n, const double (*t
         const double d0 = tri[0][2], d1 = tri[1][2], d2 = tri[2][2];           // (tri: the unclipped triangle in the face's coordinates)
         if (d0 >= 64.0 * delta && d1 >= 64.0 * delta && d2 >= 64.0 * delta) {
             const double dd[3] = {d0, d1, d2};
-            for (int i = 0; i < 3; ++i) { out.px[i] = (float)(tri[i][0] / dd[i]); out.py[i] = (float)(tri[i][1] / dd[i]); }
+            for (int i = 0; i < 3; ++i) { out.px[i] = (float)(tri[i][0] / dd[i]); out.py[i] = (float)(tri[i][1] / dd[i]); out.pw[i] = (float)(1.0 / dd[i]); }
             out.hasTri = true;
             out.pad = (float)(pad + 1e-6);                      // (+ the rounding of the stored vertices)
         }
@@ -476,28 +476,22 @@ DXV_HD bool dm_footprint(const TriPos& tp, uint32_t face, DirFootprint& out)
 DXV_HD DirRecord dm_record(const DirFootprint& f)
 {
     DirRecord r;
-    r.spare[0] = r.spare[1] = 0u;
     r.u0 = f.u0; r.u1 = f.u1; r.v0 = f.v0; r.v1 = f.v1;
-    r.r0 = half_down(f.r0); r.r1 = half_up(f.r1);
+    r.rr = (uint32_t)half_down(f.r0) | ((uint32_t)half_up(f.r1) << 16);
     r.hasTri = f.hasTri ? 1u : 0u; r.pad = f.pad;
-    for (int i = 0; i < 3; ++i) { r.px[i] = f.px[i]; r.py[i] = f.py[i]; }
+    for (int i = 0; i < 3; ++i) { r.px[i] = f.px[i]; r.py[i] = f.py[i]; r.pw[i] = f.pw[i]; }
     return r;
 }
 DXV_HD DirRecord dm_record(const TriPos& tp, uint32_t face)
 {
-    DirRecord r;
     DirFootprint f;
-    r.spare[0] = r.spare[1] = 0u;
     if (!dm_footprint(tp, face, f)) {
-        r.u0 = 1.0f; r.u1 = 0.0f; r.v0 = 1.0f; r.v1 = 0.0f; r.r0 = r.r1 = 0u; r.hasTri = 0u; r.pad = 0.0f;
-        for (int i = 0; i < 3; ++i) r.px[i] = r.py[i] = 0.0f;
+        DirRecord r;
+        r.u0 = 1.0f; r.u1 = 0.0f; r.v0 = 1.0f; r.v1 = 0.0f; r.rr = 0u; r.hasTri = 0u; r.pad = 0.0f;
+        for (int i = 0; i < 3; ++i) r.px[i] = r.py[i] = r.pw[i] = 0.0f;
         return r;
     }
-    r.u0 = f.u0; r.u1 = f.u1; r.v0 = f.v0; r.v1 = f.v1;
-    r.r0 = half_down(f.r0); r.r1 = half_up(f.r1);
-    r.hasTri = f.hasTri ? 1u : 0u; r.pad = f.pad;
-    for (int i = 0; i < 3; ++i) { r.px[i] = f.px[i]; r.py[i] = f.py[i]; }
-    return r;
+    return dm_record(f);
 }
 
 // texel rectangle [i0, i1] x [j0, j1] of a record (false: none)
@@ -507,6 +501,76 @@ DXV_HD bool dm_rect(const DirRecord& e, uint32_t R, uint32_t& i0, uint32_t& i1, 
     if (e.u1 < -1.0f || e.u0 > 1.0f || e.v1 < -1.0f || e.v0 > 1.0f) return false;      // rays only have |u|, |v| <= 1
     i0 = dm_texel(e.u0, R); i1 = dm_texel(e.u1, R); j0 = dm_texel(e.v0, R); j1 = dm_texel(e.v1, R);
     return true;
+}
+
+// Radial range of a record INSIDE texel (i, j), as halfs rounded outward: a triangle that spans several texels (every triangle of
+// a coarse mesh, of a soup) is radially much thinner over one of them than as a whole, and the radial range is what culls an entry
+// before its triangle is fetched, what orders a texel's list and what lets a scan stop behind a hit.
+// 1 / depth along the face axis is LINEAR in the face coordinates (u, v) over the triangle's plane: w(u, v) = pw0 + gu (u - px0)
+// + gv (v - py0), its extremes over a rectangle lie at the corners, and a point of the plane in direction (u, v) has radius
+// sqrt(1 + u^2 + v^2) / w(u, v).  The rectangle is the texel cut by the record's box, widened by the record's pad (the rays of the
+// texel, the dilated triangle's outline); the plane extrapolated beyond the triangle only widens the range.  Points within the
+// dilation delta of the plane lie within delta rho / |d| of it along a ray (d: the plane's distance from the centre, 1 / d^2 =
+// w(0, 0)^2 + gu^2 + gv^2): taken twice, plus the whole footprint's own margins.  The result is cut with the whole footprint's
+// range; records without a projected triangle, seen edge-on, or whose plane passes the centre keep that range.
+constexpr uint32_t kDmLocalRadialFrom = 12u;         // footprints of more texels than this get per-texel radial ranges
+// hasTri bit 1: the record's footprint covers more than kDmLocalRadialFrom texels of the map the lists are built on (`texels`: the
+// area of its rectangle there) and has a projected triangle -- set by whoever makes the record for a map (k_dm_records, hostcheck)
+DXV_HD void dm_record_on_map(DirRecord& rec, uint32_t texels)
+{
+    if ((rec.hasTri & 1u) && texels > kDmLocalRadialFrom) rec.hasTri |= 2u;
+}
+DXV_HD void dm_local_radial(const DirRecord& rec, uint32_t R, uint32_t i, uint32_t j, uint32_t& r0h, uint32_t& r1h)
+{
+    r0h = rec.rr & 0xffffu; r1h = rec.rr >> 16;
+    // (a footprint of a few texels is hardly thinner over one of them: the whole range, for nothing -- every record of a mesh whose
+    // triangles are as small as the texels ends here; the flag is set where the record's rectangle on this map is known: dm_record_on_map)
+    if (!(rec.hasTri & 2u)) return;
+    // (single precision throughout -- this runs once per entry in two passes of the build -- with every rounding paid for below: the fit
+    // of a triangle seen within 1e-3 of edge-on is not trusted at all, the fitted w carries 2e-3 of its own variation over the
+    // rectangle and 1e-5 of its size, the radii 3e-5 of theirs.  Plain IEEE operations, no contraction: host and device agree.)
+    const float ax = rec.px[1] - rec.px[0], ay = rec.py[1] - rec.py[0], aw = rec.pw[1] - rec.pw[0];
+    const float bx = rec.px[2] - rec.px[0], by = rec.py[2] - rec.py[0], bw = rec.pw[2] - rec.pw[0];
+    const float det = ax * by - ay * bx;
+    const float scale = (ax * ax + ay * ay) + (bx * bx + by * by);
+    if (!(__builtin_fabsf(det) > 1e-3f * scale) || !(scale > 1e-24f)) return;   // seen (nearly) edge-on, or degenerate: no plane to speak of
+    const float gu = (aw * by - bw * ay) / det, gv = (bw * ax - aw * bx) / det;
+    const float w00 = rec.pw[0] - gu * rec.px[0] - gv * rec.py[0];
+    const float invd = __builtin_sqrtf(w00 * w00 + gu * gu + gv * gv);
+    if (!(invd * kDmDelta < 0.125f)) return;                                    // the plane passes (nearly) through the centre
+    const float eps = rec.pad + 4e-6f;
+    float ua = 2.0f * (float)i / (float)R - 1.0f, ub = 2.0f * (float)(i + 1u) / (float)R - 1.0f;
+    float va = 2.0f * (float)j / (float)R - 1.0f, vb = 2.0f * (float)(j + 1u) / (float)R - 1.0f;
+    if (rec.u0 > ua) ua = rec.u0;
+    if (rec.u1 < ub) ub = rec.u1;
+    if (rec.v0 > va) va = rec.v0;
+    if (rec.v1 < vb) vb = rec.v1;
+    ua -= eps; ub += eps; va -= eps; vb += eps;
+    if (!(ua <= ub && va <= vb)) return;
+    const float w0 = w00 + gu * ua + gv * va, w1 = w00 + gu * ub + gv * va, w2 = w00 + gu * ua + gv * vb, w3 = w00 + gu * ub + gv * vb;
+    float wmin = w0 < w1 ? w0 : w1, wmax = w0 > w1 ? w0 : w1;
+    if (w2 < wmin) wmin = w2;
+    if (w3 < wmin) wmin = w3;
+    if (w2 > wmax) wmax = w2;
+    if (w3 > wmax) wmax = w3;
+    const float terms = __builtin_fabsf(w00) + __builtin_fabsf(gu) * (__builtin_fabsf(ua) > __builtin_fabsf(ub) ? __builtin_fabsf(ua) : __builtin_fabsf(ub)) +
+                        __builtin_fabsf(gv) * (__builtin_fabsf(va) > __builtin_fabsf(vb) ? __builtin_fabsf(va) : __builtin_fabsf(vb));
+    const float slack = 2e-3f * (wmax - wmin) + 1e-5f * terms;
+    wmin -= slack; wmax += slack;
+    const float ulo = ua > 0.0f ? ua : ub < 0.0f ? -ub : 0.0f, vlo = va > 0.0f ? va : vb < 0.0f ? -vb : 0.0f;
+    const float uhi = -ua > ub ? -ua : ub, vhi = -va > vb ? -va : vb;
+    const float thick = 2.0f * kDmDelta * invd + 3e-5f;
+    if (wmax > 0.0f) {
+        float rmin = __builtin_sqrtf(1.0f + ulo * ulo + vlo * vlo) / wmax;
+        rmin = rmin * (1.0f - thick) - 4.0f * kDmDelta;
+        if (rmin > 0.0f) { const uint32_t h = half_down(rmin); if (h > r0h) r0h = h; }
+    }
+    if (wmin > 1e-6f) {
+        float rmax = __builtin_sqrtf(1.0f + uhi * uhi + vhi * vhi) / wmin;
+        rmax = rmax * (1.0f + thick) + 4.0f * kDmDelta;
+        if (rmax < 60000.0f) { const uint32_t h = half_up(rmax); if (h < r1h) r1h = h; }
+    }
+    if (r0h > r1h) r0h = r1h;                                                   // (cannot happen for a range that holds a point; keeps the words ordered)
 }
 
 // The entry of a record in texel (i, j) of its rectangle: the box cut to the texel in local cells, the radial word, and
@@ -521,7 +585,9 @@ DXV_HD DirEntry dm_local_entry(const DirRecord& rec, uint32_t R, uint32_t i, uin
 {
     DirEntry e;
     e.tri = tri;
-    e.rr = ((0x7fffu - rec.r0) | (rec.r1 << 16)) | 0x80008000u;
+    uint32_t r0h, r1h;
+    dm_local_radial(rec, R, i, j, r0h, r1h);
+    e.rr = ((0x7fffu - r0h) | (r1h << 16)) | 0x80008000u;
     uint32_t t0, c0, t1, c1, x0, x1, y0, y1;
     dm_local(rec.u0, R, t0, c0); dm_local(rec.u1, R, t1, c1);
     x0 = t0 < i ? 0u : c0; x1 = t1 > i ? kDmCells - 1u : c1;
@@ -529,7 +595,7 @@ DXV_HD DirEntry dm_local_entry(const DirRecord& rec, uint32_t R, uint32_t i, uin
     y0 = t0 < j ? 0u : c0; y1 = t1 > j ? kDmCells - 1u : c1;
     e.box = x0 | (y0 << 8) | ((kDmCells - 1u - x1) << 16) | ((kDmCells - 1u - y1) << 24);
     e.edge = 0u;
-    if (!rec.hasTri) return e;
+    if (!(rec.hasTri & 1u)) return e;
     const double area2 = ((double)rec.px[1] - rec.px[0]) * ((double)rec.py[2] - rec.py[0]) - ((double)rec.py[1] - rec.py[0]) * ((double)rec.px[2] - rec.px[0]);
     if (!(__builtin_fabs(area2) > 1e-14)) return e;                     // seen edge-on: the box has to do
     const double sgn = area2 > 0.0 ? 1.0 : -1.0;

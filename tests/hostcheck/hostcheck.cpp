@@ -130,11 +130,18 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
     const DirKeyLayout lay = dm_key_layout(R);
     for (uint32_t t = 0; t < s->T; ++t)
         for (uint32_t f = 0; f < 6; ++f) {
-            const DirRecord e = rec[(size_t)t * 6 + f] = dm_record(s->triPos[t], f);
+            DirRecord e = dm_record(s->triPos[t], f);
             uint32_t i0, i1, j0, j1;
-            if (!dm_rect(e, R, i0, i1, j0, j1)) continue;
+            const bool seen = dm_rect(e, R, i0, i1, j0, j1);
+            if (seen) dm_record_on_map(e, (i1 - i0 + 1u) * (j1 - j0 + 1u));
+            rec[(size_t)t * 6 + f] = e;
+            if (!seen) continue;
             for (uint32_t j = j0; j <= j1; ++j)
-                for (uint32_t i = i0; i <= i1; ++i) keys.push_back(dm_key(lay, (f * R + j) * R + i, (uint16_t)e.r1, t));
+                for (uint32_t i = i0; i <= i1; ++i) {
+                    uint32_t r0h, r1h;
+                    dm_local_radial(e, R, i, j, r0h, r1h);
+                    keys.push_back(dm_key(lay, (f * R + j) * R + i, (uint16_t)r1h, t));
+                }
         }
     std::sort(keys.begin(), keys.end());
     s->dmR = R;
@@ -148,8 +155,8 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
         if (i == 0 || dm_key_cell(lay, keys[i - 1]) != cell) s->dmCells[cell].begin = (uint32_t)i;
         if (s->dmCells[cell].count == 0xffffu) return ~0ull;             // does not fit the 16-bit count
         s->dmCells[cell].count++;
-        s->dmCells[cell].r1max = (uint16_t)rc.r1;
-        const uint32_t th = half_up(half_bits_to_float(rc.r1) - half_bits_to_float(rc.r0));
+        s->dmCells[cell].r1max = (uint16_t)((s->dmEntries[i].rr >> 16) & 0x7fffu);
+        const uint32_t th = half_up(dm_entry_r1(s->dmEntries[i]) - dm_entry_r0(s->dmEntries[i]));
         if (th > s->dmCells[cell].thick) s->dmCells[cell].thick = (uint16_t)th;
     }
     for (DirCell& cell : s->dmCells) {

