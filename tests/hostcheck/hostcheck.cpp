@@ -250,6 +250,23 @@ __attribute__((visibility("default"))) int hc_dm_footprint(const float* tri, uin
     out[0] = f.u0; out[1] = f.u1; out[2] = f.v0; out[3] = f.v1; out[4] = f.r0; out[5] = f.r1;
     return 1;
 }
+// dm_local_radial of one triangle's record on one face and map, for texel (i, j): out = r0, r1 of the whole footprint and of the texel
+// (as floats); returns 0 when the face does not see the triangle or the texel lies outside its rectangle, 2 when the record gets
+// per-texel ranges on this map (footprints of many texels), else 1
+__attribute__((visibility("default"))) int hc_dm_local_radial(const float* tri, uint32_t face, uint32_t R, uint32_t i, uint32_t j, float* out)
+{
+    TriPos tp;
+    tp.v0 = {tri[0], tri[1], tri[2], 0.0f}; tp.v1 = {tri[3], tri[4], tri[5], 0.0f}; tp.v2 = {tri[6], tri[7], tri[8], 0.0f};
+    DirRecord rec = dm_record(tp, face);
+    uint32_t i0, i1, j0, j1;
+    if (!dm_rect(rec, R, i0, i1, j0, j1) || i < i0 || i > i1 || j < j0 || j > j1) return 0;
+    dm_record_on_map(rec, (i1 - i0 + 1u) * (j1 - j0 + 1u));
+    uint32_t r0h, r1h;
+    dm_local_radial(rec, R, i, j, r0h, r1h);
+    out[0] = half_to_float((uint16_t)(rec.rr & 0xffffu)); out[1] = half_to_float((uint16_t)(rec.rr >> 16));
+    out[2] = half_to_float((uint16_t)r0h); out[3] = half_to_float((uint16_t)r1h);
+    return (rec.hasTri & 2u) ? 2 : 1;
+}
 __attribute__((visibility("default"))) uint32_t hc_normal_class(const float* tri, const float* nrm)
 {
     return normal_class(F4{tri[0], tri[1], tri[2], 0}, F4{tri[3], tri[4], tri[5], 0}, F4{tri[6], tri[7], tri[8], 0},

@@ -297,6 +297,60 @@ def test_footprints_contain_every_point_of_the_triangle(hostcheck):
     assert checked > 150000
 
 
+def test_radial_range_per_texel_holds_every_point_of_the_triangle_there(hostcheck):
+    """dm_local_radial (dxv_dirmap.h): the radial range of an entry cut to its texel.  Points of the triangle whose direction
+    falls into texel (i, j) of a face must have their radius inside that texel's range -- for big, small, steep, nearly
+    edge-on and near-centre triangles, on coarse and fine maps; and the cut must be worth something (on big footprints the
+    mean range shrinks a lot)."""
+    import ctypes as C
+    L = hostcheck.lib
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
+    L.hc_dm_local_radial.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
+    rng = np.random.default_rng(515)
+    tris = list(rng.uniform(-1, 1, size=(120, 3, 3)).astype(np.float32))                       # big
+    c = rng.uniform(-0.9, 0.9, size=(120, 1, 3))
+    tris += list((c + rng.uniform(-0.15, 0.15, size=(120, 3, 3))).astype(np.float32))         # a few texels
+    d = rng.normal(size=(60, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    for k in range(60):                                                                        # nearly edge-on: two vertices almost on one ray
+        a = d[k] * rng.uniform(0.2, 0.5); b = d[k] * rng.uniform(0.6, 0.95) + rng.normal(size=3) * 1e-3
+        tris.append(np.array([a, b, a + rng.normal(size=3) * 0.2], np.float32))
+    tris += list((rng.uniform(-1, 1, size=(40, 3, 3)) * np.array([1, 1, 0.02])).astype(np.float32))   # planes near the centre
+    w = rng.uniform(0, 1, size=(4000, 2))
+    w = w[w.sum(1) <= 1.0]
+    out = np.zeros(4, np.float32)
+    checked = cut = 0
+    whole = local = 0.0
+    for R in (32, 256):
+        for t in tris:
+            pts = t[0].astype(np.float64) * (1 - w.sum(1))[:, None] + t[1].astype(np.float64) * w[:, :1] + t[2].astype(np.float64) * w[:, 1:]
+            pts = pts[np.abs(pts).max(1) > 1e-2]
+            a = np.abs(pts).argmax(1)
+            ax = pts[np.arange(len(pts)), a]
+            face = 2 * a + (ax < 0)
+            u = pts[np.arange(len(pts)), (a + 1) % 3] / np.abs(ax)
+            v = pts[np.arange(len(pts)), (a + 2) % 3] / np.abs(ax)
+            rad = np.linalg.norm(pts, axis=1)
+            ti = np.clip(((u + 1) * 0.5 * R).astype(int), 0, R - 1)
+            tj = np.clip(((v + 1) * 0.5 * R).astype(int), 0, R - 1)
+            # (points within 1e-6 of a texel border may belong to the neighbour: the builder and the kernel use float arithmetic)
+            fu, fv = (u + 1) * 0.5 * R - ti, (v + 1) * 0.5 * R - tj
+            inner = (fu > 1e-3) & (fu < 1 - 1e-3) & (fv > 1e-3) & (fv < 1 - 1e-3)
+            cells = {}
+            for k in np.nonzero(inner)[0][:600]:
+                cells.setdefault((int(face[k]), int(ti[k]), int(tj[k])), []).append(rad[k])
+            for (f, i, j), rs in cells.items():
+                kind = L.hc_dm_local_radial(np.ascontiguousarray(t.reshape(-1)), f, R, i, j, out)
+                assert kind != 0, (t.tolist(), f, i, j)
+                g0, g1, l0, l1 = (float(x) for x in out)
+                assert g0 <= l0 <= l1 <= g1
+                assert l0 <= min(rs) and max(rs) <= l1, (t.tolist(), R, f, i, j, (g0, g1), (l0, l1), (min(rs), max(rs)))
+                checked += len(rs)
+                if kind == 2:
+                    cut += 1; whole += g1 - g0; local += l1 - l0
+    assert checked > 100000 and cut > 5000
+    assert local < 0.5 * whole, (local, whole)           # over footprints of many texels the ranges shrink by more than half on average
+
+
 def frustum_corner_case():
     """Known-answer case of the round-2 soak failure (seed 77001): a triangle whose edge runs through a frustum corner, hit
     by the ray of voxel (63, 54, 45) at 96^3 at radius 0.3692, next to the foot of the perpendicular from the grid centre
