@@ -73,7 +73,8 @@ def main():
                     "subbox": int(rng.integers(0, 2)), "morton": int(rng.integers(0, 2)),
                     "lists": int(rng.integers(0, 3)), "listres": int(rng.choice([0, 0, 16, 64, 512, 2048])),
                     "plists": int(rng.integers(0, 3)), "plistres": int(rng.choice([0, 0, 16, 128, 1024])),
-                    "plan": int(rng.integers(0, 3)), "queuewaves": int(rng.choice([0, 0, 8, 64, 1000]))}
+                    "plan": int(rng.integers(0, 3)), "queuewaves": int(rng.choice([0, 0, 8, 64, 1000])),
+                    "dispatch": int(rng.choice([1, 1, 0, 2]))}
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))
