@@ -34,8 +34,17 @@ __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restric
             if (dm_footprint(tp, face, f)) {
                 DirRecord e = dm_record(f);
                 uint32_t i0, i1, j0, j1;
-                if (dm_rect(e, R, i0, i1, j0, j1)) c = (i1 - i0 + 1u) * (j1 - j0 + 1u);
-                dm_record_on_map(e, c);
+                if (dm_rect(e, R, i0, i1, j0, j1)) {
+                    c = (i1 - i0 + 1u) * (j1 - j0 + 1u);
+                    dm_record_on_map(e, c);                             // (by the rectangle's area, like every other threshold of the record)
+                    // texels wholly outside an edge of the projected triangle get no entry (dm_texel_outside: k_dm_emit skips the same ones)
+                    const DirTexelTest tt = dm_texel_test(e, c);
+                    if (tt.on) {
+                        c = 0;
+                        for (uint32_t j = j0; j <= j1; ++j)
+                            for (uint32_t x = i0; x <= i1; ++x) c += dm_texel_outside(tt, R, x, j) ? 0u : 1u;
+                    }
+                }
                 rec[i] = e;
             }
             counts[i] = c;
@@ -131,8 +140,10 @@ __global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restric
         const uint32_t tri = i / 6u, face = i % 6u;
         uint64_t* out = keys + offsets[i];
         const DirRecord rc = rec[i];
+        const DirTexelTest tt = dm_texel_test(rc, area);
         for (uint32_t j = j0; j <= j1; ++j)
             for (uint32_t x = i0; x <= i1; ++x) {
+                if (dm_texel_outside(tt, R, x, j)) continue;            // (not counted either: k_dm_records)
                 uint32_t r0h, r1h;                                      // (the entry's own far radius: the record cut to this texel)
                 dm_local_radial(rc, R, x, j, r0h, r1h);
                 *out++ = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
@@ -149,11 +160,19 @@ __global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restric
         (void)dm_rect(rc, R, a0, a1, b0, b1);
         const uint32_t w = a1 - a0 + 1u, n = w * (b1 - b0 + 1u), tri = k / 6u, face = k % 6u;
         uint64_t* out = keys + offsets[k];
-        for (uint32_t idx = lane; idx < n; idx += 64u) {
+        const DirTexelTest tt = dm_texel_test(rc, n);
+        uint32_t base = 0;                                              // texels with an entry so far (wave-uniform)
+        for (uint32_t first = 0; first < n; first += 64u) {
+            const uint32_t idx = first + lane;
             const uint32_t x = a0 + idx % w, j = b0 + idx / w;
-            uint32_t r0h, r1h;
-            dm_local_radial(rc, R, x, j, r0h, r1h);
-            out[idx] = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
+            const bool keep = idx < n && !dm_texel_outside(tt, R, x, j);
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                uint32_t r0h, r1h;
+                dm_local_radial(rc, R, x, j, r0h, r1h);
+                out[base + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
+            }
+            base += (uint32_t)__builtin_popcountll(km);
         }
     }
 }

@@ -114,8 +114,10 @@ struct dxv_ctx {
     int optLists = 1;                // reference rule through the lists (-40...-60 % against the tree walk, profiles/r01/final/ab_lists.jsonl):
                                      // 1 = from a scene's second launch on (from the first when that launch is large: build_lists), 2 = from the first, 0 = tree walk
     int optListRes = 0;              // texels per face side; 0 = by triangle count (list_resolution)
-    uint32_t listResFloor = 0;       // automatic resolution: not below this (512 once the scene has been launched at 1024^3 or beyond:
-    bool listFloorTried = false;     // a texel should stay about two voxels wide -- dragon x9 at 1024^3: 2.82 -> 2.48 ms)
+    uint32_t listResFloor = 0;       // automatic resolution: not below this (512 once a scene of 20 k triangles or more that was not refitted
+    bool listFloorTried = false;     // is launched AGAIN: a static scene -- the finer map is 10 - 20 % faster at every grid size since texels
+                                     // outside a triangle's outline get no entry, and costs a build of 1.5 - 2 x)
+    bool refitted = false;           // dxv_refit has run since dxv_build: the mesh is being animated, its lists are built for one launch
     float listMs = 0.0f;
     uint8_t *dListScratchA = nullptr, *dListScratchB = nullptr;   // scratch of the list build, kept between builds (a refit rebuilds them)
     size_t listScratchACap = 0, listScratchBCap = 0;
@@ -491,7 +493,11 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels,
         const double gainMs = (double)firstLaunchVoxels * 1e-8 * depth, buildMs = 0.1 + 0.15e-6 * (double)total;
         if (gainMs < buildMs) { release(); return 0; }
     }
-    if (!c->optListRes && !firstLaunchVoxels && R == 256u && perTexel() > 10.0 && perTexel() <= 32.0) {
+    // (round 4: with no entries for texels outside a triangle's outline the 512 map beats the 256 map at every grid size measured,
+    // 128^3 to 1024^3, by 5 - 22 % -- profiles/r04/ab_texels_outside_the_outline.jsonl -- so every scene that is presumed static
+    // takes it; a mesh that is being refitted, or a first launch that must pay for its build at once, keeps the base map)
+    const bool oneLaunch = firstLaunchVoxels != 0 || c->refitted;
+    if (!c->optListRes && !oneLaunch && R == 256u && perTexel() <= 32.0) {
         if (recount(512u)) return 1;
     } else if (!c->optListRes && perTexel() > 32.0) {
         if (R != 256u && recount(256u)) return 1;
@@ -658,11 +664,12 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
         if (sync_frames(c)) return 1;
         if (build_lists(c, fs, voxels, true)) return 1;
     }
-    // A scene that has lists on the 256 map and is now launched (again) at 1024^3 or beyond: once, the 512 map instead -- the
-    // map that suits a grid keeps a texel about two voxels wide (measured: 128^3 -> R 128, 256^3 and 512^3 -> 256, 1024^3 -> 512;
-    // profiles/r03/ab_listres_vs_grid.jsonl).  Deep scenes fall back to their coarse map inside build_lists.
-    if (!relaunch && p.mode == DXV_MODE_REFERENCE && c->optLists && !c->optListRes && c->listState == 1 && c->listRes < 512u && p.N >= 1024u &&
-        !c->listFloorTried && c->launchesOfScene > 0 && c->hdr.numTris >= 20000u) {
+    // A scene that has lists on the 256 map (a first launch that had to pay for its build at once) and is now launched AGAIN without
+    // having been refitted: a static scene -- once, the 512 map instead (faster at every grid size, build_lists_into).  Deep scenes
+    // fall back to their coarse map inside build_lists.
+    if (!relaunch && p.mode == DXV_MODE_REFERENCE && c->optLists && !c->optListRes && c->listState == 1 && c->listRes < 512u && !c->refitted &&
+        !c->listFloorTried && c->launchesOfScene > 0 && c->hdr.numTris >= 20000u &&
+        (double)c->listEntries <= 32.0 * 6.0 * (double)c->listRes * (double)c->listRes) {       // (deep scenes keep their coarse map: build_lists_into)
         if (sync_frames(c)) return 1;
         c->listResFloor = 512u; c->listFloorTried = true;
         if (build_lists(c, fs)) return 1;
@@ -923,7 +930,7 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     c->vbCopyQueued = false;
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
     c->dVb = nullptr; c->dIb = nullptr;
-    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
+    c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->refitted = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
     DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
@@ -1056,6 +1063,7 @@ int dxv_refit(dxv_ctx* c)
     }
     const uint32_t hadListsOn = c->listState == 1 ? c->listRes : 0u;
     c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0;
+    c->refitted = true;
     c->specRes = 0;
     if (alloc_pyramid(c)) return 1;
     BuildBuffers b{};
@@ -1074,7 +1082,7 @@ int dxv_refit(dxv_ctx* c)
     // pass needs the new triangle records only, so it runs here, behind the refit, and its total comes back with the root box.
     uint32_t spec = 0;
     if (c->optLists && (hadListsOn || c->optLists == 2) && c->dListScratchA && c->listScratchACap >= list_scratch_a(nullptr, c->hdr.numTris).bytes) {
-        spec = c->optListRes ? (uint32_t)c->optListRes : hadListsOn ? hadListsOn : list_resolution(c);
+        spec = c->optListRes ? (uint32_t)c->optListRes : list_resolution(c);     // (the base map: a mesh that is being refitted gets its lists built for one launch)
         const ListScratchA sa = list_scratch_a(c->dListScratchA, c->hdr.numTris);
         DXV_HIP(c, hipEventRecord(c->evList[0], c->stream));
         DXV_HIP(c, dirmap_count(scene_tripos(c), c->hdr.numTris, spec, sa.rec, sa.counts, sa.total, c->stream));
@@ -1093,7 +1101,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
+    c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->refitted = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
     if (alloc_pyramid(c)) return 1;
@@ -1440,8 +1448,9 @@ int dxv_build_lists_for_grid(dxv_ctx* c, uint32_t N)
     if (!c) return 1;
     if (!c->haveScene) return fail(c, "dxv_build_lists_for_grid: no scene");
     DXV_HIP(c, hipSetDevice(c->device));
-    // the map a launch at this grid size would move to (launch_now: a texel about two voxels wide -- 512 from 1024^3 on)
-    if (N >= 1024u && !c->optListRes && c->hdr.numTris >= 20000u && !c->listFloorTried && c->listResFloor < 512u) {
+    // the map the launches of a static scene move to (launch_now: the 512 map, at every grid size)
+    (void)N;
+    if (!c->optListRes && c->hdr.numTris >= 20000u && !c->refitted && !c->listFloorTried && c->listResFloor < 512u) {
         if (sync_frames(c)) return 1;
         c->listResFloor = 512u; c->listFloorTried = true;
         if (c->listState == 1 && c->listRes >= 512u) return 0;
@@ -1518,7 +1527,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         (withPl && (h.offPlCells != b.offPlCells || h.offPlEntries != b.offPlEntries)) || (!withPl && (h.offPlCells || h.offPlEntries || h.plCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
-    c->haveScene = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
+    c->haveScene = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->refitted = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported
     // triangle count over the old, smaller buffers.

@@ -136,8 +136,10 @@ __attribute__((visibility("default"))) uint64_t hc_dirmap_build(void* p, uint32_
             if (seen) dm_record_on_map(e, (i1 - i0 + 1u) * (j1 - j0 + 1u));
             rec[(size_t)t * 6 + f] = e;
             if (!seen) continue;
+            const DirTexelTest tt = dm_texel_test(e, (i1 - i0 + 1u) * (j1 - j0 + 1u));
             for (uint32_t j = j0; j <= j1; ++j)
                 for (uint32_t i = i0; i <= i1; ++i) {
+                    if (dm_texel_outside(tt, R, i, j)) continue;
                     uint32_t r0h, r1h;
                     dm_local_radial(e, R, i, j, r0h, r1h);
                     keys.push_back(dm_key(lay, (f * R + j) * R + i, (uint16_t)r1h, t));
@@ -266,6 +268,17 @@ __attribute__((visibility("default"))) int hc_dm_local_radial(const float* tri, 
     out[0] = half_to_float((uint16_t)(rec.rr & 0xffffu)); out[1] = half_to_float((uint16_t)(rec.rr >> 16));
     out[2] = half_to_float((uint16_t)r0h); out[3] = half_to_float((uint16_t)r1h);
     return (rec.hasTri & 2u) ? 2 : 1;
+}
+// dm_texel_outside for texel (i, j) of a triangle's record on one face and map: 1 = no entry there, 0 = entry (or no record / outside
+// the rectangle: -1)
+__attribute__((visibility("default"))) int hc_dm_texel_outside(const float* tri, uint32_t face, uint32_t R, uint32_t i, uint32_t j)
+{
+    TriPos tp;
+    tp.v0 = {tri[0], tri[1], tri[2], 0.0f}; tp.v1 = {tri[3], tri[4], tri[5], 0.0f}; tp.v2 = {tri[6], tri[7], tri[8], 0.0f};
+    const DirRecord rec = dm_record(tp, face);
+    uint32_t i0, i1, j0, j1;
+    if (!dm_rect(rec, R, i0, i1, j0, j1) || i < i0 || i > i1 || j < j0 || j > j1) return -1;
+    return dm_texel_outside(dm_texel_test(rec, (i1 - i0 + 1u) * (j1 - j0 + 1u)), R, i, j) ? 1 : 0;
 }
 __attribute__((visibility("default"))) uint32_t hc_normal_class(const float* tri, const float* nrm)
 {

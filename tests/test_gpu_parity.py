@@ -1000,9 +1000,15 @@ def test_first_launch_list_policy(dxv, dragon):
     v.Voxelize(416)
     assert v.stats()["list_entries"] == 0 and v.CountSolid() == solid
     v.set_option("lists", 1)
-    vb9, ib9, _ = make_mesh("dragon9")                                  # 12.6 entries per texel: a first-launch build keeps the base map
-    v.InitFromArrays(vb9, ib9)
+    vb9, ib9, _ = make_mesh("dragon9")                                  # a first-launch build keeps the base map (it must pay at once);
+    v.InitFromArrays(vb9, ib9)                                          # launched again, un-refitted, the scene is static: once, the 512 map
     res, counts = [], []
+    for _ in range(3):
+        v.Voxelize(416)
+        res.append(v.stats()["list_res"]); counts.append(v.CountSolid())
+    assert res == [256, 512, 512] and len(set(counts)) == 1, (res, counts)
+    v.UpdateVertices(np.ascontiguousarray(vb9, np.float32))             # a mesh that is being animated keeps the base map, however often it is launched
+    res = []
     for _ in range(3):
         v.Voxelize(416)
         res.append(v.stats()["list_res"]); counts.append(v.CountSolid())

@@ -306,6 +306,7 @@ def test_radial_range_per_texel_holds_every_point_of_the_triangle_there(hostchec
     L = hostcheck.lib
     f32p = np.ctypeslib.ndpointer(np.float32, flags="C")
     L.hc_dm_local_radial.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
+    L.hc_dm_texel_outside.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     rng = np.random.default_rng(515)
     tris = list(rng.uniform(-1, 1, size=(120, 3, 3)).astype(np.float32))                       # big
     c = rng.uniform(-0.9, 0.9, size=(120, 1, 3))
@@ -341,6 +342,8 @@ def test_radial_range_per_texel_holds_every_point_of_the_triangle_there(hostchec
             for (f, i, j), rs in cells.items():
                 kind = L.hc_dm_local_radial(np.ascontiguousarray(t.reshape(-1)), f, R, i, j, out)
                 assert kind != 0, (t.tolist(), f, i, j)
+                # ... and a texel that holds a point of the triangle keeps its entry (dm_texel_outside)
+                assert L.hc_dm_texel_outside(np.ascontiguousarray(t.reshape(-1)), f, R, i, j) == 0, (t.tolist(), R, f, i, j)
                 g0, g1, l0, l1 = (float(x) for x in out)
                 assert g0 <= l0 <= l1 <= g1
                 assert l0 <= min(rs) and max(rs) <= l1, (t.tolist(), R, f, i, j, (g0, g1), (l0, l1), (min(rs), max(rs)))
