@@ -229,9 +229,9 @@ DXV_API int dxv_render(dxv_ctx* ctx, const float eye[3], const float view_proj[1
  * second launch (option lists); dxv_build_lists builds them now.  A scene exported after that carries them as two more
  * sections of the blob, and the importing contexts adopt them instead of building their own. */
 DXV_API int dxv_build_lists(dxv_ctx* ctx);
-/* ... on the map a launch at grid_dim would use (a texel should stay about two voxels wide: scenes launched at 1024^3 and beyond
- * move from the 256 to the 512 map once): the exporting rank builds that map before dxv_scene_export, so that the importing
- * ranks do not each rebuild it at their first launch.  Lists that cannot be had on the finer map leave the ones there are. */
+/* ... on the map the launches of a static scene move to (the 512 map for scenes of 20,000 triangles or more, at every grid size;
+ * grid_dim is accepted for compatibility): the exporting rank builds that map before dxv_scene_export, so that the importing
+ * ranks do not each rebuild it at their second launch.  Lists that cannot be had on the finer map leave the ones there are. */
 DXV_API int dxv_build_lists_for_grid(dxv_ctx* ctx, uint32_t grid_dim);
 /* The same for the parity rule's row lists (option plists): built now instead of at the scene's second parity launch; a scene
  * exported after that carries them too (33 + 72 MB at 1 M triangles), and an importing context adopts them. */
@@ -270,7 +270,11 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 whose eight lengths a dxv_sync has read since it was built: one workgroup per queued brick dealt out by the
  *                 hardware (1, default; 2: only for partitions of up to 2^25 voxels) instead of persistent waves (0).  The first
  *                 launch of a queue, and every launch under plan = 2, does not know its size and uses the persistent waves.
- *   listres 0|16..4096  texels per cube-map face side of the lists (power of two; 0 = by triangle count)
+ *   listres 0|16..4096  texels per cube-map face side of the lists (power of two).  0 = automatic: 128 below 20,000 triangles,
+ *                 256 up to 3 M, 512 beyond -- and the 512 map for every scene of 20,000 triangles or more that is presumed
+ *                 STATIC: built by dxv_build_lists / lists = 2 on a scene that has not been refitted, or launched a second time
+ *                 without a refit in between (one rebuild).  A mesh that is being refitted, and a first launch whose build
+ *                 must pay for itself at once, keep the base map.  Deep scenes (over 32 entries per texel) take coarser maps.
  *   plists 0|1|2    parity rule through row lists of the (y, z) plane: 1 (default) from a scene's second parity launch,
  *                 2 from the first, 0 = always walk the tree; plistres 0|16..4096: texels per side of their grid
  *   plan   0|1|2  lists kernel through a work queue: only the 4^3-voxel bricks that can hold a live ray are run (decided per
