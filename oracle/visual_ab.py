@@ -91,7 +91,40 @@ def variants_of(vb, ib, N):
     out["mirrored + normalising transform with a 10 % larger half extent (Voxelizer.cpp:56)"] = (mx(grid), b2)
     out["mirrored + grid shifted by one voxel in x"] = (mx(np.roll(grid, 1, axis=2)), scene.bound)
     out["mirrored + grid shifted by one voxel in y"] = (mx(np.roll(grid, 1, axis=1)), scene.bound)
+    # the OBJ file's raw coordinates (x, y, z): today's loader without its z negation (XUSGObjLoader.cpp:198,213); with the index
+    # reversal (:227) or without makes no difference to a grid -- the rule reads vertex normals, never the winding
+    out["raw OBJ coordinates (x, y, z): the current source without the loader's z negation"] = (sz.voxelize(N), sz.bound)
     return out
+
+
+def root_cause_rows(shot, vb, ib, N=64):
+    """Which SINGLE difference from today's source reproduces the screenshot?  Silhouette AND shading for every candidate: a mirrored
+    image or a camera on the other side can match the silhouette, only a scene that is mirrored relative to camera AND light matches
+    the colours (the light is fixed in world space, Content/Voxelizer.cpp:93)."""
+    ref_mask = silhouette(shot)
+    raw = vb.copy(); raw[:, 2] *= -1; raw[:, 5] *= -1                     # (x, y, z) as the OBJ file has them
+    rot = vb.copy(); rot[:, 0] *= -1; rot[:, 3] *= -1                     # (-x, y, -z) of the file = today's loader output mirrored in x
+    neg = raw.copy(); neg[:, 0] *= -1; neg[:, 3] *= -1                    # (-x, y, z) of the file
+    rows = {}
+
+    def row(name, v, eye=None, flip=False):
+        sc = orc.Scene(v, ib)
+        e, vp = camera.default_view_proj(W, H) if eye is None else camera.default_view_proj(W, H, eye=eye)
+        img = orc.render(sc.voxelize(N), sc.bound, e, vp, W, H)
+        if flip:
+            img = np.ascontiguousarray(img[:, ::-1])
+        m = measures(silhouette(img), ref_mask, img, shot)
+        rows[name] = {"iou": m["iou"], "mean_abs_rgb_diff_inside": m["mean_abs_rgb_diff_inside"]}
+
+    row("today's source: loader output (x, y, -z), eye (8, 12, -14)", vb)
+    row("raw OBJ (x, y, z) (no z negation, with or without index reversal), eye (8, 12, -14)", raw)
+    row("(-x, y, z) of the file, eye (8, 12, -14)", neg)
+    row("(-x, y, -z) of the file = the raw OBJ turned by 180 degrees about y, eye (8, 12, -14)", rot)
+    row("today's source seen from eye (-8, 12, -14)", vb, eye=(-8.0, 12.0, -14.0))
+    row("today's source seen from eye (-8, 12, -14), image mirrored left-right", vb, eye=(-8.0, 12.0, -14.0), flip=True)
+    row("raw OBJ (x, y, z) seen from the other side, eye (-8, 12, 14)", raw, eye=(-8.0, 12.0, 14.0))
+    row("today's source seen from eye (8, 12, 14)", vb, eye=(8.0, 12.0, 14.0))
+    return rows
 
 
 def compare(shot, vb, ib, N=64, eye=None):
@@ -128,16 +161,31 @@ def main():
         g, bound = variants_of(vb, ib, N)["restated, scene mirrored in x"]
         nudges[str(tuple(float(v) for v in eye))] = measures(silhouette(orc.render(g, bound, e, vp, W, H)), ref_mask)["iou"]
     print("eye nudged by 0.5:", {k: round(v, 4) for k, v in nudges.items()})
+    rows = root_cause_rows(shot, vb, ib, N)
+    for name, m in rows.items():
+        print(f"root cause: {name:95s} IoU {m['iou']:.4f}  rgb {m['mean_abs_rgb_diff_inside']:.2f}")
     out = {"screenshot": "Doc/Images/SolidVoxelization.jpg", "client_area_box_px": list(box), "rendered_px": [W, H],
            "grid": N, "camera": {"eye": list(camera.DEFAULT_EYE), "focus": list(camera.DEFAULT_FOCUS), "fov_y_deg": 45.0},
            "threshold_sum_abs_rgb": THRESH, "screenshot_object_pixels": int(ref_mask.sum()), "variants": res,
            "iou_of_the_mirrored_variant_with_the_eye_nudged_by_0.5": nudges,
+           "root_cause": {"rows": rows,
+                          "shipped_binaries": "tests/golden/shipped_binaries.json (oracle/shipped_binaries.py): the DXIL the reference ships negates y of the "
+                                              "ray origin and nothing else, samples the grid at (0.5, -0.5, 0.5) * pos + 0.5, and the loader inside "
+                                              "Bin/DXRVoxelizer.exe (linked 2025-03-14) negates z of every v / vn record -- the binaries are today's source",
+                          "verdict": "ONE candidate matches silhouette and shading: the vertex data (-x, y, -z) of the file -- the OBJ's raw coordinates "
+                                     "(the chirality of a loader without forDX's z negation) turned by 180 degrees about y -- with today's camera and "
+                                     "light (IoU 0.998, 0.7 / 255).  The raw coordinates themselves do not (0.48); a camera on the other side or a mirrored "
+                                     "image match the silhouette only (0.993 - 0.997, colours off by 5 - 65 / 255: the light did not move with them).  "
+                                     "Neither today's source nor any binary the reference ships produces that scene: the screenshots are older than both "
+                                     "(a loader without the z negation AND a bunny.obj facing the other way, or a world transform since removed) -- "
+                                     "nothing in /root/reference says which."},
            "FINDING": "The screenshot is the restated pipeline's image of the scene MIRRORED IN X (IoU 0.998, mean colour difference inside the "
                       "silhouette 0.6 / 255: voxelizer, predicate, alpha, transform, camera, march and lighting all agree), not of the scene as the "
                       "current source reads (IoU 0.55).  With x mirrored, every other convention is pinned: each wrong variant drops the IoU to "
                       "0.07 - 0.85 and a single voxel of shift shows.  mirror_x(loader output) = the OBJ file's raw coordinates rotated by 180 "
                       "degrees about y: the screenshot was taken with a build whose chain held one more reflection than today's source -- the "
-                      "loader's z negation (XUSGObjLoader.cpp:198) did not exist or was undone elsewhere.  The compiled CURRENT loader is what "
+                      "loader's z negation (XUSGObjLoader.cpp:198) did not exist or was undone elsewhere (root_cause below: no single edit of today's "
+                      "source does it, and the shipped exe and DXIL are today's source).  The compiled CURRENT loader is what "
                       "the oracle is pinned to byte for byte (tests/test_oracle_objloader.py), so the product follows the source, not the "
                       "screenshot; a caller who wants the screenshot's chirality negates x of the vertex buffer."}
     # the second screenshot (README.md:10, "not default" grid size): the same view of a finer grid.  Its grid size is not recorded; the

@@ -70,3 +70,24 @@ def test_second_screenshot_agrees(orc):
     m = va.measures(va.silhouette(orc.render(np.ascontiguousarray(g[:, :, ::-1]), scene.bound, eye, vp, va.W, va.H)), ref)
     w = va.measures(va.silhouette(orc.render(g, scene.bound, eye, vp, va.W, va.H)), ref)
     assert m["iou"] > 0.98 and w["iou"] < 0.65
+
+
+def test_root_cause_rows_one_candidate_matches_silhouette_and_shading(orc):
+    """Which single difference from today's source gives the screenshot (oracle/visual_ab.py: root_cause_rows): only the file's
+    (-x, y, -z) -- its raw coordinates turned by 180 degrees about y -- matches silhouette AND colours; raw coordinates do not, a camera
+    on the other side or a mirrored image match the silhouette alone.  The shipped exe and DXIL are today's source
+    (tests/test_shipped_binaries.py): the screenshots are older than every binary the reference ships."""
+    PIL = pytest.importorskip("PIL.Image")
+    import visual_ab as va
+    d = np.load(os.path.join(ROOT, "tests", "golden", "meshes", "bunny.npz"))
+    shot = np.asarray(PIL.open(os.path.join(ROOT, "tests", "golden", "visual", "reference_client_area_1280x720.jpg")).convert("RGB")).astype(np.float64)
+    rows = va.root_cause_rows(shot, d["vb"], d["ib"], 64)
+    fixture = json.load(open(os.path.join(ROOT, "tests", "golden", "visual_ab.json")))["root_cause"]["rows"]
+    assert set(rows) == set(fixture)
+    for name, m in rows.items():
+        assert abs(m["iou"] - fixture[name]["iou"]) < 2e-3 and abs(m["mean_abs_rgb_diff_inside"] - fixture[name]["mean_abs_rgb_diff_inside"]) < 0.2, name
+    both = [n for n, m in rows.items() if m["iou"] > 0.99 and m["mean_abs_rgb_diff_inside"] < 1.5]
+    assert both == ["(-x, y, -z) of the file = the raw OBJ turned by 180 degrees about y, eye (8, 12, -14)"]
+    silhouette_only = [n for n, m in rows.items() if m["iou"] > 0.99 and m["mean_abs_rgb_diff_inside"] >= 1.5]
+    assert len(silhouette_only) == 2 and all("eye (-8" in n for n in silhouette_only)
+    assert rows["raw OBJ (x, y, z) (no z negation, with or without index reversal), eye (8, 12, -14)"]["iou"] < 0.6
