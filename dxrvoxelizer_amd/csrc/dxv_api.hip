@@ -86,8 +86,10 @@ struct dxv_ctx {
         uint32_t plan_bricks = 0, plan_waves = 0;
         float plan_ms = 0.0f;
         // work queue of the lists kernel (traverse.hip): the frame's own, written and read on the frame's stream only
-        uint32_t* dQueue = nullptr;
+        uint32_t* dQueue = nullptr;      // two headers, then the slots (dxv_device.h)
         size_t queueWords = 0;           // allocated 32-bit words
+        uint32_t queueHdr = 0;           // the header (0 / 1) of the frame's current queue; the next build takes the other one ...
+        bool queueOtherClear = false;    // ... which is all zero (cleared at the allocation, then by every build's k_plan_bricks)
         bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
         bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
         hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
@@ -134,7 +136,7 @@ struct dxv_ctx {
         unsigned long long listTotal;
         uint32_t listLongest, pad;
         uint32_t status[DXV_FRAME_COUNT][4];
-        uint32_t queueHeader[DXV_FRAME_COUNT][kQueueHeaderWords];
+        uint32_t queueLens[DXV_FRAME_COUNT][8 * 64];     // the eight length words of a frame's queue (each in a 256-byte line of its own)
     };
     Pinned* pin = nullptr;
     hipEvent_t evList[4] = {};       // around the counting pass, around the rest of the build
@@ -150,6 +152,8 @@ struct dxv_ctx {
     int optPlan = 1;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch, 2 = on every launch
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
+    int optPlanRegion = 0;           // log2 of the run of Morton bricks dealt to one queue: 6, 7, 8; 0 = by the partition's size (plan_region_bits)
+    int optFuse = 1;                 // 1: the queue build clears the grid as well (one kernel in front of the brick kernel); 0: memsets in front of it
     int optDispatch = 1;             // a kept queue whose lengths the host knows: 0 = persistent waves all the same, 1 = one workgroup per
                                      // queued brick dealt out by the hardware (-1 ... -10 % per launch, and back-to-back launches overlap
                                      // their ends: profiles/r04/ab_dispatch_kept_queue.jsonl), 2 = that for partitions of up to 2^25 voxels only
@@ -698,12 +702,21 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
                     DXV_HIP(c, hipStreamSynchronize(fs));
                     (void)hipFree(f.dQueue); f.dQueue = nullptr; f.queueWords = 0;
                     const hipError_t qe = hipMalloc(&f.dQueue, sizeof(uint32_t) * words);
-                    if (qe == hipSuccess) f.queueWords = words;
+                    if (qe == hipSuccess) {
+                        f.queueWords = words;
+                        DXV_HIP(c, hipMemsetAsync(f.dQueue, 0, sizeof(uint32_t) * kQueueSlotsAt, fs));      // both headers
+                        f.queueHdr = 0; f.queueOtherClear = true;
+                    }
                     else if (qe == hipErrorOutOfMemory) (void)hipGetLastError();       // no queue: the brick-box launch still works
                     else return fail(c, "work queue: hipMalloc failed: %s", hipGetErrorString(qe));
                     f.clearSig = 0;
                 }
-                if (f.dQueue) { queued = true; p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves; }
+                if (f.dQueue) {
+                    queued = true; p.queue = f.dQueue + f.queueHdr * kQueueHeaderWords; p.queueSlots = f.dQueue + kQueueSlotsAt; p.queueCap = cap;
+                    p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves;
+                    p.planRegionBits = c->optPlanRegion ? (uint32_t)c->optPlanRegion : plan_region_bits(p.N, p.nz);
+                    p.planClear = c->optFuse ? 1u : 0u;
+                }
             }
         }
     }
@@ -762,7 +775,8 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             uint64_t sig = 0;
             auto mix = [&](uint64_t v) { sig = (sig ^ v) * 0x9E3779B97F4A7C15ull; sig ^= sig >> 29; };
             mix(0x7175657565ull); mix(c->listEpoch); mix(p.N); mix(p.nz); mix(p.z0); mix(p.zBlock); mix(p.zPeriod);
-            mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels)); mix(reinterpret_cast<uint64_t>(p.queue));
+            mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels)); mix(reinterpret_cast<uint64_t>(f.dQueue));
+            mix(p.planRegionBits);
             sig |= 1ull;
             const bool rebuild = c->optPlan == 2 || f.ptrExposed || f.clearSig != sig;
             hipEvent_t pe[2] = {f.evP0, f.evP1};
@@ -770,9 +784,18 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             // (option dispatch: 1 = whenever known, 2 = for partitions of up to 2^25 voxels)
             uint32_t listed = 0;
             if (!rebuild && f.queueLenSig == sig && (c->optDispatch == 1 || (c->optDispatch == 2 && voxels <= (1ull << 25)))) listed = f.queueLenMax;
+            if (rebuild) {
+                // the new queue goes into the frame's other header, which the last build left cleared; this build clears the one it leaves
+                const uint32_t target = f.queueHdr ^ 1u;
+                p.queue = f.dQueue + target * kQueueHeaderWords;
+                p.queueZero = f.dQueue + f.queueHdr * kQueueHeaderWords;
+                if (!f.queueOtherClear) DXV_HIP(c, hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kQueueHeaderWords, fs));
+                f.queueOtherClear = false;                                 // (until this launch is in the stream)
+                f.clearSig = 0; f.queueLenSig = 0;
+            }
             DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, listed, fs));
+            if (rebuild) { f.queueHdr ^= 1u; f.queueOtherClear = true; }
             f.clearSig = f.ptrExposed ? 0 : sig;
-            if (rebuild) f.queueLenSig = 0;
             f.lastQueued = true; f.lastRebuilt = rebuild;
         } else DXV_HIP(c, launch_voxelize(p, c->optBrick, st, fs));
         if (p.lists) f.lastRedoParity = -1;                        // no column to run out of, nothing to redo
@@ -1167,10 +1190,10 @@ int sync_frame(dxv_ctx* c, uint32_t i)
     for (int attempt = 0; attempt < 8; ++attempt) {
         // status words and the queue's header in one round trip, into page-locked words
         uint32_t* words = c->pin->status[i];
-        const uint32_t* hdr = c->pin->queueHeader[i];
+        const uint32_t* lens = c->pin->queueLens[i];
         const bool readQueue = f.pending && f.lastQueued;
         DXV_HIP(c, hipMemcpyAsync(words, f.dStatus, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, fs));
-        if (readQueue) DXV_HIP(c, hipMemcpyAsync(c->pin->queueHeader[i], f.dQueue, sizeof(uint32_t) * kQueueHeaderWords, hipMemcpyDeviceToHost, fs));
+        if (readQueue) DXV_HIP(c, hipMemcpyAsync(c->pin->queueLens[i], f.dQueue + f.queueHdr * kQueueHeaderWords + queue_len_word(0), sizeof(c->pin->queueLens[i]), hipMemcpyDeviceToHost, fs));
         DXV_HIP(c, hipStreamSynchronize(fs));
         // lists this launch was queued behind without waiting for their verdict: withdrawn -> the launch again, through the tree
         if (settle_lists(c)) return 1;
@@ -1187,8 +1210,9 @@ int sync_frame(dxv_ctx* c, uint32_t i)
                 f.plan_bricks = 0;
                 f.queueLenMax = 0;
                 for (uint32_t x = 0; x < 8u; ++x) {
-                    f.plan_bricks += hdr[queue_len_word(x)];
-                    if (hdr[queue_len_word(x)] > f.queueLenMax) f.queueLenMax = hdr[queue_len_word(x)];
+                    const uint32_t len = lens[queue_len_word(x) - queue_len_word(0)];
+                    f.plan_bricks += len;
+                    if (len > f.queueLenMax) f.queueLenMax = len;
                 }
                 f.queueLenSig = f.clearSig;                             // (the queue of this signature: 0 = none kept)
                 if (f.lastRebuilt) f.plan_ms = f.timed ? elapsed(f.evP0, f.evP1) : 0.0f;
@@ -1668,6 +1692,12 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "queuewaves")) {
         if (value < 0 || value > (1 << 20)) return fail(c, "option queuewaves: %lld not in [0, 2^20]", (long long)value);
         c->optQueueWaves = (int)value;
+    } else if (!strcmp(key, "planregion")) {
+        if (value != 0 && (value < 6 || value > 8)) return fail(c, "option planregion: %lld not in {0,6,7,8}", (long long)value);
+        c->optPlanRegion = (int)value;
+    } else if (!strcmp(key, "fuse")) {
+        if (value != 0 && value != 1) return fail(c, "option fuse: %lld not in {0,1}", (long long)value);
+        c->optFuse = (int)value;
     } else if (!strcmp(key, "events")) {
         if (value != 0 && value != 1) return fail(c, "option events: %lld not in {0,1}", (long long)value);
         c->optEvents = (int)value;
@@ -1795,7 +1825,7 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
     while ((1u << p.zShift) < p.zBlock) ++p.zShift;
     uint32_t cap = 0;
     (void)plan_queue_words(p.N, p.nz, &cap);
-    p.queue = f.dQueue; p.queueCap = cap; p.mip = c->dMip;
+    p.queue = f.dQueue + f.queueHdr * kQueueHeaderWords; p.queueSlots = f.dQueue + kQueueSlotsAt; p.queueCap = cap; p.mip = c->dMip;
     VoxelizeParams q = p;
     const uint32_t nb = plan_layout(q);
     uint32_t* bits = nullptr;

@@ -91,21 +91,29 @@ struct VoxelizeParams {
     uint32_t lists;         // 1: reference rule reads the direction-space lists of p.scene (no tree walk)
     uint64_t* clearSig;     // host word of the frame (or NULL): signature of the partial launch whose memset the grid still carries -- the same launch again skips the memset
     uint32_t ablate;        // timing-only builds of the lists kernel (wrong grids; tools/ablate.py), 0 = the real kernel
-    uint32_t* queue;        // work queue of the lists kernel (traverse.hip): len[8], head[8], spare header words, then 8 x queueCap brick words
+    uint32_t* queue;        // work queue of the lists kernel (traverse.hip): the header this launch uses (64 heads, 8 lengths, every word in a line of its own)
+    uint32_t* queueSlots;   // ... its 8 x queueCap brick words
+    uint32_t* queueZero;    // ... the frame's OTHER header, cleared by k_plan_bricks for the launch that builds the next queue (or NULL)
     uint32_t queueCap;
+    uint32_t planRegionBits; // log2 of the run of consecutive Morton bricks that goes to one queue (6, 7 or 8)
+    uint32_t planClear;     // 1: k_plan_bricks also clears the grid (and the texel image): no memset in front of it
     uint32_t queueWaves;    // persistent waves to launch; 0 = what the device holds at once
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
-// header of the queue memory: 64 heads (eight per queue: head h of queue x hands out the slots k = h mod 8 of that queue; head
-// number 8 x + h), then the eight lengths, every word in a 256-byte line of its own; then the slots
+// header of a queue: 64 heads (eight per queue: head h of queue x hands out the slots k = h mod 8 of that queue; head
+// number 8 x + h), then the eight lengths, every word in a 256-byte line of its own.  Queue memory of a frame: TWO headers, then
+// the slots: a launch that builds a queue takes the header the last build did not use -- all zero, because that build's
+// k_plan_bricks cleared it (and the allocation cleared both) -- so no memset stands between a launch and its queue build.
 constexpr uint32_t kQueueHeaderWords = 5120u;
+constexpr uint32_t kQueueSlotsAt = 2u * kQueueHeaderWords;
 DXV_HD constexpr uint32_t queue_head_word(uint32_t x, uint32_t h) { return 64u * (1u + 8u * x + h); }
 DXV_HD constexpr uint32_t queue_len_word(uint32_t x) { return 64u * (65u + x); }
 // work queue of the lists kernel with 4 x 4 x 4 bricks (traverse.hip): built on the device in front of the launch
 uint32_t plan_layout(VoxelizeParams& p);           // fills the brick-order fields for the whole partition, returns its bricks
+uint32_t plan_region_bits(uint32_t N, uint32_t nz); // the run length (log2 bricks) a partition of this size deals to its queues
 size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut);     // 32-bit words of queue memory for a partition; *capOut = words per XCD queue
-hipError_t plan_build(const VoxelizeParams& p, hipStream_t s);          // header cleared + k_plan_bricks (p.queue, p.queueCap, p.mip set)
+hipError_t plan_build(const VoxelizeParams& p, hipStream_t s);          // k_plan_bricks into the (zero) header p.queue; p.queueSlots, p.queueCap, p.mip set
 // rebuild: grid cleared + queue built in front of the kernel; else only the queue heads are reset (same launch as before into the same buffers)
 // (planEvents: two events recorded around the queue build of a rebuilding launch, or NULL)
 hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, uint32_t listedLen, hipStream_t s);

@@ -107,8 +107,9 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 //    wave that finds nothing, a false negative cannot happen -- k_plan_check below is the exhaustive proof obligation);
 //  * layout: regions of 256 consecutive bricks of the Morton order (8 x 8 x 4 bricks) are dealt round-robin to eight
 //    queues, one per XCD (blocks b and b + 8 share one), so that an XCD's private L2 sees compact regions; a region's
-//    workgroup appends its live bricks to its queue with one atomic add.  Queue memory (dxv_device.h): a header -- eight
-//    heads per queue and the eight lengths, every word in a 256-byte line of its own -- and 8 x cap brick words
+//    workgroup appends its live bricks to its queue with one atomic add (small partitions: runs of 64 bricks, one add per
+//    wave -- k_plan_bricks).  Queue memory (dxv_device.h): two headers -- eight heads per queue and the eight lengths, every
+//    word in a 256-byte line of its own; a build takes the one the last build left cleared -- and 8 x cap brick words
 //    (bx | by << 10 | bz << 20);
 //  * how: k_voxelize_queue is launched with as many single-wave workgroups as the GPU holds at once.  Every wave takes its
 //    bricks one at a time from a head of its XCD's queue with a returning atomic add, asked for one brick ahead.  Which
@@ -119,17 +120,32 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 //    definitions); and, for queues that are launched again, orders made on the device from MEASURED times -- the cheapest chunks of
 //    64 slots last (-3 % of a rank's share, +1 % on a whole grid), all chunks by cost (-6 % / +4 %), the bricks that took over three
 //    times the mean first and the shortest last (nothing): none earns a second copy of the queue.
-// Bricks that are not queued are zero by the launch's memset of the grid.
+// Bricks that are not queued are zero because k_plan_bricks clears the partition's grid while it builds the queue.
 // ---------------------------------------------------------------------------------------------
 [[maybe_unused]] constexpr uint32_t kQueueNoPrefetch = 1024u;
 constexpr uint32_t kPlanRegionBits = 8u;                               // regions of 256 consecutive bricks = one workgroup of k_plan_bricks
 // (header layout: queue_len_word / queue_head_word in dxv_device.h -- every queue's two words in a 256-byte line of its own:
 // returning atomics on ONE line serialise at ~90 per us for all eight queues together, 2.7 ms of a launch when first tried)
 
+// The launch's zeros travel with the queue build: workgroup b clears the b-th share of the grid (and of the texel image) with
+// 16-byte stores while its threads wait for their four mip words -- one kernel in front of the brick kernel instead of a memset
+// of the grid, a memset of the header and this one (three dependent dispatches: ~5 us each on top of their own time).
+// Block 0 clears the frame's other header for the launch that builds the next queue.
+__device__ __forceinline__ void plan_clear(uint8_t* base, size_t bytes, uint32_t nblocks)
+{
+    const size_t chunk = (((bytes + nblocks - 1u) / nblocks) + 15u) & ~(size_t)15u;
+    const size_t lo = (size_t)blockIdx.x * chunk;
+    if (lo >= bytes) return;
+    const size_t hi = lo + chunk < bytes ? lo + chunk : bytes, full = lo + ((hi - lo) & ~(size_t)15u);
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (size_t o = lo + 16u * threadIdx.x; o < full; o += 16u * 256u) *reinterpret_cast<uint4*>(base + o) = z;
+    if (full + threadIdx.x < hi) base[full + threadIdx.x] = 0;           // (a grid whose bytes are no multiple of 16: the last block's tail)
+}
+
 __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t nb)
 {
     __shared__ uint32_t waveCount[4];
-    __shared__ uint32_t regionBase;
+    __shared__ uint32_t groupBase[4];
     const uint32_t lin = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     bool live = false;
     uint32_t bx = 0, by = 0, bz = 0;
@@ -139,22 +155,30 @@ __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t 
         dm_brick_hull(p.N, p.nz, p.z0, p.zBlock, p.zShift, p.zPeriod, bx, by, bz, x0, x1, y0, y1, z0, z1);
         live = dm_box_may_be_live(x0, x1, y0, y1, z0, z1, p.scene.rootLo, p.scene.rootHi, p.mip, p.scene.dmR);
     }
+    if (p.planClear) {
+        plan_clear(p.grid, (size_t)p.N * p.N * p.nz, gridDim.x);
+        if (p.texels) plan_clear(reinterpret_cast<uint8_t*>(p.texels), (size_t)p.N * p.N * p.nz * 4u, gridDim.x);
+    }
+    if (p.queueZero && blockIdx.x == 0u)
+        for (uint32_t k = threadIdx.x; k < kQueueHeaderWords; k += 256u) p.queueZero[k] = 0u;
     const unsigned long long m = __ballot(live);
     if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
     __syncthreads();
-    // (measured and dropped, profiles/r04/: dealing finer -- runs of 64 bricks -- or to the queue that is shortest at the moment: no
-    // faster, the eight queues end within 2 % of each other as it is; a second queue per XCD, run last, for the bricks near or across
-    // the outer end of their lists: no faster in two definitions, 8 % slower in one)
-    const uint32_t x = blockIdx.x & 7u;
-    if (threadIdx.x == 0u) {
-        const uint32_t n = waveCount[0] + waveCount[1] + waveCount[2] + waveCount[3];
-        regionBase = n ? atomicAdd(p.queue + queue_len_word(x), n) : 0u;
+    // Runs of 2^planRegionBits consecutive Morton bricks go to one queue, the runs dealt round-robin: 256 (8 x 8 x 4 bricks, the whole
+    // workgroup) on large partitions -- an XCD's L2 sees compact pieces of the grid; 64 (4 x 4 x 4 bricks, one wave each) on small
+    // ones, where eight queues of a few dozen runs each differ by 10 - 20 % in cost and the launch ends with its longest queue.
+    const uint32_t wavesPerRun = 1u << (p.planRegionBits - 6u), first = w & ~(wavesPerRun - 1u);
+    const uint32_t x = (lin >> p.planRegionBits) & 7u;
+    if (lane == 0u && w == first) {
+        uint32_t n = 0;
+        for (uint32_t k = 0; k < wavesPerRun; ++k) n += waveCount[first + k];
+        groupBase[first] = n ? atomicAdd(p.queue + queue_len_word(x), n) : 0u;
     }
     __syncthreads();
     if (!live) return;
     uint32_t rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-    for (uint32_t k = 0; k < w; ++k) rank += waveCount[k];
-    p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + regionBase + rank] = bx | (by << 10) | (bz << 20);
+    for (uint32_t k = first; k < w; ++k) rank += waveCount[k];
+    p.queueSlots[(size_t)x * p.queueCap + groupBase[first] + rank] = bx | (by << 10) | (bz << 20);
 }
 
 // the brick order of the whole partition (no brick box): what k_plan_bricks, the checker and the host agree on
@@ -170,23 +194,35 @@ uint32_t plan_layout(VoxelizeParams& p)
     p.superY = nby >> m;
     return nbx * nby * nbz;
 }
-// words of queue memory a partition needs (header + eight queues, each able to hold every region dealt to it in full)
+// Run length by partition size.  Large partitions: 256 bricks (an XCD's L2 sees compact pieces of the grid, and with thousands of
+// runs per queue the eight queues end within 2 % of each other).  Small ones -- a 256^3 grid, a rank's share of 512^3 at 4 ranks
+// or more: 2^19 bricks or fewer -- take runs of 64: a queue of a few hundred runs of very different cost ends 10 - 20 % away
+// from its neighbours, and the launch ends with the longest.
+uint32_t plan_region_bits(uint32_t N, uint32_t nz)
+{
+    const uint64_t nb = (uint64_t)((N + 3u) / 4u) * ((N + 3u) / 4u) * ((nz + 3u) / 4u);
+    return nb <= (1ull << 19) ? 6u : kPlanRegionBits;
+}
+// words of queue memory a partition needs (two headers + eight queues, each able to hold every run dealt to it in full, whatever
+// the run length)
 size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut)
 {
     const uint64_t nb = (uint64_t)((N + 3u) / 4u) * ((N + 3u) / 4u) * ((nz + 3u) / 4u);
-    const uint64_t nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
-    const uint64_t cap = ((nr + 7u) / 8u) << kPlanRegionBits;
+    uint64_t cap = 0;
+    for (uint32_t rb = 6u; rb <= kPlanRegionBits; ++rb) {
+        const uint64_t runs = (nb + (1u << rb) - 1u) >> rb, c = ((runs + 7u) / 8u) << rb;
+        if (c > cap) cap = c;
+    }
     if (capOut) *capOut = (uint32_t)cap;
-    return kQueueHeaderWords + 8u * (size_t)cap;
+    return kQueueSlotsAt + 8u * (size_t)cap;
 }
 
-// header cleared, then one workgroup per region; p.queue / p.queueCap / p.mip set by the caller
+// one workgroup per 256 bricks into the header p.queue, which the caller vouches is all zero; p.queueSlots / p.queueCap / p.mip set by the caller
 hipError_t plan_build(const VoxelizeParams& pin, hipStream_t s)
 {
     VoxelizeParams p = pin;
     const uint32_t nb = plan_layout(p), nr = (nb + (1u << kPlanRegionBits) - 1u) >> kPlanRegionBits;
-    hipError_t e = hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kQueueHeaderWords, s);
-    if (e != hipSuccess) return e;
+    if (p.planRegionBits < 6u || p.planRegionBits > kPlanRegionBits) p.planRegionBits = kPlanRegionBits;
     k_plan_bricks<<<dim3(nr), dim3(256), 0, s>>>(p, nb);
     return hipGetLastError();
 }
@@ -205,7 +241,7 @@ __global__ __launch_bounds__(256) void k_plan_mark(VoxelizeParams p, uint32_t* _
     for (uint32_t x = 0; x < 8u; ++x) {
         const uint32_t len = p.queue[queue_len_word(x)];
         for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < len; k += gridDim.x * 256u) {
-            const uint32_t w = p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + k];
+            const uint32_t w = p.queueSlots[(size_t)x * p.queueCap + k];
             const uint32_t id = ((w >> 20) * nbx + ((w >> 10) & 1023u)) * nbx + (w & 1023u);
             const uint32_t old = atomicOr(bits + (id >> 5), 1u << (id & 31u));
             if (old & (1u << (id & 31u))) atomicAdd(out + 4, 1ull);
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
         const uint32_t x = cur >> 3, h = cur & 7u;
         const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
         uint32_t* head = p.queue + queue_head_word(x, h);
-        const uint32_t* slots = p.queue + kQueueHeaderWords + (size_t)x * p.queueCap;
+        const uint32_t* slots = p.queueSlots + (size_t)x * p.queueCap;
         if (len > h) {
         // One brick ahead: the add for the next brick is issued in front of the current one, and its answer is taken out of its
         // vector register as soon as the brick's first load (the rays' cells: all 64 lanes make that step together) has arrived --
@@ -401,7 +437,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p)
     const uint32_t x = blockIdx.x & 7u, k = blockIdx.x >> 3;
     const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
     if (k >= len) return;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[kQueueHeaderWords + (size_t)x * p.queueCap + k]);
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queueSlots[(size_t)x * p.queueCap + k]);
     const SceneView& sc = p.scene;
     const uint32_t N = p.N, nz = p.nz;
     const uint32_t bx = w & 1023u, by = (w >> 10) & 1023u, bz = w >> 20;
@@ -471,8 +507,10 @@ hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32
         return hipGetLastError();
     }
     if (rebuild) {
-        if ((e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s)) != hipSuccess) return e;
-        if (p.texels && (e = hipMemsetAsync(p.texels, 0, (size_t)p.N * p.N * p.nz * 4, s)) != hipSuccess) return e;
+        if (!p.planClear) {
+            if ((e = hipMemsetAsync(p.grid, 0, (size_t)p.N * p.N * p.nz, s)) != hipSuccess) return e;
+            if (p.texels && (e = hipMemsetAsync(p.texels, 0, (size_t)p.N * p.N * p.nz * 4, s)) != hipSuccess) return e;
+        }
         if (planEvents && (e = hipEventRecord(planEvents[0], s)) != hipSuccess) return e;
         if ((e = plan_build(p, s)) != hipSuccess) return e;
         if (planEvents && (e = hipEventRecord(planEvents[1], s)) != hipSuccess) return e;
