@@ -300,6 +300,7 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
 // Max-mip of the texels' far radii (dm_mip_max, dxv_dirmap.h).  k_dm_mip_tiles: one workgroup per TILE x TILE texels of a face
 // (TILE = min(R, 32)): level 0 from the cells, levels 1 .. log2(TILE) through LDS.  k_dm_mip_top: the levels above, one
 // workgroup, each level from the one below (a few hundred words at R = 256).
+template <bool COUNTS>
 __global__ __launch_bounds__(256) void k_dm_mip_tiles(const DirCell* __restrict__ cells, uint32_t R, uint32_t tile, uint16_t* __restrict__ mip)
 {
     __shared__ uint16_t lds[2][32 * 32];
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void k_dm_mip_tiles(const DirCell* __restrict_
     const uint32_t ti0 = (in % tilesPerSide) * tile, tj0 = (in / tilesPerSide) * tile;
     for (uint32_t k = threadIdx.x; k < tile * tile; k += 256u) {
         const uint32_t i = ti0 + k % tile, j = tj0 + k / tile;
-        const uint32_t key = dm_mip_key(cells[(face * R + j) * R + i]);
+        const uint32_t key = COUNTS ? dm_mip_count_key(cells[(face * R + j) * R + i]) : dm_mip_key(cells[(face * R + j) * R + i]);
         lds[0][k] = (uint16_t)key;
         mip[(face * R + j) * R + i] = (uint16_t)key;
     }
@@ -451,14 +452,43 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     return hipGetLastError();
 }
 
-// mip: dm_mip_words(R) 16-bit words
+// "A long list", per level of the count mip: one and a half times the mean of the level's non-empty cells (at least 8).  A brick's
+// rays look into a patch of texels whose size depends on the grid (4 voxels of 2 / N against texels of 2 / R); the launch picks the
+// level whose cells are about that patch (dm_heavy_level) and calls a brick heavy when the longest list it can look into is
+// longer than that level's word -- a scene of 13 entries per direction and one of 8 draw the line in different places.
+__global__ __launch_bounds__(256) void k_dm_heavy_thresholds(uint32_t R, const uint16_t* __restrict__ counts, uint16_t* __restrict__ thr)
+{
+    __shared__ unsigned long long sum[4];
+    __shared__ uint32_t num[4];
+    const uint32_t l = blockIdx.x, r = R >> l, n = 6u * r * r;
+    const uint16_t* cells = counts + dm_mip_offset(R, l);
+    unsigned long long s = 0;
+    uint32_t c = 0;
+    for (uint32_t k = threadIdx.x; k < n; k += 256u) { const uint32_t v = cells[k]; s += v; c += v ? 1u : 0u; }
+    for (int off = 32; off; off >>= 1) { s += __shfl_down(s, off); c += __shfl_down(c, off); }
+    if ((threadIdx.x & 63u) == 0u) { sum[threadIdx.x >> 6] = s; num[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const unsigned long long st = sum[0] + sum[1] + sum[2] + sum[3];
+        const uint32_t ct = num[0] + num[1] + num[2] + num[3];
+        const unsigned long long t = ct ? (3ull * st + 2ull * ct - 1ull) / (2ull * ct) : 8ull;
+        thr[l] = (uint16_t)(t < 8ull ? 8ull : t > 65535ull ? 65535ull : t);
+    }
+}
+
+// mip: dm_mip_buffer_words(R) 16-bit words (far radii, then entry counts, then the count levels' "long list" words)
 hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream_t s)
 {
     const uint32_t tile = R < 32u ? R : 32u;
     uint32_t tileLevel = 0;
     while ((1u << tileLevel) < tile) ++tileLevel;
-    k_dm_mip_tiles<<<6u * (R / tile) * (R / tile), 256, 0, s>>>(cells, R, tile, mip);
+    k_dm_mip_tiles<false><<<6u * (R / tile) * (R / tile), 256, 0, s>>>(cells, R, tile, mip);
     if (tileLevel + 1u < dm_mip_levels(R)) k_dm_mip_top<<<1, 1024, 0, s>>>(R, tileLevel, mip);
+    // ... and the max-mip of the texels' entry counts behind it (dm_box_max_count: which bricks a launch starts with)
+    uint16_t* counts = mip + dm_mip_words(R);
+    k_dm_mip_tiles<true><<<6u * (R / tile) * (R / tile), 256, 0, s>>>(cells, R, tile, counts);
+    if (tileLevel + 1u < dm_mip_levels(R)) k_dm_mip_top<<<1, 1024, 0, s>>>(R, tileLevel, counts);
+    k_dm_heavy_thresholds<<<dm_mip_levels(R), 256, 0, s>>>(R, counts, counts + dm_mip_words(R));
     return hipGetLastError();
 }
 

@@ -18,7 +18,11 @@
 using namespace dxv;
 
 namespace {
+#if defined(DXV_QUEUE_TIMES)
+constexpr uint32_t kRedoCap = 1u << 21;   // (diagnostic build: the list doubles as the buffer of per-workgroup time stamps)
+#else
 constexpr uint32_t kRedoCap = 1u << 16;   // rays per launch the redo pass takes before the column is grown instead
+#endif
 thread_local std::string g_createError;
 
 size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
@@ -93,7 +97,7 @@ struct dxv_ctx {
         bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
         bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
         hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
-        uint32_t queueLenMax = 0;        // longest of the frame's eight queues, as last read by dxv_sync ...
+        uint32_t queueLens[16] = {};     // the lengths of the frame's eight queues and how many of each are heavy, as last read by dxv_sync ...
         uint64_t queueLenSig = 0;        // ... for the queue of this signature (clearSig); 0: not known
         hipEvent_t evEnd = nullptr;      // behind the frame's last launch, always recorded: what a refit on another stream waits for on the device
         bool usedLists = false;          // the frame's last launch went through the direction-space lists ...
@@ -136,7 +140,7 @@ struct dxv_ctx {
         unsigned long long listTotal;
         uint32_t listLongest, pad;
         uint32_t status[DXV_FRAME_COUNT][4];
-        uint32_t queueLens[DXV_FRAME_COUNT][8 * 64];     // the eight length words of a frame's queue (each in a 256-byte line of its own)
+        uint32_t queueLens[DXV_FRAME_COUNT][16 * 64];    // the sixteen count words of a frame's queue (light and heavy bricks of the eight queues; each in a 256-byte line of its own)
     };
     Pinned* pin = nullptr;
     hipEvent_t evList[4] = {};       // around the counting pass, around the rest of the build
@@ -152,7 +156,9 @@ struct dxv_ctx {
     int optPlan = 1;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch, 2 = on every launch
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
+    int optQueueHeads = 8;           // heads per queue (persistent waves): 1, 2, 4, 8
     int optPlanRegion = 0;           // log2 of the run of Morton bricks dealt to one queue: 6, 7, 8; 0 = by the partition's size (plan_region_bits)
+    int optPlanHeavy = 0;            // list length beyond which a brick starts early; 0 = long for this scene (k_dm_heavy_thresholds), 65535: no brick does
     int optFuse = 1;                 // 1: the queue build clears the grid as well (one kernel in front of the brick kernel); 0: memsets in front of it
     int optDispatch = 1;             // a kept queue whose lengths the host knows: 0 = persistent waves all the same, 1 = one workgroup per
                                      // queued brick dealt out by the hardware (-1 ... -10 % per launch, and back-to-back launches overlap
@@ -540,7 +546,7 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels,
     // the max-mip of the texels' far radii goes with the lists (a launch's work queue is probed against it)
     if (dm_mip_words(R) > c->mipCap) {
         (void)hipFree(c->dMip); c->dMip = nullptr; c->mipCap = 0;
-        if ((e = hipMalloc(&c->dMip, sizeof(uint16_t) * (size_t)dm_mip_words(R))) != hipSuccess) return bail(e, "hipMalloc");
+        if ((e = hipMalloc(&c->dMip, sizeof(uint16_t) * (size_t)dm_mip_buffer_words(R))) != hipSuccess) return bail(e, "hipMalloc");   // (far radii, entry counts)
         c->mipCap = dm_mip_words(R);
     }
     if ((e = dirmap_mip(c->dListCells, R, c->dMip, stream)) != hipSuccess) return bail(e, "dirmap_mip");
@@ -713,9 +719,10 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
                 }
                 if (f.dQueue) {
                     queued = true; p.queue = f.dQueue + f.queueHdr * kQueueHeaderWords; p.queueSlots = f.dQueue + kQueueSlotsAt; p.queueCap = cap;
-                    p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves;
+                    p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves; p.queueHeads = (uint32_t)c->optQueueHeads;
                     p.planRegionBits = c->optPlanRegion ? (uint32_t)c->optPlanRegion : plan_region_bits(p.N, p.nz);
                     p.planClear = c->optFuse ? 1u : 0u;
+                    p.planHeavy = (uint32_t)c->optPlanHeavy;
                 }
             }
         }
@@ -776,14 +783,14 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch = false)
             auto mix = [&](uint64_t v) { sig = (sig ^ v) * 0x9E3779B97F4A7C15ull; sig ^= sig >> 29; };
             mix(0x7175657565ull); mix(c->listEpoch); mix(p.N); mix(p.nz); mix(p.z0); mix(p.zBlock); mix(p.zPeriod);
             mix(reinterpret_cast<uint64_t>(p.grid)); mix(reinterpret_cast<uint64_t>(p.texels)); mix(reinterpret_cast<uint64_t>(f.dQueue));
-            mix(p.planRegionBits);
+            mix(p.planRegionBits); mix(p.planHeavy);
             sig |= 1ull;
             const bool rebuild = c->optPlan == 2 || f.ptrExposed || f.clearSig != sig;
             hipEvent_t pe[2] = {f.evP0, f.evP1};
             // a queue launched again whose lengths an earlier dxv_sync has read: its size is known, the hardware can deal it out
             // (option dispatch: 1 = whenever known, 2 = for partitions of up to 2^25 voxels)
-            uint32_t listed = 0;
-            if (!rebuild && f.queueLenSig == sig && (c->optDispatch == 1 || (c->optDispatch == 2 && voxels <= (1ull << 25)))) listed = f.queueLenMax;
+            const uint32_t* listed = nullptr;
+            if (!rebuild && f.queueLenSig == sig && f.plan_bricks && (c->optDispatch == 1 || (c->optDispatch == 2 && voxels <= (1ull << 25)))) listed = f.queueLens;
             if (rebuild) {
                 // the new queue goes into the frame's other header, which the last build left cleared; this build clears the one it leaves
                 const uint32_t target = f.queueHdr ^ 1u;
@@ -1208,11 +1215,10 @@ int sync_frame(dxv_ctx* c, uint32_t i)
             f.redo_rays = f.lastRedoParity < 0 ? 0u : words[1 + f.lastRedoParity];
             if (readQueue) {
                 f.plan_bricks = 0;
-                f.queueLenMax = 0;
                 for (uint32_t x = 0; x < 8u; ++x) {
-                    const uint32_t len = lens[queue_len_word(x) - queue_len_word(0)];
-                    f.plan_bricks += len;
-                    if (len > f.queueLenMax) f.queueLenMax = len;
+                    f.queueLens[8u + x] = lens[queue_heavy_word(x) - queue_len_word(0)];
+                    f.queueLens[x] = lens[queue_len_word(x) - queue_len_word(0)] + f.queueLens[8u + x];
+                    f.plan_bricks += f.queueLens[x];
                 }
                 f.queueLenSig = f.clearSig;                             // (the queue of this signature: 0 = none kept)
                 if (f.lastRebuilt) f.plan_ms = f.timed ? elapsed(f.evP0, f.evP1) : 0.0f;
@@ -1589,7 +1595,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         // the max-mip of the far radii is a function of the cells: made here, not carried in the blob
         if (dm_mip_words(h.listRes) > c->mipCap) {
             (void)hipFree(c->dMip); c->dMip = nullptr; c->mipCap = 0;
-            DXV_HIP(c, hipMalloc(&c->dMip, sizeof(uint16_t) * (size_t)dm_mip_words(h.listRes)));
+            DXV_HIP(c, hipMalloc(&c->dMip, sizeof(uint16_t) * (size_t)dm_mip_buffer_words(h.listRes)));
             c->mipCap = dm_mip_words(h.listRes);
         }
         DXV_HIP(c, dirmap_mip(c->dListCells, h.listRes, c->dMip, c->stream));
@@ -1692,9 +1698,15 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "queuewaves")) {
         if (value < 0 || value > (1 << 20)) return fail(c, "option queuewaves: %lld not in [0, 2^20]", (long long)value);
         c->optQueueWaves = (int)value;
+    } else if (!strcmp(key, "queueheads")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, "option queueheads: %lld not in {1,2,4,8}", (long long)value);
+        c->optQueueHeads = (int)value;
     } else if (!strcmp(key, "planregion")) {
         if (value != 0 && (value < 6 || value > 8)) return fail(c, "option planregion: %lld not in {0,6,7,8}", (long long)value);
         c->optPlanRegion = (int)value;
+    } else if (!strcmp(key, "planheavy")) {
+        if (value < 0 || value > 65535) return fail(c, "option planheavy: %lld not in [0, 65535]", (long long)value);
+        c->optPlanHeavy = (int)value;
     } else if (!strcmp(key, "fuse")) {
         if (value != 0 && value != 1) return fail(c, "option fuse: %lld not in {0,1}", (long long)value);
         c->optFuse = (int)value;

@@ -53,7 +53,7 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
                        uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longest,
                        hipStream_t s);
 
-// max-mip of the texels' far radii (dxv_dirmap.h: dm_mip_max), dm_mip_words(R) 16-bit words: what the launch's work queue is probed against
+// max-mips of the texels' far radii and entry counts (dxv_dirmap.h: dm_mip_max), dm_mip_buffer_words(R) 16-bit words: what the launch's work queue is probed against
 hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream_t s);
 
 // consistency of a list section that arrived in a blob (dxv_scene_import): out[0] = cells whose range leaves the entries,
@@ -96,8 +96,10 @@ struct VoxelizeParams {
     uint32_t* queueZero;    // ... the frame's OTHER header, cleared by k_plan_bricks for the launch that builds the next queue (or NULL)
     uint32_t queueCap;
     uint32_t planRegionBits; // log2 of the run of consecutive Morton bricks that goes to one queue (6, 7 or 8)
+    uint32_t planHeavy;     // a brick that can look into a list of more entries than this goes to the front of its queue; 0: the scene's own "long list" (k_dm_heavy_thresholds)
     uint32_t planClear;     // 1: k_plan_bricks also clears the grid (and the texel image): no memset in front of it
     uint32_t queueWaves;    // persistent waves to launch; 0 = what the device holds at once
+    uint32_t queueHeads;    // heads per queue the persistent waves draw from: 1, 2, 4 or 8
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
@@ -105,10 +107,16 @@ hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEnt
 // number 8 x + h), then the eight lengths, every word in a 256-byte line of its own.  Queue memory of a frame: TWO headers, then
 // the slots: a launch that builds a queue takes the header the last build did not use -- all zero, because that build's
 // k_plan_bricks cleared it (and the allocation cleared both) -- so no memset stands between a launch and its queue build.
-constexpr uint32_t kQueueHeaderWords = 5120u;
+// A queue is filled from both ends: the bricks that can look into a long list (dm_box_max_count: the few that take several times
+// the mean) from slot 0 upwards, all others from slot cap - 1 downwards; its items are numbered heavy first (queue_slot), so a
+// launch starts with its long bricks and ends with ordinary ones.  Header words per queue: eight heads, the number of heavy and
+// the number of light bricks.
+constexpr uint32_t kQueueHeaderWords = 5632u;
 constexpr uint32_t kQueueSlotsAt = 2u * kQueueHeaderWords;
 DXV_HD constexpr uint32_t queue_head_word(uint32_t x, uint32_t h) { return 64u * (1u + 8u * x + h); }
-DXV_HD constexpr uint32_t queue_len_word(uint32_t x) { return 64u * (65u + x); }
+DXV_HD constexpr uint32_t queue_len_word(uint32_t x) { return 64u * (65u + x); }      // light bricks of queue x
+DXV_HD constexpr uint32_t queue_heavy_word(uint32_t x) { return 64u * (73u + x); }    // heavy bricks of queue x (the sixteen words lie behind one another: one copy for dxv_sync)
+DXV_HD constexpr uint32_t queue_slot(uint32_t k, uint32_t heavy, uint32_t cap) { return k < heavy ? k : cap - 1u - (k - heavy); }   // item k of a queue
 // work queue of the lists kernel with 4 x 4 x 4 bricks (traverse.hip): built on the device in front of the launch
 uint32_t plan_layout(VoxelizeParams& p);           // fills the brick-order fields for the whole partition, returns its bricks
 uint32_t plan_region_bits(uint32_t N, uint32_t nz); // the run length (log2 bricks) a partition of this size deals to its queues
@@ -116,7 +124,8 @@ size_t plan_queue_words(uint32_t N, uint32_t nz, uint32_t* capOut);     // 32-bi
 hipError_t plan_build(const VoxelizeParams& p, hipStream_t s);          // k_plan_bricks into the (zero) header p.queue; p.queueSlots, p.queueCap, p.mip set
 // rebuild: grid cleared + queue built in front of the kernel; else only the queue heads are reset (same launch as before into the same buffers)
 // (planEvents: two events recorded around the queue build of a rebuilding launch, or NULL)
-hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, uint32_t listedLen, hipStream_t s);
+// listedLens: the eight lengths of a kept queue and how many of each are heavy (16 words) as the host last read them (one workgroup per item, dealt out by the hardware), or NULL (persistent waves)
+hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, const uint32_t* listedLens, hipStream_t s);
 // test hook: every voxel's first-step decision against the queue; bits: one per brick of the partition, out: 16 words
 hipError_t launch_plan_check(const VoxelizeParams& p, uint32_t* bits, unsigned long long* out, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack

@@ -215,6 +215,7 @@ DXV_HD uint32_t dm_mip_offset(uint32_t R, uint32_t level)
 }
 DXV_HD uint32_t dm_mip_words(uint32_t R) { return dm_mip_offset(R, dm_mip_levels(R)); }    // 16-bit words
 DXV_HD uint32_t dm_mip_key(const DirCell& c) { return c.count ? (uint32_t)c.r1max : 0u; }
+DXV_HD uint32_t dm_mip_count_key(const DirCell& c) { return (uint32_t)c.count; }       // the second mip (behind the first): list lengths
 
 // maximum key over texels [i0, i1] x [j0, j1] of a face (a superset: the coarsest level at which the rectangle is at most
 // 2 x 2 cells; four loads)
@@ -244,39 +245,76 @@ DXV_HD uint32_t dm_mip_max(const uint16_t* mip, uint32_t R, uint32_t face, uint3
 //    faces of three of its corners; per present face the texel rectangle of the box comes from the extreme quotients;
 //  * every ray of the box starts at or beyond rhoMin: dead iff every texel it can look into is empty or ends before
 //    rhoMin * 0.999f.
+// (the faces a box of one octant can look into, each with the rectangle of texels its rays can fall on: visit(face, i0, i1, j0, j1)
+// returns true to stop; the box must not straddle a centre plane)
+template <class Visit>
+DXV_HD bool dm_box_faces(float x0, float x1, float y0, float y1, float z0, float z1, uint32_t R, Visit&& visit)
+{
+    const bool nx = x1 < 0.0f, ny = y1 < 0.0f, nz = z1 < 0.0f;
+    const float xa = nx ? -x1 : x0, xb = nx ? -x0 : x1, ya = ny ? -y1 : y0, yb = ny ? -y0 : y1, za = nz ? -z1 : z0, zb = nz ? -z0 : z1;
+    // rectangle of texels for numerator range [na, nb] (sign neg) over denominator range [da, db]
+    auto range = [&](float na, float nb, bool neg, float da, float db, uint32_t& t0, uint32_t& t1) {
+        const float lo = na / db, hi = nb / da;
+        t0 = dm_texel(neg ? -hi : lo, R); t1 = dm_texel(neg ? -lo : hi, R);
+    };
+    uint32_t i0, i1, j0, j1;
+    if (xb >= ya && xb >= za) {                                         // face X: u = y / |x|, v = z / |x|
+        range(ya, yb, ny, xa, xb, i0, i1); range(za, zb, nz, xa, xb, j0, j1);
+        if (visit(nx ? 1u : 0u, i0, i1, j0, j1)) return true;
+    }
+    if (!(xa >= yb && xa >= za) && yb >= za) {                          // face Y: u = z / |y|, v = x / |y|
+        range(za, zb, nz, ya, yb, i0, i1); range(xa, xb, nx, ya, yb, j0, j1);
+        if (visit(ny ? 3u : 2u, i0, i1, j0, j1)) return true;
+    }
+    if (!(xa >= ya && xa >= zb) && !(ya >= zb)) {                       // face Z: u = x / |z|, v = y / |z|
+        range(xa, xb, nx, za, zb, i0, i1); range(ya, yb, ny, za, zb, j0, j1);
+        if (visit(nz ? 5u : 4u, i0, i1, j0, j1)) return true;
+    }
+    return false;
+}
+DXV_HD bool dm_box_straddles(float x0, float x1, float y0, float y1, float z0, float z1)
+{
+    return !(x0 > 0.0f || x1 < 0.0f) || !(y0 > 0.0f || y1 < 0.0f) || !(z0 > 0.0f || z1 < 0.0f);
+}
 DXV_HD bool dm_box_may_be_live(float x0, float x1, float y0, float y1, float z0, float z1, const float* rootLo, const float* rootHi,
                                const uint16_t* mip, uint32_t R)
 {
     if ((x0 > 0.0f && axis_leaves_root(x0, rootLo[0], rootHi[0])) || (x1 < 0.0f && axis_leaves_root(x1, rootLo[0], rootHi[0]))) return false;
     if ((y0 > 0.0f && axis_leaves_root(y0, rootLo[1], rootHi[1])) || (y1 < 0.0f && axis_leaves_root(y1, rootLo[1], rootHi[1]))) return false;
     if ((z0 > 0.0f && axis_leaves_root(z0, rootLo[2], rootHi[2])) || (z1 < 0.0f && axis_leaves_root(z1, rootLo[2], rootHi[2]))) return false;
-    if (!(x0 > 0.0f || x1 < 0.0f) || !(y0 > 0.0f || y1 < 0.0f) || !(z0 > 0.0f || z1 < 0.0f)) return true;     // straddles a centre plane
+    if (dm_box_straddles(x0, x1, y0, y1, z0, z1)) return true;          // straddles a centre plane
     const bool nx = x1 < 0.0f, ny = y1 < 0.0f, nz = z1 < 0.0f;
-    const float xa = nx ? -x1 : x0, xb = nx ? -x0 : x1, ya = ny ? -y1 : y0, yb = ny ? -y0 : y1, za = nz ? -z1 : z0, zb = nz ? -z0 : z1;
+    const float xa = nx ? -x1 : x0, ya = ny ? -y1 : y0, za = nz ? -z1 : z0;
     const float rhoMin = __builtin_sqrtf((xa * xa + ya * ya) + za * za), nearMin = rhoMin * 0.999f;
-    // rectangle of texels for numerator range [na, nb] (sign neg) over denominator range [da, db]
-    auto range = [&](float na, float nb, bool neg, float da, float db, uint32_t& t0, uint32_t& t1) {
-        const float lo = na / db, hi = nb / da;
-        t0 = dm_texel(neg ? -hi : lo, R); t1 = dm_texel(neg ? -lo : hi, R);
-    };
-    auto face_live = [&](uint32_t face, uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1) {
+    return dm_box_faces(x0, x1, y0, y1, z0, z1, R, [&](uint32_t face, uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1) {
         const uint32_t key = dm_mip_max(mip, R, face, i0, i1, j0, j1);
         return key != 0u && !(half_bits_to_float(key) < nearMin);
-    };
-    uint32_t i0, i1, j0, j1;
-    if (xb >= ya && xb >= za) {                                         // face X: u = y / |x|, v = z / |x|
-        range(ya, yb, ny, xa, xb, i0, i1); range(za, zb, nz, xa, xb, j0, j1);
-        if (face_live(nx ? 1u : 0u, i0, i1, j0, j1)) return true;
-    }
-    if (!(xa >= yb && xa >= za) && yb >= za) {                          // face Y: u = z / |y|, v = x / |y|
-        range(za, zb, nz, ya, yb, i0, i1); range(xa, xb, nx, ya, yb, j0, j1);
-        if (face_live(ny ? 3u : 2u, i0, i1, j0, j1)) return true;
-    }
-    if (!(xa >= ya && xa >= zb) && !(ya >= zb)) {                       // face Z: u = x / |z|, v = y / |z|
-        range(xa, xb, nx, za, zb, i0, i1); range(ya, yb, ny, za, zb, j0, j1);
-        if (face_live(nz ? 5u : 4u, i0, i1, j0, j1)) return true;
-    }
-    return false;
+    });
+}
+// The longest list any ray of the box can look into (an upper bound: the same rectangles through the max-mip of the texels' entry
+// counts, which lies behind the first mip in memory).  Not a matter of results: it decides which bricks a launch starts with --
+// a brick is as long as its longest list, one in a hundred takes three to seven times the mean, and a launch whose last bricks
+// are of that kind ends with a handful of waves on an idle GPU (k_plan_bricks).  Boxes that straddle a centre plane: 0.
+DXV_HD uint32_t dm_box_max_count(float x0, float x1, float y0, float y1, float z0, float z1, const uint16_t* countMip, uint32_t R)
+{
+    if (dm_box_straddles(x0, x1, y0, y1, z0, z1)) return 0u;
+    uint32_t most = 0;
+    (void)dm_box_faces(x0, x1, y0, y1, z0, z1, R, [&](uint32_t face, uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1) {
+        const uint32_t c = dm_mip_max(countMip, R, face, i0, i1, j0, j1);
+        if (c > most) most = c;
+        return false;
+    });
+    return most;
+}
+// memory of the two mips and the per-level "long list" words behind them (dirmap.hip: k_dm_heavy_thresholds), 16-bit words
+DXV_HD uint32_t dm_mip_buffer_words(uint32_t R) { return 2u * dm_mip_words(R) + 16u; }
+// the level of the count mip whose cells are about the patch of texels a 4^3-voxel brick of an N^3 grid looks into
+// (4 voxels of 2 / N at a typical distance of 0.7 from the centre: ~5.6 R / N texels across)
+DXV_HD uint32_t dm_heavy_level(uint32_t R, uint32_t N)
+{
+    uint32_t l = 0;
+    while ((1u << (l + 1u)) * N <= 8u * R && l + 1u < dm_mip_levels(R)) ++l;      // 2^l <= 8 R / N < 2^(l + 1):  512 / 512 -> 3, 512 / 256 -> 4, 512 / 1024 -> 2
+    return l;
 }
 
 // the hull of the voxel centres of brick (bx, by, bz) of 4 x 4 x 4 voxels in a partition's local brick grid (x0 <= x1 ...; y falls

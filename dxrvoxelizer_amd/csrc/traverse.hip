@@ -144,8 +144,7 @@ __device__ __forceinline__ void plan_clear(uint8_t* base, size_t bytes, uint32_t
 
 __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t nb)
 {
-    __shared__ uint32_t waveCount[4];
-    __shared__ uint32_t groupBase[4];
+    __shared__ uint32_t heavyCount[4], lightCount[4], heavyBase[4], lightBase[4];
     const uint32_t lin = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     bool live = false;
     uint32_t bx = 0, by = 0, bz = 0;
@@ -161,24 +160,38 @@ __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t 
     }
     if (p.queueZero && blockIdx.x == 0u)
         for (uint32_t k = threadIdx.x; k < kQueueHeaderWords; k += 256u) p.queueZero[k] = 0u;
-    const unsigned long long m = __ballot(live);
-    if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
+    // heavy: one of the brick's rays can look into a list that is long for this scene (one and a half times the mean of the count
+    // mip at the level of a brick's patch of texels: k_dm_heavy_thresholds) -- 2 - 6 % of the queued bricks, among them 99 % of those
+    // that take three times the mean and more (profiles/r05/brick_features.jsonl)
+    bool heavy = false;
+    if (live) {
+        float x0, x1, y0, y1, z0, z1;
+        dm_brick_hull(p.N, p.nz, p.z0, p.zBlock, p.zShift, p.zPeriod, bx, by, bz, x0, x1, y0, y1, z0, z1);
+        const uint16_t* countMip = p.mip + dm_mip_words(p.scene.dmR);
+        const uint32_t longList = p.planHeavy ? p.planHeavy : countMip[dm_mip_words(p.scene.dmR) + dm_heavy_level(p.scene.dmR, p.N)];
+        heavy = dm_box_max_count(x0, x1, y0, y1, z0, z1, countMip, p.scene.dmR) > longList;
+    }
+    const unsigned long long mh = __ballot(live && heavy), ml = __ballot(live && !heavy);
+    if (lane == 0u) { heavyCount[w] = (uint32_t)__builtin_popcountll(mh); lightCount[w] = (uint32_t)__builtin_popcountll(ml); }
     __syncthreads();
     // Runs of 2^planRegionBits consecutive Morton bricks go to one queue, the runs dealt round-robin: 256 (8 x 8 x 4 bricks, the whole
-    // workgroup) on large partitions -- an XCD's L2 sees compact pieces of the grid; 64 (4 x 4 x 4 bricks, one wave each) on small
-    // ones, where eight queues of a few dozen runs each differ by 10 - 20 % in cost and the launch ends with its longest queue.
+    // workgroup: an XCD's L2 sees compact pieces of the grid), 128 or 64 (one wave each).
     const uint32_t wavesPerRun = 1u << (p.planRegionBits - 6u), first = w & ~(wavesPerRun - 1u);
     const uint32_t x = (lin >> p.planRegionBits) & 7u;
     if (lane == 0u && w == first) {
-        uint32_t n = 0;
-        for (uint32_t k = 0; k < wavesPerRun; ++k) n += waveCount[first + k];
-        groupBase[first] = n ? atomicAdd(p.queue + queue_len_word(x), n) : 0u;
+        uint32_t nh = 0, nl = 0;
+        for (uint32_t k = 0; k < wavesPerRun; ++k) { nh += heavyCount[first + k]; nl += lightCount[first + k]; }
+        heavyBase[first] = nh ? atomicAdd(p.queue + queue_heavy_word(x), nh) : 0u;
+        lightBase[first] = nl ? atomicAdd(p.queue + queue_len_word(x), nl) : 0u;
     }
     __syncthreads();
     if (!live) return;
-    uint32_t rank = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-    for (uint32_t k = first; k < w; ++k) rank += waveCount[k];
-    p.queueSlots[(size_t)x * p.queueCap + groupBase[first] + rank] = bx | (by << 10) | (bz << 20);
+    const unsigned long long before = (1ull << lane) - 1ull;
+    uint32_t rank = (uint32_t)__builtin_popcountll((heavy ? mh : ml) & before);
+    for (uint32_t k = first; k < w; ++k) rank += heavy ? heavyCount[k] : lightCount[k];
+    // (heavy bricks from slot 0 upwards, the others from the far end downwards: queue_slot)
+    const uint32_t slot = heavy ? heavyBase[first] + rank : p.queueCap - 1u - (lightBase[first] + rank);
+    p.queueSlots[(size_t)x * p.queueCap + slot] = bx | (by << 10) | (bz << 20);
 }
 
 // the brick order of the whole partition (no brick box): what k_plan_bricks, the checker and the host agree on
@@ -239,9 +252,9 @@ __global__ __launch_bounds__(256) void k_plan_mark(VoxelizeParams p, uint32_t* _
 {
     const uint32_t nbx = (p.N + 3u) / 4u;
     for (uint32_t x = 0; x < 8u; ++x) {
-        const uint32_t len = p.queue[queue_len_word(x)];
+        const uint32_t heavy = p.queue[queue_heavy_word(x)], len = heavy + p.queue[queue_len_word(x)];
         for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < len; k += gridDim.x * 256u) {
-            const uint32_t w = p.queueSlots[(size_t)x * p.queueCap + k];
+            const uint32_t w = p.queueSlots[(size_t)x * p.queueCap + queue_slot(k, heavy, p.queueCap)];
             const uint32_t id = ((w >> 20) * nbx + ((w >> 10) & 1023u)) * nbx + (w & 1023u);
             const uint32_t old = atomicOr(bits + (id >> 5), 1u << (id & 31u));
             if (old & (1u << (id & 31u))) atomicAdd(out + 4, 1ull);
@@ -290,6 +303,88 @@ hipError_t launch_plan_check(const VoxelizeParams& pin, uint32_t* bits, unsigned
 }
 
 // ---------------------------------------------------------------------------------------------
+// Eight queues of unequal length, eight XCDs of equal appetite.  Runs of bricks are dealt to the queues by their number, not by
+// what they hold: on a rank's share of the grid the queues differ by up to 30 % in length (bunny x16 at 8 ranks: 6,400 against
+// 9,100 bricks), and a launch ends with its longest queue while half of the GPU idles (profiles/r05/wg_times_before.jsonl).  So
+// the launch is dealt out in EQUAL shares: XCD x runs T = ceil(total / 8) items -- its own queue's first min(len_x, T), and, when
+// its queue is shorter than T, items from the far end of the queues that are longer (what they hold beyond their own first T), in
+// queue order.  A pure function of the eight lengths, which every workgroup reads from the header: no second pass over the
+// queues, nothing moved; 85 - 100 % of an XCD's bricks are still its own compact runs.
+// ---------------------------------------------------------------------------------------------
+struct QueueLens { uint32_t len[8], heavy[8]; };        // items per queue, of which heavy
+#if defined(__HIP_DEVICE_COMPILE__)
+// (the arithmetic runs on lanes 0 .. 7 of the wave -- one length each -- where a brick body that has not begun yet leaves every
+// vector register free; held in scalar registers the eight lengths cost the persistent kernel a wave per SIMD)
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v, int n)      // lane i <- lane i - n of its row of 16, 0 where there is none
+{
+    return n == 1 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true)
+         : n == 2 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true)
+                  : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t prefix8(uint32_t v)                 // inclusive prefix sums over lanes 0 .. 7 (v = 0 on the lanes behind them)
+{
+    v += dpp_row_shr(v, 1); v += dpp_row_shr(v, 2); v += dpp_row_shr(v, 4);
+    return v;
+}
+__device__ __forceinline__ uint32_t queue_lens(const uint32_t* hdr, uint32_t& T, uint32_t& H)   // lane a < 8: items of queue a, of which H heavy; T = ceil(total / 8)
+{
+    uint32_t lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    H = lane < 8u ? hdr[queue_heavy_word(0) + 64u * lane] : 0u;
+    const uint32_t L = lane < 8u ? hdr[queue_len_word(0) + 64u * lane] + H : 0u;
+    T = ((uint32_t)__builtin_amdgcn_readlane((int)prefix8(L), 7) + 7u) >> 3;
+    return L;
+}
+// item j (< T) of XCD x: queue and slot; false: none (the last few of the 8 T items when the total is no multiple of 8)
+__device__ __forceinline__ bool queue_item(const uint32_t* hdr, uint32_t cap, uint32_t x, uint32_t j, uint32_t& y, uint32_t& slot)
+{
+    uint32_t T, H, lane, k;
+    const uint32_t L = queue_lens(hdr, T, H), lenX = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)x);
+    if (j < lenX) { y = x; k = j; }                             // (j < T: one of the queue's own first T)
+    else {
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const uint32_t spare = lane < 8u && L < T ? T - L : 0u, extra = L > T ? L - T : 0u;
+        const uint32_t spareBefore = prefix8(spare) - spare, extraBefore = prefix8(extra) - extra;
+        // the (j - len_x)-th slot this XCD has to spare, counted behind the spare slots of the XCDs 0 .. x - 1, is given the g-th
+        // brick that some queue holds beyond its own first T
+        const uint32_t g = j - lenX + (uint32_t)__builtin_amdgcn_readlane((int)spareBefore, (int)x);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(lane < 8u && g >= extraBefore && g - extraBefore < extra);
+        if (!m) return false;
+        y = (uint32_t)__builtin_ctzll(m);
+        k = T + g - (uint32_t)__builtin_amdgcn_readlane((int)extraBefore, (int)y);
+    }
+    slot = queue_slot(k, (uint32_t)__builtin_amdgcn_readlane((int)H, (int)y), cap);
+    return true;
+}
+// the same from eight lengths the host holds (a kept queue, k_voxelize_listed: kernel arguments, no load in front of the brick's own)
+__device__ __forceinline__ bool queue_item(const QueueLens& q, uint32_t cap, uint32_t x, uint32_t j, uint32_t& y, uint32_t& slot)
+{
+    uint32_t total = 0, lenX = 0, k = 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { total += q.len[a]; lenX = x == (uint32_t)a ? q.len[a] : lenX; }
+    const uint32_t T = (total + 7u) >> 3;
+    bool found = j < lenX;
+    y = x; k = j;
+    if (!found) {
+        uint32_t g = j - lenX;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) g += ((uint32_t)a < x && q.len[a] < T) ? T - q.len[a] : 0u;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const uint32_t extra = q.len[a] > T ? q.len[a] - T : 0u;
+            if (!found && g < extra) { y = (uint32_t)a; k = T + g; found = true; }
+            g -= found ? 0u : extra;
+        }
+    }
+    uint32_t heavy = 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) heavy = y == (uint32_t)a ? q.heavy[a] : heavy;
+    slot = queue_slot(k, heavy, cap);
+    return found;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // The lists kernel over the work queue: persistent single-wave workgroups (see above).  One brick = one pass of the body of
 // k_voxelize<Brick<4,4,4>, 16, 0, TEXELS, 4>; the 64 result bytes of a brick leave as 16 dwords (one per 4-voxel row,
 // assembled from the wave's ballot) instead of 64 bytes.
@@ -311,17 +406,23 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
     // Every head has HOME waves that drain it to its last slot: wave w of XCD x (x = block % 8, w = block / 8) is home to the heads
     // h = w (mod 8) of queue x -- to h = w (mod W) when fewer than eight waves per XCD were launched, so that no head is without
     // one (which XCD a block really runs on is a matter of speed only).
-    const uint32_t x0 = blockIdx.x & 7u, wx = blockIdx.x >> 3, perXcd = gridDim.x >> 3, homes = perXcd < 8u ? perXcd : 8u;
+    const uint32_t nh = p.queueHeads;                                   // heads per queue in use: 1, 2, 4 or 8 (head h hands out the items = h mod nh)
+    const uint32_t x0 = blockIdx.x & 7u, wx = blockIdx.x >> 3, perXcd = gridDim.x >> 3, homes = perXcd < nh ? perXcd : nh;
     uint64_t homeMask = 0;
-    for (uint32_t h = wx % homes; h < 8u; h += homes) homeMask |= 1ull << (8u * x0 + h);
+    for (uint32_t h = wx % homes; h < nh; h += homes) homeMask |= 1ull << (8u * x0 + h);
     uint32_t cur = 8u * x0 + wx % homes;
     uint64_t tried = 0;
     for (;;) {
         tried |= 1ull << cur;
         const uint32_t x = cur >> 3, h = cur & 7u;
-        const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
+        uint32_t len, own, ownHeavy;                                    // items of XCD x: its equal share of the launch (queue_item)
+        {
+            uint32_t H;
+            const uint32_t L = queue_lens(p.queue, len, H);
+            own = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)x);  // ... of which its own queue's, and how many of those are heavy
+            ownHeavy = (uint32_t)__builtin_amdgcn_readlane((int)H, (int)x);
+        }
         uint32_t* head = p.queue + queue_head_word(x, h);
-        const uint32_t* slots = p.queueSlots + (size_t)x * p.queueCap;
         if (len > h) {
         // One brick ahead: the add for the next brick is issued in front of the current one, and its answer is taken out of its
         // vector register as soon as the brick's first load (the rays' cells: all 64 lanes make that step together) has arrived --
@@ -331,20 +432,30 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
         uint32_t jv = 0;
         if (threadIdx.x == 0u) jv = atomicAdd(head, 1u);
         uint32_t next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);
+        uint32_t wAhead = 0xffffffffu;                                  // the next brick's word when it was fetched during the current brick (no brick word has its top bits set)
+        bool asked = false;                                             // an add is in flight (asked for behind the last brick's scan)
         for (;;) {
-            const uint32_t k = 8u * next + h;
+            const uint32_t k = nh * next + h;
             if (k >= len) break;
             const bool ahead = len - k > kQueueNoPrefetch;
-            if (ahead && threadIdx.x == 0u) jv = atomicAdd(head, 1u);
-            uint32_t w;                                                 // through the scalar cache: one word per wave
-            const uint32_t* slot = slots + k;
-            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
+            if (ahead && !asked && threadIdx.x == 0u) jv = atomicAdd(head, 1u);   // (a head's first brick; later ones: behind the scan of the brick before)
             // The launch's parameters are read from the kernel-argument segment again for every brick (scalar loads that
             // hit the scalar cache): kept across the loop they would hold fifty SGPRs through the whole brick body, and the
             // body (the one of k_voxelize: 70 VGPRs, 56 SGPRs) would lose a wave per SIMD to registers.
             typedef const __attribute__((address_space(4))) VoxelizeParams* KernArg;
             KernArg pp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(pp));
+            uint32_t w = wAhead;                                        // through the scalar cache: one word per wave
+            if (w == 0xffffffffu) {
+                const uint32_t* hdr = pp->queue;
+                const uint32_t cap = pp->queueCap;
+                uint32_t qy = x, qslot = queue_slot(k, ownHeavy, cap);
+                bool any = true;
+                if (k >= own) any = queue_item(hdr, cap, x, k, qy, qslot);      // (beyond the XCD's own queue: a longer queue's far end)
+                if (!any) break;                                        // (only the very last items of the launch)
+                const uint32_t* slot = pp->queueSlots + (uint32_t)__builtin_amdgcn_readfirstlane((int)(qy * cap + qslot));   // (8 cap <= 2^27 bricks)
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
+            }
             SceneView sc;                                               // (what the lists' path reads of it)
             sc.nodes = nullptr; sc.wide = nullptr; sc.plCells = nullptr; sc.plEntries = nullptr; sc.plR = 0;
             sc.triPos = pp->scene.triPos; sc.triNrm = pp->scene.triNrm;
@@ -366,12 +477,34 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
             ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
             const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
             DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
-            if (ahead) next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);    // the next brick's number
+            wAhead = 0xffffffffu;
+            if (ahead) {
+                next = (uint32_t)__builtin_amdgcn_readlane((int)jv, 0);  // the next brick's number
+                // ... and its word, asked for now: fetched at the top of the loop it is a scalar load that nothing hides -- 0.7 us of an
+                // 11 us brick, the difference between these waves and a workgroup per brick dealt out by the hardware.  (One scalar
+                // register through the body; items beyond the XCD's own queue -- queue_item -- are looked up when their turn comes.)
+                const uint32_t kn = nh * next + h;
+                if (kn < own) {
+                    typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+                    wAhead = ((ConstWords)pp->queueSlots)[x * pp->queueCap + queue_slot(kn, ownHeavy, pp->queueCap)];
+                }
+            }
             if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) start.live = false;   // provably missMain
             Hit best;
             float bestDet = 1.0f;
             const StridedStack stk{stack + tid, 64};
             trace_reference_dm_from<StridedStack, 0>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
+            // The add for the brick AFTER the next one, here: vector memory answers in order, so an add asked for right in front of a
+            // brick's first load makes that load wait for the add's 1.1 - 1.3 us instead of its own 0.8 -- asked for behind the scan,
+            // it has the predicate, the stores and the next brick's ray set-up (nine divisions) to come back in.
+            asked = false;
+            if (ahead) {
+                const uint32_t kn = nh * next + h;
+                if (kn < len && len - kn > kQueueNoPrefetch) {
+                    if (threadIdx.x == 0u) jv = atomicAdd(head, 1u);
+                    asked = true;
+                }
+            }
             uint32_t texel = 0;
             const uint8_t occ = shade_reference<4, 0>(sc, r, best, bestDet, TEXELS ? &texel : nullptr);
             // the lane's voxel once more (nothing of it was kept through the body)
@@ -426,18 +559,23 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
 
 // The same brick body with one workgroup per queued brick, dispatched by the hardware: for a queue that is launched AGAIN and whose
 // eight lengths the host has read meanwhile (dxv_sync of an earlier launch of the same queue) -- the launch's size is then
-// known without a round trip of its own.  Workgroup b takes slot b / 8 of queue b % 8 (workgroups b and b + 8 share an XCD);
+// known without a round trip of its own.  Workgroup b takes item b / 8 of XCD b % 8's equal share (workgroups b and b + 8 share an XCD);
 // no heads, no adds, parameters in scalar registers from the start.  What it is for: short launches (a 256^3 grid, a rank's
 // share), whose few bricks per persistent wave leave the end of the launch ragged (option dispatch).
 template <bool TEXELS>
-__global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p)
+__global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, QueueLens lens)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ int32_t stack[16 * 64];
     const uint32_t x = blockIdx.x & 7u, k = blockIdx.x >> 3;
-    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queue[queue_len_word(x)]);
-    if (k >= len) return;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queueSlots[(size_t)x * p.queueCap + k]);
+#if defined(DXV_QUEUE_TIMES)
+    const uint64_t tStart = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0u && 3u * blockIdx.x + 2u < p.redoCap) { p.redo[3u * blockIdx.x] = 0; p.redo[3u * blockIdx.x + 1u] = 0; }
+#endif
+    // (x's equal share of the launch: its own queue's first bricks, then what longer queues hold beyond theirs -- queue_item)
+    uint32_t qy, qslot;
+    if (!queue_item(lens, p.queueCap, x, k, qy, qslot)) return;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queueSlots[(size_t)qy * p.queueCap + qslot]);
     const SceneView& sc = p.scene;
     const uint32_t N = p.N, nz = p.nz;
     const uint32_t bx = w & 1023u, by = (w >> 10) & 1023u, bz = w >> 20;
@@ -472,6 +610,15 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p)
             *reinterpret_cast<uint32_t*>(p.grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;
         }
     }
+#if defined(DXV_QUEUE_TIMES)
+    // (diagnostic build only, tools/wg_times.py: start and end of every workgroup in 100 MHz ticks, and the XCD it ran on)
+    if (threadIdx.x == 0u && 3u * blockIdx.x + 2u < p.redoCap) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.redo[3u * blockIdx.x] = tStart; p.redo[3u * blockIdx.x + 1u] = (__builtin_amdgcn_s_memrealtime() & 0x0fffffffffffffffull) | ((uint64_t)(xcc & 15u) << 60);
+        p.redo[3u * blockIdx.x + 2u] = w;
+    }
+#endif
 #else
     (void)p;
 #endif
@@ -495,15 +642,22 @@ static uint32_t queue_waves(bool texels)
 // rebuild: clear the grid and build the queue in front of the launch (a launch that may not rely on anything an earlier
 // launch left behind); else the caller vouches that the frame's grid and queue are those of the same launch made before
 // (same lists, partition and buffers: the kernel writes the same bricks every time) and only the queue heads are reset.
-hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, uint32_t listedLen, hipStream_t s)
+hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, const uint32_t* listedLens, hipStream_t s)
 {
+    QueueLens lens{};
+    uint32_t listedLen = 0;
+    if (listedLens) {
+        uint32_t total = 0;
+        for (int a = 0; a < 8; ++a) { lens.len[a] = listedLens[a]; lens.heavy[a] = listedLens[8 + a]; total += listedLens[a]; }
+        listedLen = (total + 7u) / 8u;
+    }
     const VoxelizeParams& p = pin;
     hipError_t e;
     if (!rebuild && listedLen) {
-        // the queue as it stands, one workgroup per slot of the longest of the eight queues and per queue
+        // the queue as it stands, one workgroup per item of an XCD's equal share (listedLen = ceil(total / 8)) and per XCD
         if (wavesOut) *wavesOut = 8u * listedLen;
-        if (p.texels) k_voxelize_listed<true><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p);
-        else k_voxelize_listed<false><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p);
+        if (p.texels) k_voxelize_listed<true><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens);
+        else k_voxelize_listed<false><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens);
         return hipGetLastError();
     }
     if (rebuild) {

@@ -23,9 +23,9 @@ vb, ib, _ = make_mesh(mesh)
 v.InitFromArrays(vb, ib)
 share = int(os.environ.get("QT_WORLD", "1"))          # QT_WORLD=8: rank 0's share of the block-cyclic partition instead of the whole grid
 for _ in range(3):
-    v.VoxelizeInterleaved(N, 0, share, 8, 0) if share > 1 else v.Voxelize(N, 0)
+    v.VoxelizeInterleaved(N, 0, share, 4, 0) if share > 1 else v.Voxelize(N, 0)
 st = v.stats()
-raw = np.zeros(1 << 16, np.uint64)
+raw = np.zeros(1 << 21, np.uint64)
 v._check(v._lib.dxv_debug_download(v._ctx, 100, raw.ctypes.data_as(C.c_void_p), raw.nbytes))
 w = st["plan_waves"]
 t = raw[:4 * w].reshape(w, 4).astype(np.int64)

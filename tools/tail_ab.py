@@ -39,7 +39,7 @@ def main():
         v.InitFromArrays(vb, ib)
         v.build_lists(grid=N)
         acc = {name: {"full_kept": [], "full_fresh": [], "g256_kept": [], "g256_fresh": [], "rank_kept": [[] for _ in range(a.world)],
-                      "rank_fresh": [[] for _ in range(a.world)]} for name, _ in sets}
+                      "rank_fresh": [[] for _ in range(a.world)], "plan_full": [], "plan_rank0": []} for name, _ in sets}
         ref_grids = {}
 
         def apply(opts, plan):
@@ -57,6 +57,8 @@ def main():
                     apply(opts, plan)
                     v.Voxelize(N, 0); v.Voxelize(N, 0)                    # (kept: the second one has the lengths; both: warm)
                     acc[name]["full_" + tag].append(one(lambda: v.Voxelize(N, 0)))
+                    if plan == 2:
+                        acc[name]["plan_full"].append(v.stats()["plan_ms"])
                     if a.check and rep == 0:
                         g = v.Grid()
                         key = ("full", 0)
@@ -71,6 +73,8 @@ def main():
                         f = lambda: v.VoxelizeInterleaved(N, r, a.world, a.zblock, 0)        # noqa: E731
                         f(); f()
                         acc[name]["rank_" + tag][r].append(one(f))
+                        if plan == 2 and r == 0:
+                            acc[name]["plan_rank0"].append(v.stats()["plan_ms"])
                         if a.check and rep == 0:
                             g = v.Grid()
                             key = ("rank", r)
@@ -89,6 +93,7 @@ def main():
                 out[tag] = {"full_ms": round(full, 4), "rank_ms": [round(x, 4) for x in ranks], "slowest_rank_ms": round(max(ranks), 4),
                             "ideal_speedup": round(full / max(ranks), 2), "sum_over_full": round(sum(ranks) / full, 3),
                             "g256_ms": round(g256, 4), "g256_gvoxels_s": round((N // 2) ** 3 / g256 / 1e6, 1)}
+            out["fresh"]["queue_build_ms"] = {"full": round(med(d["plan_full"]), 4), "rank0": round(med(d["plan_rank0"]), 4)}
             print(json.dumps(out), flush=True)
     v.close()
 
