@@ -8,8 +8,11 @@ Called as `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environ
 starts the N ranks as a child `python -m torch.distributed.run` (127.0.0.1 rendezvous), waits and relays rank 0's line.
 
 A step = one Voxelize pass (the reference's per-frame DispatchRays, Content/Voxelizer.cpp:366)
-over the whole grid with the scene already resident in HBM: the BVH is built once in Init like
-the reference's acceleration structure (Content/Voxelizer.cpp:73) and is reported separately.
+over the whole grid with the scene already resident in HBM: LBVH and candidate lists are built once in
+Init like the reference's acceleration structure (Content/Voxelizer.cpp:73) and are reported separately.
+`value` is the step with NOTHING carried from launch to launch (the library's default, option plan = 2: every
+step builds its work queue on the device, clears its grid and writes every voxel); the same steps with the
+queue and the zeros kept (plan = 1) are config.kept_step, and config.first_voxelize_after_init is the cold call.
 With N > 1 the grid is Z-slab partitioned, one process per GPU; rank 0 builds the LBVH and the
 scene blob is broadcast once over RCCL; there is no per-step collective.  Total work is fixed
 (strong scaling).  Rank 0 prints ONE JSON line.
@@ -217,7 +220,6 @@ def main():
     stream = torch.cuda.Stream()                 # a real (non-null) stream: frame 0's kernels, torch events and
     torch.cuda.set_stream(stream)                # RCCL all share it
     vox.set_stream(stream.cuda_stream)
-    vox.set_option("lists", 2)       # candidate lists from a scene's first launch on: their build stays in the warm-up (config.candidates.build_ms)
     if args.brick >= 0:
         vox.set_option("brick", args.brick)
     if args.stack >= 0:
@@ -228,9 +230,11 @@ def main():
     bcast_ms, bcast = 0.0, {}
     if rank == 0:
         vb, ib, label = make_mesh(args.mesh)
-        vox.InitFromArrays(vb, ib)               # upload + LBVH build (not part of a step)
+        vox.InitFromArrays(vb, ib)               # upload + LBVH + candidate lists (Init work, not part of a step)
         cold_build_ms = vox.stats()["build_ms"]  # (the first build of a process pays for code loading and allocations)
+        cold_list_ms = vox.stats()["list_ms"]
         vox.InitFromArrays(vb, ib)               # ... the same again: the figure config.build_roofline is made from
+        warm_list_ms = vox.stats()["list_ms"]
     if use_dist:
         torch.cuda.synchronize()
         dist.barrier()
@@ -276,10 +280,10 @@ def main():
             elif nzn:
                 vox.Voxelize(n, mode, z0n, nzn, sync=False, frameIndex=f)
 
-        if n not in prepared:                    # the scene's candidate lists, like the reference's acceleration structure part of Init,
-            prepared.add(n)                      # not of a step: built by the first launch of a scene (include/dxv.h, option lists).
-            step()                               # (The launch's work queue is built on the device inside every launch that needs one:
-            vox.SyncAll()                        # option plan, and config.fresh_step below.)
+        if n not in prepared:                    # (one launch allocates the frame's grid and queue; the lists exist since Init)
+            prepared.add(n)
+            step()
+            vox.SyncAll()
             # ... and the GPU out of its idle clocks: the same launch for ~0.1 s before anything is timed (a timed region of 20
             # steps is 16 ms: on a GPU that has just woken up it measured 4 % less than the same steps a second later)
             t_spin = time.perf_counter()
@@ -345,33 +349,39 @@ def main():
         return {"median": float(np.median(xs)), "min": float(np.min(xs)), "max": float(np.max(xs))} if len(xs) else None
 
     frames = max(1, min(args.frames, vox.FrameCount))
-    dt, kernel_ms, _ = timed_region(frames, args.steps, args.warmup)
+    # THE HEADLINE: every step builds its work queue on the device, clears the grid and writes every voxel (plan = 2, the library's
+    # default): nothing a step does depends on what an earlier launch left behind.
+    vox.set_option("plan", 2)
+    dt, step_ms_events, _ = timed_region(frames, args.steps, args.warmup)
     dt_max = reduce_max(dt)
     _, _, per_step = timed_region(1, args.steps, 1, per_step=True)      # the same steps once more with an event behind every one: their spread
-    # The headline's steps launch the same partition into the same frame again and again (the reference's own loop,
-    # Content/Voxelizer.cpp:108-113): from the second one on they keep the frame's work queue and the zeros of the bricks it does
-    # not run (option plan = 1).  The no-carried-state figure: the same steps with the queue rebuilt on the device and the whole
-    # grid cleared inside EVERY step (plan = 2) -- what a scene that changes every frame, or a caller's first launch, pays.
-    fresh = None
-    if mode == dxv.MODE_REFERENCE and st_probe()["plan_bricks"]:
-        vox.set_option("plan", 2)
-        dtf, kf, _ = timed_region(frames, args.steps, args.warmup)
-        dtf = reduce_max(dtf)
-        vox.set_option("events", 1)
-        pm = []
-        for _ in range(5):                                              # (a few launches with the library's events: the queue build alone)
+    st_run = st_probe()                          # of the timed rule (the extras below overwrite the launch fields)
+    queued = bool(st_run["plan_bricks"]) and mode == dxv.MODE_REFERENCE
+    # the queue build (the kernel in front of the brick kernel: queue + clear) on its own: a few launches with the library's events
+    pm = []
+    if queued:
+        for _ in range(7):
             if interleave:
                 vox.VoxelizeInterleaved(N, rank, world, zblock, mode)
             elif nz:
                 vox.Voxelize(N, mode, z0, nz)
             pm.append(vox.stats()["plan_ms"])
-        fresh = {"dt": dtf, "kernel_ms": kf, "plan_ms": float(np.median(pm)), "bricks": vox.stats()["plan_bricks"]}
+    plan_ms = float(np.median(pm)) if pm else 0.0
+    kernel_ms = step_ms_events - plan_ms         # the dominant kernel's average launch duration: the step between two events minus the kernel in front of it
+    # The same steps with the queue and the zeros of the bricks it does not run KEPT from step to step (plan = 1: a static scene
+    # voxelized into the same frame again, the reference's own loop, Content/Voxelizer.cpp:108-113; launched through the hardware's
+    # dispatcher once a sync has read the queue's lengths)
+    kept = None
+    if queued:
         vox.set_option("plan", 1)
-        timed_region(1, 2, 1)                                           # (back to the kept queue for what follows)
-    rank_kernel_ms = gather(kernel_ms)           # every rank's mean launch duration: an imbalance of the partition shows here
+        dtk, kk, _ = timed_region(frames, args.steps, args.warmup)
+        dtk = reduce_max(dtk)
+        kept = {"dt": dtk, "kernel_ms": kk, "waves": st_probe()["plan_waves"]}
+        vox.set_option("plan", 2)
+        timed_region(1, 2, 1)                                           # (back to the default for what follows)
+    rank_kernel_ms = gather(step_ms_events)      # every rank's mean step between two events: an imbalance of the partition shows here
     rank_wall_ms = gather(dt / max(args.steps, 1) * 1e3)
     kmax = max(rank_kernel_ms)
-    st_run = vox.stats()                         # of the timed rule (the extras below overwrite the launch fields)
     solid = vox.CountSolid() if nz else 0
     tot = torch.tensor([float(solid)], dtype=torch.float64, device="cuda")
     if use_dist:
@@ -380,11 +390,13 @@ def main():
     extras = {}
     if not args.no_extras:
         # the same steps with two voxelizations in flight per GPU, at every N (like-for-like ratios across N)
-        other = 2 if frames == 1 else 1
-        dt2, k2, _ = timed_region(other, args.steps, 2)
-        dt2 = reduce_max(dt2)
-        extras[f"frames_in_flight_{other}"] = {"value": (N ** 3) * args.steps / dt2 / 1e6, "unit": "Mvoxels/s",
-                                               "ms_per_step": dt2 / args.steps * 1e3, "kernel_ms": reduce_max(k2)}
+        # (the reference keeps FrameCount = 3 grids in flight, Content/Voxelizer.h:24: consecutive frames write different grids and
+        # overlap on the GPU; the headline keeps ONE in flight at every N so that values at different N compare like for like)
+        for other in ((2, 3) if frames == 1 else (1,)):
+            dt2, k2, _ = timed_region(other, args.steps, 2)
+            dt2 = reduce_max(dt2)
+            extras[f"frames_in_flight_{other}"] = {"value": (N ** 3) * args.steps / dt2 / 1e6, "unit": "Mvoxels/s",
+                                                   "ms_per_step": dt2 / args.steps * 1e3, "kernel_ms": reduce_max(k2)}
     if world == 1 and not args.no_extras:
 
         def median_ms(m, reps=5):
@@ -403,7 +415,7 @@ def main():
             # the kernel north_star describes (LBVH walk, LDS stack, ballot vote) on the same scene
             vox.set_option("lists", 0)
             tw = median_ms(mode)
-            vox.set_option("lists", 2)
+            vox.set_option("lists", 1)
             extras["tree_walk_ms"] = tw
             extras["tree_walk_mvoxels_s"] = N ** 3 / tw / 1e3
             if N == 512:
@@ -416,10 +428,15 @@ def main():
                         ts.append(vox.stats()["voxelize_ms"])
                     return float(np.median(ts))
                 l256 = median_ms_at(256, mode)
+                vox.set_option("plan", 1)
+                k256 = median_ms_at(256, mode)
+                vox.set_option("plan", 2)
                 vox.set_option("lists", 0)
                 t256 = median_ms_at(256, mode)
-                vox.set_option("lists", 2)
-                extras["grid_256"] = {"ms": l256, "mvoxels_s": 256 ** 3 / l256 / 1e3, "tree_walk_ms": t256, "tree_walk_mvoxels_s": 256 ** 3 / t256 / 1e3}
+                vox.set_option("lists", 1)
+                extras["grid_256"] = {"ms": l256, "mvoxels_s": 256 ** 3 / l256 / 1e3, "kept_queue_ms": k256, "kept_queue_mvoxels_s": 256 ** 3 / k256 / 1e3,
+                                      "tree_walk_ms": t256, "tree_walk_mvoxels_s": 256 ** 3 / t256 / 1e3,
+                                      "note": "standalone launches, median of 7, the library's events around each: ms = nothing carried (plan = 2)"}
                 vox.Voxelize(N, mode)                                    # (the 512^3 grid again for what follows)
             if args.mesh == "torus1m":
                 # the other "1 M-triangle mesh" BASELINE.md names (no part of its grid is cleared by the partial launch)
@@ -428,7 +445,7 @@ def main():
                 lm = median_ms(mode)
                 vox.set_option("lists", 0)
                 tm = median_ms(mode)
-                vox.set_option("lists", 2)
+                vox.set_option("lists", 1)
                 extras["bunny16"] = {"workload": f"{blabel}, {N}^3, reference predicate", "ms": lm, "mvoxels_s": N ** 3 / lm / 1e3,
                                      "tree_walk_ms": tm, "tree_walk_mvoxels_s": N ** 3 / tm / 1e3}
 
@@ -448,6 +465,26 @@ def main():
                                           "value": (n4 ** 3) * k4 / dt4 / 1e6, "unit": "Mvoxels/s", "steps": k4,
                                           "ms_per_step": dt4 / k4 * 1e3, "rank_kernel_ms": rk4, "step_ms": stats_ms(step4)}
 
+    cold = None
+    if rank == 0 and world == 1 and not args.no_extras and mode == dxv.MODE_REFERENCE:
+        # The cold call: one Init (upload, LBVH, candidate lists) and the scene's first three Voxelize calls, on a context that has
+        # launched other things before (allocations of this size exist; the code is loaded)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vox.InitFromArrays(vb, ib)
+        torch.cuda.synchronize()
+        init_ms = (time.perf_counter() - t0) * 1e3
+        sti = vox.stats()
+        calls = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            vox.Voxelize(N, mode)
+            calls.append({"wall_ms": (time.perf_counter() - t0) * 1e3, "events_ms": vox.stats()["voxelize_ms"]})
+        cold = {"what": "InitFromArrays (upload + LBVH + lists, host wall clock around the call) and the scene's first three synchronous Voxelize "
+                        "calls (wall clock, and the library's events around what the launch put into the stream)",
+                "init_wall_ms": init_ms, "init_parts_ms": {"upload": sti["upload_ms"], "lbvh": sti["build_ms"], "lists": sti["list_ms"]},
+                "voxelize_calls": calls, "init_plus_first_voxelize_ms": init_ms + calls[0]["wall_ms"]}
+
     if rank == 0:
         value = (N ** 3) * args.steps / dt_max / 1e6
         bytes_launch = algorithmic_bytes(N, nz, T, V)
@@ -455,7 +492,7 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (collected and corrected as MI355X_MICROARCH.md
         # prescribes; tools/collect_evidence.py) -- only when they were taken on THESE sources: the file carries the hash of
         # csrc/ at the time, and a figure of other kernels is not reported as this run's
-        traffic, traffic_note = None, None
+        traffic, traffic_note, l1 = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -464,6 +501,7 @@ def main():
                 ent = tj.get(key, {})
                 if ent.get("source_hash") == source_hash():
                     traffic = ent.get("hbm_bytes_per_launch")
+                    l1 = ent.get("l1")                               # the vector-L1 view of the same launch (tools/collect_evidence_r5.py)
                 elif ent:
                     traffic_note = (f"profiles/traffic.json holds {ent.get('hbm_bytes_per_launch')} B for this workload, measured on sources "
                                     f"{ent.get('source_hash', '(round ' + str(ent.get('round')) + ', no hash)')}; this run's are {source_hash()}: not reported")
@@ -471,20 +509,17 @@ def main():
                 traffic = None
         bricks = st_run.get("plan_bricks", 0)
         scene_bytes = bytes_launch - N * N * nz                  # the read side of the algorithmic bytes
-        stored_kept = 64 * bricks if bricks else N * N * nz       # a step with the kept queue stores its queued bricks only
-        fresh_out = None
-        if fresh:
-            f_ms = fresh["dt"] / args.steps * 1e3
-            f_stored = N * N * nz + 64 * fresh["bricks"]          # the grid's clear + the queued bricks' results
-            fresh_out = {"what": "the same steps with nothing carried from launch to launch (option plan = 2): the work queue rebuilt on the "
-                                 "device and the whole grid cleared inside every step",
-                         "plan": "rebuilt in the step", "grid": "cleared in the step",
-                         "ms_per_step": f_ms, "mvoxels_s": (N ** 3) * args.steps / fresh["dt"] / 1e6, "kernel_ms": fresh["kernel_ms"],
-                         "queue_build_ms": fresh["plan_ms"], "queued_bricks": fresh["bricks"],
-                         "roofline": {"bound": "hbm", "stored_bytes": f_stored, "read_bytes": scene_bytes,
-                                      "achieved": (f_stored + scene_bytes) / (fresh["kernel_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                      "frac": (f_stored + scene_bytes) / (fresh["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                      "note": "bytes this step really stores (memset of the grid + 64 B per queued brick) + the scene read once"}}
+        stored = N * N * nz + 64 * bricks if queued else N * N * nz   # the grid's clear + the queued bricks' results
+        kernel = ("k_voxelize_queue" if queued else "k_voxelize") if args.mode == "reference" else "k_parity_rows"
+        kept_out = None
+        if kept:
+            k_ms = kept["dt"] / args.steps * 1e3
+            kept_out = {"what": "the same steps with the work queue and the zeros of the bricks it does not run KEPT from step to step (option plan = 1): a "
+                                "static scene voxelized into the same frame again, the reference's own loop (Content/Voxelizer.cpp:108-113); the kept "
+                                "queue's size is known to the host, so the hardware deals it out (k_voxelize_listed, one workgroup per brick)",
+                        "ms_per_step": k_ms, "mvoxels_s": (N ** 3) * args.steps / kept["dt"] / 1e6, "kernel_ms": kept["kernel_ms"],
+                        "workgroups_launched": kept["waves"], "stored_bytes_per_launch": 64 * bricks,
+                        "roofline_frac_on_algorithmic_bytes": bytes_launch / (kept["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         out = {
             "metric": "solid Mvoxels/s at 512^3 (1M-tri mesh)" if (N == 512 and args.mesh == "torus1m")
                       else f"solid Mvoxels/s at {N}^3 ({label})",
@@ -494,14 +529,20 @@ def main():
             "config": {"workload": f"{label}, {T} triangles, {N}^3 grid, {args.mode} predicate, "
                                    f"one ray per voxel, " + (f"Z blocks of {zblock} slices dealt round-robin over {world} GPUs"
                                                            if interleave else f"Z-slab partition over {world} GPU(s)"),
+                       "step": "one Voxelize with nothing carried from launch to launch (option plan = 2, the library's default): the work queue built on "
+                               "the device, the grid cleared and every voxel written inside the step" if queued else "one Voxelize",
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
                        "slab_slices_rank0": nz, "frames_in_flight": frames, "solid_voxels": int(tot.item()),
-                       "untimed_launches_before_warmup": untimed[0],     # one builds the scene's candidate lists (Init work), the others spin the clocks up (--spin-ms)
-                       "fresh_step": fresh_out,
+                       "steps": args.steps, "warmup": args.warmup, "spin_ms": args.spin_ms,
+                       "untimed_launches_before_warmup": untimed[0],     # one allocates the frame's grid and queue, the others spin the clocks up (--spin-ms)
+                       "queue_build_ms": plan_ms, "queued_bricks": bricks,
+                       "kept_step": kept_out,
+                       "first_voxelize_after_init": cold,
                        "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": args.backend if use_dist else None,
                        "tree_height": st0["tree_height"], "stack_entries": st_run["stack_entries"],
                        "candidates": ({"structure": "direction-space lists", "texels_per_face_side": st_run["list_res"],
-                                       "entries": st_run["list_entries"], "build_ms": st_run["list_ms"]}
+                                       "entries": st_run["list_entries"], "build_ms": warm_list_ms if rank == 0 else None,
+                                       "build_ms_first_in_process": cold_list_ms if rank == 0 else None, "built": "in Init"}
                                       if st_run.get("list_entries") else {"structure": "LBVH walk"}),
                        "build_ms": st0["build_ms"], "build_ms_first_in_process": cold_build_ms,
                        "build_stages_ms": {k: st0[k] for k in ("prep_ms", "sort_ms", "hierarchy_ms", "refit_ms")},
@@ -514,27 +555,25 @@ def main():
                        "scene_broadcast": ({"bytes": bcast.get("bytes"), "collective_ms": bcast.get("broadcast_ms"),
                                             "checksum": f"{bcast.get('checksum', 0):#018x}", "ranks_equal": len(set(bcast.get("checksums", [0]))) == 1}
                                            if bcast else None),
-                       "kernel_ms_max_over_ranks": kmax, "rank_kernel_ms": rank_kernel_ms, "rank_ms_per_step": rank_wall_ms,
+                       "step_ms_max_over_ranks": kmax, "rank_step_ms_events": rank_kernel_ms, "rank_ms_per_step": rank_wall_ms,
                        "rank_imbalance": max(rank_kernel_ms) / (sum(rank_kernel_ms) / len(rank_kernel_ms)) if min(rank_kernel_ms) > 0 else None,
                        "step_ms_rank0": stats_ms(per_step),
-                       "work_queue": ({"queued_bricks": st_run["plan_bricks"], "workgroups_launched": st_run["plan_waves"],
-                                       "launch": ("one workgroup per slot of the kept queue, dealt out by the hardware (its lengths were read by a "
-                                                  "dxv_sync before the timed region; option dispatch)" if st_run["plan_waves"] >= st_run["plan_bricks"]
-                                                  else "persistent waves taking bricks from the queue's heads"),
-                                       "built": "on the device inside the launch that needs it (option plan); the headline's steps keep it"}
-                                      if st_run.get("plan_bricks") else None),
+                       "work_queue": ({"queued_bricks": bricks, "workgroups_launched": st_run["plan_waves"],
+                                       "launch": "persistent waves taking bricks from the queue's heads (a launch that builds its queue does not know its size)",
+                                       "built": "on the device inside every step, by the kernel that also clears the grid (k_plan_bricks)"}
+                                      if queued else None),
                        **extras},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, **({"traffic_note": traffic_note} if traffic_note else {}),
-                         "stored_bytes_per_launch": stored_kept,
-                         "achieved_on_stored_bytes": (stored_kept + scene_bytes) / (kernel_ms * 1e-3) / 1e9,
-                         "kernel": (("k_voxelize_listed" if st_run["plan_waves"] >= st_run["plan_bricks"] else "k_voxelize_queue") if st_run.get("plan_bricks") else "k_voxelize")
-                                   if args.mode == "reference" else "k_parity_rows", "kernel_ms": kernel_ms,
+                         "stored_bytes_per_launch": stored,
+                         "achieved_on_stored_bytes": (stored + scene_bytes) / (kernel_ms * 1e-3) / 1e9,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "step_ms_between_events": step_ms_events,
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once); a step that keeps "
-                                 "its queue stores only its queued bricks (stored_bytes_per_launch; config.fresh_step stores all of it); the kernel "
-                                 "is not bound by bandwidth: compulsory HBM bytes are a few per cent of what 8 TB/s moves in its "
-                                 "run time (DESIGN.md section 4 names the measured limiter)"},
+                         "l1": l1,
+                         "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once) over the dominant kernel's average "
+                                 "launch duration = the step between two events on the kernels' stream minus the queue build in front of it (config.queue_build_ms, "
+                                 "the library's events); the kernel is not bound by HBM bandwidth: it is a gather bound by the vector L1 / address "
+                                 "units (roofline.l1: line accesses per clock and CU against the measured roof of tools/micro/l1_roof.hip; DESIGN.md section 4.2)"},
         }
     # The CPU baseline is rank 0's alone and runs AFTER the process group is gone: no rank sits in an RCCL barrier (where a watchdog
     # bites first on a new node) while rank 0 runs the oracle for seconds.

@@ -6,6 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+API_VERSION = 5          # DXV_API_VERSION of include/dxv.h (tests/test_cabi.py compares the two)
 
 
 class DxvError(RuntimeError):
@@ -97,5 +98,12 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
+        # include/dxv.h: a binding compares the library's version with the header's it was written against before its first
+        # call (an older build loaded through DXV_LIBRARY differs in options and in the meaning of the dxv_stats plan fields);
+        # DXV_ALLOW_API_MISMATCH=1: the A/B tools that load an older build on purpose
+        got = lib.dxv_api_version()
+        if got != API_VERSION and os.environ.get("DXV_ALLOW_API_MISMATCH") != "1":
+            raise DxvError(f"{path} reports DXV_API_VERSION {got}, this binding was written against {API_VERSION} "
+                           "(rebuild with `python -m dxrvoxelizer_amd.build`, or set DXV_ALLOW_API_MISMATCH=1 for an A/B against an older build)")
         _LIB = lib
     return _LIB

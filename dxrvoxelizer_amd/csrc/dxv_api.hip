@@ -153,8 +153,8 @@ struct dxv_ctx {
     uint16_t* dMip = nullptr;
     size_t mipCap = 0;               // 16-bit words
     uint64_t listEpoch = 0;          // counts list builds / imports: a frame's queue belongs to the lists it was probed against
-    int optPlan = 1;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
-                                     // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch, 2 = on every launch
+    int optPlan = 2;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
+                                     // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch (opt-in), 2 = on every launch (default: nothing carried)
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
     int optQueueHeads = 8;           // heads per queue (persistent waves): 1, 2, 4, 8
     int optPlanRegion = 0;           // log2 of the run of Morton bricks dealt to one queue: 6, 7, 8; 0 = by the partition's size (plan_region_bits)

@@ -112,10 +112,13 @@ class _DeviceBuffer:
 
 
 def device_grid_tensor(vox, device):
-    """The context's device-resident grid of the last Voxelize as a torch uint8 tensor (no copy)."""
+    """The context's device-resident grid of the last Voxelize as a torch uint8 tensor (no copy).  torch tensors are writable
+    (torch refuses a read-only __cuda_array_interface__), so the pointer is taken through dxv_grid_device_ptr: the library then
+    knows the caller may write into the grid at any time and never relies on zeros an earlier launch left there (option plan = 1
+    would; the default, plan = 2, clears the grid in every launch anyway)."""
     import torch
 
-    return torch.as_tensor(_DeviceBuffer(vox.grid_device_ptr(writable=False), vox.grid_bytes()), device=device)
+    return torch.as_tensor(_DeviceBuffer(vox.grid_device_ptr(writable=True), vox.grid_bytes()), device=device)
 
 
 def allgather_grid(vox, dist, N, world, zblock, device):

@@ -65,12 +65,15 @@ class Voxelizer:
             raise DxvError(self._lib.dxv_last_error(self._ctx).decode())
 
     # ---- reference surface ------------------------------------------------------------------
-    def Init(self, fileName, posScale=(0.0, 0.0, 0.0, 1.0)):
+    def Init(self, fileName, posScale=(0.0, 0.0, 0.0, 1.0), dynamicMesh=False):
         """Voxelizer::Init (Content/Voxelizer.cpp:30-79) minus the D3D12 arguments."""
         vb, ib, _ = obj_load(fileName)
-        return self.InitFromArrays(vb, ib, posScale)
+        return self.InitFromArrays(vb, ib, posScale, dynamicMesh)
 
-    def InitFromArrays(self, vb, ib, posScale=(0.0, 0.0, 0.0, 1.0)):
+    def InitFromArrays(self, vb, ib, posScale=(0.0, 0.0, 0.0, 1.0), dynamicMesh=False):
+        """Upload, bound, LBVH -- and, like the reference's Init (Content/Voxelizer.cpp:73), everything else the launches trace
+        through: the candidate lists of the reference rule on the map a static scene is launched with, so that the first
+        Voxelize costs what every later one costs.  dynamicMesh=True (a mesh that is refitted every frame): the LBVH only."""
         self.posScale = tuple(posScale)  # display only in the reference (Voxelizer.cpp:84-87)
         vb = np.ascontiguousarray(vb, np.float32).reshape(-1, 6)
         ib = np.ascontiguousarray(ib, np.uint32).reshape(-1)
@@ -78,7 +81,12 @@ class Voxelizer:
             raise DxvError("index count is not a multiple of 3")
         self._check(self._lib.dxv_set_mesh(self._ctx, vb, len(vb), ib, ib.size // 3))
         self._check(self._lib.dxv_build(self._ctx))
+        if not dynamicMesh:
+            self._check(self._lib.dxv_build_lists_for_grid(self._ctx, 0))
         return True
+
+    def InitDynamic(self, vb, ib, posScale=(0.0, 0.0, 0.0, 1.0)):
+        return self.InitFromArrays(vb, ib, posScale, dynamicMesh=True)
 
     def UpdateVertices(self, vb, refit=True):
         """Animated vertices on fixed topology: upload + refit of the existing hierarchy (N4)."""

@@ -22,9 +22,11 @@ extern "C" {
 
 /* Bumped whenever an entry point changes its signature or a struct of this header its layout; dxv_api_version() returns the
  * value the loaded library was built with -- a binding compares the two before its first call.
+ * 5: option plan defaults to 2 (every launch builds its queue and clears its grid: nothing carried from launch to launch; the kept
+ *    queue is opt-in), options planregion / planheavy / fuse / queueheads;
  * 4: dxv_stats plan fields describe the work queue, options planorder / planregion gone, dxv_debug_plan_check, dxv_trim;
  * 3: dxv_debug_list_check takes a slab (z0, nz). */
-#define DXV_API_VERSION 4
+#define DXV_API_VERSION 5
 DXV_API int dxv_api_version(void);
 
 typedef struct dxv_ctx dxv_ctx;
@@ -225,9 +227,20 @@ DXV_API int dxv_render(dxv_ctx* ctx, const float eye[3], const float view_proj[1
  * rank 0 builds once and the host layer broadcasts it (RCCL over xGMI) to the other ranks.
  * export copies the blob into caller-provided DEVICE memory; import adopts a blob from DEVICE
  * memory as if dxv_set_mesh + dxv_build had run here. */
-/* The candidate lists of the reference rule (direction-space lists) are built at a scene's first or
- * second launch (option lists); dxv_build_lists builds them now.  A scene exported after that carries them as two more
- * sections of the blob, and the importing contexts adopt them instead of building their own. */
+/* STATIC and DYNAMIC scenes -- the two ways through this header:
+ *   static   dxv_set_mesh; dxv_build; dxv_build_lists_for_grid;  then dxv_voxelize* per frame.  The reference's case
+ *            (Content/Voxelizer.cpp:73: Init builds everything the frames trace through) and what the host mirrors' Init does
+ *            (include/dxv_voxelizer.hpp, dxrvoxelizer_amd/voxelizer.py): LBVH and candidate lists exist when Init returns, and
+ *            every launch is the same launch -- it builds its work queue, clears its grid and runs (option plan = 2): a scene's
+ *            first Voxelize costs what its hundredth costs.
+ *   dynamic  dxv_set_mesh; dxv_build;  then per frame dxv_update_vertices(_device); dxv_refit; dxv_voxelize_async.  The lists of
+ *            a mesh that is being refitted are built inside each frame's launch, on the coarser map (option lists, listres).
+ * A caller who does neither (dxv_build, then dxv_voxelize) is treated as dynamic until the scene is launched a second time without
+ * a refit in between: option lists says when the lists are built then.
+ *
+ * The candidate lists of the reference rule (direction-space lists): dxv_build_lists builds them now.  A
+ * scene exported after that carries them as two more sections of the blob, and the importing contexts adopt them instead of
+ * building their own. */
 DXV_API int dxv_build_lists(dxv_ctx* ctx);
 /* ... on the map the launches of a static scene move to (the 512 map for scenes of 20,000 triangles or more, at every grid size;
  * grid_dim is accepted for compatibility): the exporting rank builds that map before dxv_scene_export, so that the importing
@@ -267,9 +280,9 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 always at the first (2); scenes whose lists would exceed 256 entries per triangle + 64 M or
  *                 65,535 entries in one texel keep the tree walk (stats.list_entries = 0)
  *   dispatch 0|1|2  a launch through a KEPT work queue (plan = 1, same lists / partition / buffers as the frame's last launch)
- *                 whose eight lengths a dxv_sync has read since it was built: one workgroup per queued brick dealt out by the
- *                 hardware (1, default; 2: only for partitions of up to 2^25 voxels) instead of persistent waves (0).  The first
- *                 launch of a queue, and every launch under plan = 2, does not know its size and uses the persistent waves.
+ *                 whose sixteen counts a dxv_sync has read since it was built: one workgroup per queued brick dealt out by the
+ *                 hardware (1, default; 2: only for partitions of up to 2^25 voxels) instead of persistent waves (0).  A launch that
+ *                 builds its queue (every launch under plan = 2) does not know its size and uses the persistent waves.
  *   listres 0|16..4096  texels per cube-map face side of the lists (power of two).  0 = automatic: 128 below 20,000 triangles,
  *                 256 up to 3 M, 512 beyond -- and the 512 map for every scene of 20,000 triangles or more that is presumed
  *                 STATIC: built by dxv_build_lists / lists = 2 on a scene that has not been refitted, or launched a second time
@@ -279,10 +292,22 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 2 from the first, 0 = always walk the tree; plistres 0|16..4096: texels per side of their grid
  *   plan   0|1|2  lists kernel through a work queue: only the 4^3-voxel bricks that can hold a live ray are run (decided per
  *                 brick on the device, in front of the kernel in the same stream: the brick's footprint in direction space and
- *                 its smallest start radius against a max-mip of the lists' far radii; no host round trip), taken from per-XCD
- *                 queues by persistent waves; the rest of the grid is the launch's memset.  1 (default): queue and memset are
- *                 kept while the frame's next launch is the same one (same lists, partition, buffers); 2: built and cleared on
- *                 every launch (nothing carried from launch to launch); 0: no queue, brick box around the scene in Morton order
+ *                 its smallest start radius against a max-mip of the lists' far radii; no host round trip).  The kernel that builds
+ *                 the queue clears the partition's grid as well (option fuse), deals the bricks to eight queues -- the bricks that
+ *                 can look into a list that is long for the scene at the front (planheavy), every XCD running an equal share of
+ *                 all eight -- and persistent waves take them from there.
+ *                 2 (default): built and cleared on every launch -- NOTHING is carried from launch to launch: a scene's first,
+ *                 second and hundredth launch cost the same and write every voxel;
+ *                 1: queue and zeros are kept while the frame's next launch is the same one (same lists, partition, buffers) --
+ *                 for a caller that voxelizes a static scene into the same frame again and again (the reference's own loop,
+ *                 Content/Voxelizer.cpp:108-113): -13 % per launch at 512^3, -25 % on a rank's share at 8 ranks, and the launch
+ *                 goes through the hardware's dispatcher (option dispatch);
+ *                 0: no queue, brick box around the scene in Morton order
+ *   planregion 0|6|7|8  log2 of the run of consecutive Morton bricks that goes to one queue (0 = by partition size)
+ *   planheavy 0..65535  a brick that can look into a list of more entries than this goes to the front of its queue (0, default: one
+ *                 and a half times the scene's mean at the level of a brick's patch of texels; 65535: no brick does)
+ *   fuse   0|1    the queue build clears the grid (1, default) or memsets stand in front of it (0)
+ *   queueheads 1|2|4|8  heads per queue the persistent waves draw from (default 8)
  *   events 0|1    bracket every launch with two HIP events for stats.voxelize_ms (default 1); 0 for a caller that times its own
  *                 loop of back-to-back launches (the events cost ~8 us of stream time per launch)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)

@@ -30,25 +30,34 @@ public:
 	Voxelizer& operator=(const Voxelizer&) = delete;
 
 	// Load the OBJ, upload VB/IB, extract the bound, build the acceleration structure
-	// (Content/Voxelizer.cpp:30-79).
-	bool Init(const char* fileName, const float posScale[4] = nullptr)
+	// (Content/Voxelizer.cpp:30-79).  Like the reference's Init (:73: buildAccelerationStructures), it leaves EVERYTHING the
+	// launches trace through finished -- the LBVH and the candidate lists of the reference rule on the map a static scene is
+	// launched with: the first Voxelize costs what every later one costs.
+	bool Init(const char* fileName, const float posScale[4] = nullptr, bool dynamicMesh = false)
 	{
 		float* vb = nullptr; uint32_t* ib = nullptr; uint32_t numVerts = 0, numIndices = 0; float aabb[6];
 		if (dxv_obj_load(fileName, &vb, &numVerts, &ib, &numIndices, aabb)) return setError("cannot load OBJ file");
-		const bool ok = InitFromArrays(vb, numVerts, ib, numIndices / 3, posScale);
+		const bool ok = InitFromArrays(vb, numVerts, ib, numIndices / 3, posScale, dynamicMesh);
 		dxv_free(vb); dxv_free(ib);
 		return ok;
 	}
 
 	// Same from memory: vb = numVerts x {pos.xyz, nrm.xyz}, ib = 3*numTris indices, both in the
 	// layout ObjLoader produces (createVB/createIB, Content/Voxelizer.cpp:115-138).
+	// dynamicMesh: the vertices will be replaced and the hierarchy refitted every frame (UpdateVertices*): only the LBVH is
+	// built here, and every frame's lists are built for that frame on the coarser map (include/dxv.h, option lists).
 	bool InitFromArrays(const float* vb, uint32_t numVerts, const uint32_t* ib, uint32_t numTris,
-		const float posScale[4] = nullptr)
+		const float posScale[4] = nullptr, bool dynamicMesh = false)
 	{
 		for (int i = 0; i < 4; ++i) m_posScale[i] = posScale ? posScale[i] : (i == 3 ? 1.0f : 0.0f);
 		if (!m_ctx && dxv_create(&m_ctx, m_device)) return setError(dxv_last_error(nullptr));
 		if (dxv_set_mesh(m_ctx, vb, numVerts, ib, numTris)) return false;
-		return dxv_build(m_ctx) == 0;
+		if (dxv_build(m_ctx)) return false;
+		return dynamicMesh || dxv_build_lists_for_grid(m_ctx, 0) == 0;
+	}
+	bool InitDynamic(const float* vb, uint32_t numVerts, const uint32_t* ib, uint32_t numTris, const float posScale[4] = nullptr)
+	{
+		return InitFromArrays(vb, numVerts, ib, numTris, posScale, true);
 	}
 
 	// The hot call (Content/Voxelizer.cpp:351-369): whole grid, or slices [z0, z0+nz).

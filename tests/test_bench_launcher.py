@@ -76,6 +76,9 @@ def test_two_real_ranks_on_one_gpu_through_the_launcher(grids_json):
     # the broadcast was timed and every rank's copy of the blob checked against the source's; the no-carried-state step is in the line
     b = out["config"]["scene_broadcast"]
     assert b["bytes"] > 0 and b["collective_ms"] > 0 and b["ranks_equal"] is True and int(b["checksum"], 16) != 0
-    f = out["config"]["fresh_step"]
-    assert f["plan"] == "rebuilt in the step" and f["grid"] == "cleared in the step" and f["ms_per_step"] > 0 and f["queued_bricks"] > 0
-    assert out["config"]["work_queue"]["queued_bricks"] == f["queued_bricks"]
+    # `value` is the step with nothing carried (queue built, grid cleared in the step); the kept-queue step stands beside it
+    c = out["config"]
+    assert c["step"].startswith("one Voxelize with nothing carried") and c["queued_bricks"] > 0 and c["queue_build_ms"] > 0
+    assert c["work_queue"]["queued_bricks"] == c["queued_bricks"] and out["roofline"]["kernel"] == "k_voxelize_queue"
+    k = c["kept_step"]
+    assert k["ms_per_step"] > 0 and k["stored_bytes_per_launch"] == 64 * c["queued_bricks"]
