@@ -456,21 +456,24 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
 // rays look into a patch of texels whose size depends on the grid (4 voxels of 2 / N against texels of 2 / R); the launch picks the
 // level whose cells are about that patch (dm_heavy_level) and calls a brick heavy when the longest list it can look into is
 // longer than that level's word -- a scene of 13 entries per direction and one of 8 draw the line in different places.
-__global__ __launch_bounds__(256) void k_dm_heavy_thresholds(uint32_t R, const uint16_t* __restrict__ counts, uint16_t* __restrict__ thr)
+// (levels kDmHeavyLevelMin and up: one workgroup each -- the finest of them has 98 k cells at R = 512; the two levels below would
+// cost more than the rest of the mip build and no grid of up to 2048^3 asks for them, dm_heavy_level)
+__global__ __launch_bounds__(1024) void k_dm_heavy_thresholds(uint32_t R, const uint16_t* __restrict__ counts, uint16_t* __restrict__ thr)
 {
-    __shared__ unsigned long long sum[4];
-    __shared__ uint32_t num[4];
-    const uint32_t l = blockIdx.x, r = R >> l, n = 6u * r * r;
+    __shared__ unsigned long long sum[16];
+    __shared__ uint32_t num[16];
+    const uint32_t l = blockIdx.x + kDmHeavyLevelMin, r = R >> l, n = 6u * r * r;
     const uint16_t* cells = counts + dm_mip_offset(R, l);
     unsigned long long s = 0;
     uint32_t c = 0;
-    for (uint32_t k = threadIdx.x; k < n; k += 256u) { const uint32_t v = cells[k]; s += v; c += v ? 1u : 0u; }
+    for (uint32_t k = threadIdx.x; k < n; k += 1024u) { const uint32_t v = cells[k]; s += v; c += v ? 1u : 0u; }
     for (int off = 32; off; off >>= 1) { s += __shfl_down(s, off); c += __shfl_down(c, off); }
     if ((threadIdx.x & 63u) == 0u) { sum[threadIdx.x >> 6] = s; num[threadIdx.x >> 6] = c; }
     __syncthreads();
     if (threadIdx.x == 0u) {
-        const unsigned long long st = sum[0] + sum[1] + sum[2] + sum[3];
-        const uint32_t ct = num[0] + num[1] + num[2] + num[3];
+        unsigned long long st = 0;
+        uint32_t ct = 0;
+        for (int k = 0; k < 16; ++k) { st += sum[k]; ct += num[k]; }
         const unsigned long long t = ct ? (3ull * st + 2ull * ct - 1ull) / (2ull * ct) : 8ull;
         thr[l] = (uint16_t)(t < 8ull ? 8ull : t > 65535ull ? 65535ull : t);
     }
@@ -488,7 +491,7 @@ hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream
     uint16_t* counts = mip + dm_mip_words(R);
     k_dm_mip_tiles<true><<<6u * (R / tile) * (R / tile), 256, 0, s>>>(cells, R, tile, counts);
     if (tileLevel + 1u < dm_mip_levels(R)) k_dm_mip_top<<<1, 1024, 0, s>>>(R, tileLevel, counts);
-    k_dm_heavy_thresholds<<<dm_mip_levels(R), 256, 0, s>>>(R, counts, counts + dm_mip_words(R));
+    if (dm_mip_levels(R) > kDmHeavyLevelMin) k_dm_heavy_thresholds<<<dm_mip_levels(R) - kDmHeavyLevelMin, 1024, 0, s>>>(R, counts, counts + dm_mip_words(R));
     return hipGetLastError();
 }
 

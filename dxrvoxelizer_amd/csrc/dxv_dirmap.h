@@ -310,11 +310,13 @@ DXV_HD uint32_t dm_box_max_count(float x0, float x1, float y0, float y1, float z
 DXV_HD uint32_t dm_mip_buffer_words(uint32_t R) { return 2u * dm_mip_words(R) + 16u; }
 // the level of the count mip whose cells are about the patch of texels a 4^3-voxel brick of an N^3 grid looks into
 // (4 voxels of 2 / N at a typical distance of 0.7 from the centre: ~5.6 R / N texels across)
+constexpr uint32_t kDmHeavyLevelMin = 2u;           // (the levels below have no "long list" word: k_dm_heavy_thresholds)
 DXV_HD uint32_t dm_heavy_level(uint32_t R, uint32_t N)
 {
     uint32_t l = 0;
     while ((1u << (l + 1u)) * N <= 8u * R && l + 1u < dm_mip_levels(R)) ++l;      // 2^l <= 8 R / N < 2^(l + 1):  512 / 512 -> 3, 512 / 256 -> 4, 512 / 1024 -> 2
-    return l;
+    const uint32_t top = dm_mip_levels(R) - 1u;
+    return l < kDmHeavyLevelMin ? (kDmHeavyLevelMin < top ? kDmHeavyLevelMin : top) : l;
 }
 
 // the hull of the voxel centres of brick (bx, by, bz) of 4 x 4 x 4 voxels in a partition's local brick grid (x0 <= x1 ...; y falls

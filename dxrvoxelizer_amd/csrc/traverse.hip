@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t 
         float x0, x1, y0, y1, z0, z1;
         dm_brick_hull(p.N, p.nz, p.z0, p.zBlock, p.zShift, p.zPeriod, bx, by, bz, x0, x1, y0, y1, z0, z1);
         const uint16_t* countMip = p.mip + dm_mip_words(p.scene.dmR);
-        const uint32_t longList = p.planHeavy ? p.planHeavy : countMip[dm_mip_words(p.scene.dmR) + dm_heavy_level(p.scene.dmR, p.N)];
+        // (maps too small to have such a level -- R < 8 -- have no word: no brick is heavy there)
+        const uint32_t longList = p.planHeavy ? p.planHeavy : dm_mip_levels(p.scene.dmR) > kDmHeavyLevelMin ? countMip[dm_mip_words(p.scene.dmR) + dm_heavy_level(p.scene.dmR, p.N)] : 0xffffu;
         heavy = dm_box_max_count(x0, x1, y0, y1, z0, z1, countMip, p.scene.dmR) > longList;
     }
     const unsigned long long mh = __ballot(live && heavy), ml = __ballot(live && !heavy);
@@ -539,8 +540,10 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
         // this head is done: the wave's other home heads (fewer than eight waves per XCD), else the wave is done.  A wave does NOT go
         // looking for work on other heads or other XCDs' queues: at the end of a launch thousands of waves doing so at once are
         // thousands of adds and loads on single words (~90 per microsecond each) -- measured, in four variants: every wave spent
-        // 30 - 60 us there and a rank's share of the grid took 0.195 instead of 0.147 ms, while the eight queues end within 2 % of
-        // each other anyway (profiles/r04/queue_wave_times.jsonl, ab_queue_helping.jsonl).
+        // 30 - 60 us there and a rank's share of the grid took 0.195 instead of 0.147 ms (profiles/r04/queue_wave_times.jsonl,
+        // ab_queue_helping.jsonl).  Round 5 tried the cheapest form once more -- one load of the wave's own queue's eight heads, then a
+        // move to the head with most items left, never to another XCD's queue: a rank's share 0.142 -> 0.170 ms (the waves of a
+        // drained head all pick the same head: profiles/r05/ab_steal_within_the_queue_rejected.jsonl, .patch).
         const uint64_t homeLeft = homeMask & ~tried;
         if (!homeLeft) break;
         cur = (uint32_t)__builtin_ctzll(homeLeft);

@@ -100,25 +100,31 @@ def test_config_grid_equals_oracle_fixture(dxv, configs, key):
             check_whole(v.Grid(), configs[key], f"{key} lists={lists}")
             assert v.CountSolid() == configs[key]["solid"]
             if mode == 0 and lists == 2 and st["list_entries"] > 0:
-                # (the launches above went through the work queue -- the default: live bricks only, decided on the device in
-                # front of the kernel.)  Exhaustively: no live ray sits in a brick that was not queued; then the same launch
-                # again (it keeps queue and memset), with everything rebuilt on every launch (plan = 2), and over the brick box
+                # (the launch above went through the work queue -- the default: live bricks only, decided on the device in
+                # front of the kernel, queue built and grid cleared in every launch.)  Exhaustively: no live ray sits in a brick
+                # that was not queued; then the same launch again, the kept queue (plan = 1: the second launch keeps queue and
+                # zeros, the third is dealt out by the hardware), and over the brick box
                 assert 0 < st["plan_bricks"] <= (N // 4) ** 3 and st["plan_waves"] % 8 == 0 and st["plan_waves"] > 0
                 chk = v.plan_check()
                 assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == st["plan_bricks"], chk
                 assert chk["live_bricks"] <= chk["queued_bricks"] <= 1.5 * chk["live_bricks"] + 64, chk
-                v.Voxelize(N, mode)
-                check_whole(v.Grid(), configs[key], f"{key} queue, second launch")
-                v.set_option("plan", 2)
                 for again in range(2):
                     v.Voxelize(N, mode)
+                    assert v.stats()["plan_bricks"] == st["plan_bricks"] and v.stats()["plan_waves"] == st["plan_waves"]
+                    check_whole(v.Grid(), configs[key], f"{key} queue rebuilt, launch {again + 2}")
+                v.set_option("plan", 1)
+                for again in range(3):
+                    v.Voxelize(N, mode)
                     assert v.stats()["plan_bricks"] == st["plan_bricks"]
-                    check_whole(v.Grid(), configs[key], f"{key} queue rebuilt, launch {again}")
+                    check_whole(v.Grid(), configs[key], f"{key} kept queue, launch {again + 1}")
+                assert 8 * ((st["plan_bricks"] + 7) // 8) == v.stats()["plan_waves"]      # (one workgroup per item of an XCD's equal share)
+                chk = v.plan_check()
+                assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == st["plan_bricks"], chk
                 v.set_option("plan", 0)
                 v.Voxelize(N, mode)
                 assert v.stats()["plan_bricks"] == 0
                 check_whole(v.Grid(), configs[key], f"{key} brick box")
-                v.set_option("plan", 1)
+                v.set_option("plan", 2)
     finally:
         v.close()
 
@@ -164,7 +170,7 @@ def test_config4_dragon9_1024_slabs_and_block_cyclic(dxv, configs):
                     z0, nz = slab_range(N, r, W)
                     v.Voxelize(N, 0, z0, nz)
                     assert v.stats()["plan_bricks"] == 0 and sha(v.Grid()) == want["slabs8_sha256"][r], f"slab {r} over the brick box"
-                v.set_option("plan", 1)
+                v.set_option("plan", 2)
     finally:
         v.close()
 
@@ -187,12 +193,18 @@ def test_config5_soup10m_512(dxv, configs):
         v.Voxelize(512)
         assert v.stats()["plan_bricks"] == 0
         check_whole(v.Grid(), configs[key], f"{key} brick box")
-        v.set_option("plan", 1)
-        v.Voxelize(512)
+        for plan in (1, 1, 2):
+            v.set_option("plan", plan)
+            v.Voxelize(512)
         if v.stats()["list_entries"]:
             assert v.stats()["plan_bricks"] > 0
             chk = v.plan_check()
             assert chk["violations"] == 0 and chk["duplicates"] == 0, chk
+            # The lists' superset claim, exhaustively, on a slab of this very scene: 27 texels per triangle make config 5 the case
+            # the margin-based culls of the list build (per-texel radial ranges, no entries outside the outline) matter most for --
+            # every (ray, triangle) pair the canonical step accepts must be selectable from the ray's texel list
+            accepted, violations, first = v.list_check(512, 240, 32)
+            assert accepted > 10_000_000 and violations == 0, (accepted, violations, first)
     finally:
         v.close()
         _cache.clear()
@@ -235,13 +247,40 @@ def test_headline_partition_of_bench_at_8_ranks(dxv, configs):
     v = dxv.Voxelizer(0)
     try:
         init(v, configs, key)
-        v.set_option("lists", 2)
-        parts = []
-        for r in range(W):
-            for _ in range(3):
-                v.VoxelizeInterleaved(N, r, W, blk)
-            assert v.stats()["plan_bricks"] > 0
-            parts.append((r, v.Grid().copy()))
-        check_whole(scatter_interleaved(parts, N, W, blk), configs[key], "8 ranks x blocks of 4 slices")
+        for plan in (2, 1):                                    # the headline's steps (nothing carried) and config.kept_step's
+            v.set_option("plan", plan)
+            parts = []
+            for r in range(W):
+                for _ in range(3):
+                    v.VoxelizeInterleaved(N, r, W, blk)
+                assert v.stats()["plan_bricks"] > 0
+                parts.append((r, v.Grid().copy()))
+            check_whole(scatter_interleaved(parts, N, W, blk), configs[key], f"8 ranks x blocks of 4 slices, plan = {plan}")
+    finally:
+        v.close()
+
+
+def test_first_second_and_third_voxelize_after_init_are_the_same_launch(dxv, configs):
+    """Init leaves everything the launches trace through finished (LBVH + lists on the static scene's map, like the reference's
+    Init, Content/Voxelizer.cpp:73) and every launch builds its queue and clears its grid: a scene's first, second and third
+    Voxelize put the same kernels into the stream, take the same time (within 10 %: the library's events around the launch) and
+    give the fixture's grid."""
+    key = "torus1m/512/reference"
+    v = dxv.Voxelizer(0)
+    try:
+        init(v, configs, key)
+        st = v.stats()
+        assert st["list_entries"] == 0                         # (launch fields: nothing launched yet)
+        v.Voxelize(512)                                        # (the process's first launch at this size: allocations, code loading)
+        for cycle in range(2):
+            init(v, configs, key)                              # a new scene on the context: Init again
+            ms, lists = [], []
+            for call in range(3):
+                v.Voxelize(512)
+                s = v.stats()
+                ms.append(s["voxelize_ms"]); lists.append((s["list_res"], s["list_entries"], s["plan_bricks"], s["plan_waves"]))
+                check_whole(v.Grid(), configs[key], f"launch {call + 1} after Init")
+            assert len(set(lists)) == 1 and lists[0][0] == 512 and lists[0][2] > 0, lists       # same map, same lists, same queue, same launch shape
+            assert max(ms) <= 1.10 * min(ms), ms
     finally:
         v.close()

@@ -2,6 +2,10 @@
 on the same inputs, against the committed golden vectors, and at BASELINE.json's full sizes
 through size-independent properties.  Bar: bit-exact (uint8 occupancy, uint32 texels, uint64
 keys, node words)."""
+# NOTE on Init: the tests of this file drive the C-ABI's own rules (dxv_set_mesh + dxv_build, then launches: option lists decides
+# when the candidate lists are built) through Voxelizer.InitDynamic.  The static path of the host mirrors -- Init builds the lists,
+# every launch is the same launch -- is what tests/test_gpu_configs.py, the smoke test and bench.py run, plus the tests below that
+# say so.
 import hashlib
 import os
 import subprocess
@@ -41,7 +45,7 @@ def sha(a):
 @pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
 def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
     vb, ib, _ = request.getfixturevalue(name)
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     st = vox.stats()
     s = orc.Scene(vb, ib)
     assert np.array_equal(np.asarray(st["bound"], np.float32), s.bound)     # A2
@@ -58,7 +62,7 @@ def test_build_stages_match_host_code(vox, orc, hostcheck, request, name):
     assert np.array_equal(vox.debug(DBG_NODES64), h.nodes64()), "wide traversal nodes differ"
     vox.set_option("wide", 0)                             # the wide copy is a section of the scene: built on request
     try:
-        vox.InitFromArrays(vb, ib)
+        vox.InitDynamic(vb, ib)
         with pytest.raises(Exception):
             vox.debug(DBG_NODES64)
         assert np.array_equal(vox.debug(DBG_NODES), nodes)
@@ -96,7 +100,7 @@ def test_refit_variants_identical(dxv, request, mesh):
         v.set_option("refit", refit)
     for vb, ib in cases:
         for v in vs:
-            v.InitFromArrays(vb, ib)
+            v.InitDynamic(vb, ib)
         want = vs[0].debug(DBG_NODES)
         for refit, v in enumerate(vs[1:], 1):
             got = v.debug(DBG_NODES)
@@ -104,7 +108,7 @@ def test_refit_variants_identical(dxv, request, mesh):
                                                np.argwhere((got != want).any(1))[:4].ravel().tolist())
             assert v.stats()["tree_height"] == vs[0].stats()["tree_height"]
         for k in range(3):                   # rebuilds are deterministic
-            vs[1].InitFromArrays(vb, ib)
+            vs[1].InitDynamic(vb, ib)
             got = vs[1].debug(DBG_NODES)
             assert np.array_equal(got, want), (mesh, "rebuild", k, "differs in", int((got != want).sum()), "words")
     for v in vs:
@@ -118,22 +122,26 @@ def test_refit_variants_identical(dxv, request, mesh):
 @pytest.mark.parametrize("mode", [0, 1])
 def test_grid_64_equals_oracle_and_golden(vox, orc, request, grids_json, grids64, name, mode):
     vb, ib, _ = request.getfixturevalue(name)
-    vox.InitFromArrays(vb, ib)
-    vox.Voxelize(64, mode)
-    g = vox.Grid()
     tag = "reference" if mode == 0 else "parity"
     want = np.unpackbits(grids64[f"{name}_64_{tag}"])[: 64 ** 3].reshape(64, 64, 64)   # brute-force oracle for mode 0
-    assert int(g.sum()) == grids_json[f"{name}/64/{tag}"]["solid"]
-    assert np.array_equal(g, want), f"{int((g != want).sum())} voxels differ from the golden grid"
-    assert np.array_equal(g, orc.Scene(vb, ib).voxelize(64, mode=mode))
-    assert vox.CountSolid() == int(g.sum())
+    # the mirrors' Init (static scene: LBVH + lists, the first launch is the lists kernel through its work queue) and the C-ABI's own
+    # rules (InitDynamic: LBVH only, a small first launch walks the tree)
+    for init, lists_at_first_launch in ((vox.InitFromArrays, mode == 0), (vox.InitDynamic, False)):
+        init(vb, ib)
+        vox.Voxelize(64, mode)
+        g = vox.Grid()
+        assert (vox.stats()["list_entries"] > 0) == lists_at_first_launch
+        assert int(g.sum()) == grids_json[f"{name}/64/{tag}"]["solid"]
+        assert np.array_equal(g, want), f"{int((g != want).sum())} voxels differ from the golden grid"
+        assert np.array_equal(g, orc.Scene(vb, ib).voxelize(64, mode=mode))
+        assert vox.CountSolid() == int(g.sum())
 
 
 @pytest.mark.parametrize("name", ["bunny", "dragon"])
 def test_grid_256_golden(vox, request, grids_json, name):
     """config 2: bunny at 256^3 on one MI355X, bit-exact (hash + per-slice popcounts)."""
     vb, ib, _ = request.getfixturevalue(name)
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     # reference rule through the tree walk (lists = 0) and through the direction-space lists from the first
     # launch on (lists = 2, the shipped path from a scene's second launch), then the parity rule
     for mode, tag, lists in ((0, "reference", 0), (0, "reference", 2), (1, "parity", 1)):
@@ -148,7 +156,7 @@ def test_grid_256_golden(vox, request, grids_json, name):
 
 def test_texels_equal_oracle(vox, orc, bunny, grids_json):
     vb, ib, _ = bunny
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     vox.EnableTexels(True)
     vox.Voxelize(64)
     g, tex = vox.Grid(), vox.Texels()
@@ -161,7 +169,7 @@ def test_texels_equal_oracle(vox, orc, bunny, grids_json):
                                       ("soup", (3000,))])
 def test_synthetic_equals_brute_force_oracle(vox, orc, gen, args):
     vb, ib = getattr(meshes, gen)(*args)
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     s = orc.Scene(vb, ib)
     for mode in ((0,) if gen == "soup" else (0, 1)):
         vox.Voxelize(16, mode)
@@ -175,7 +183,7 @@ def test_single_triangle_and_duplicates(vox, orc):
     vb[3, :3], vb[4, :3] = [-1, -1, -1], [1, 1, 1]
     one = np.arange(3, dtype=np.uint32)
     for ib in (one, np.tile(one, 37), np.tile(one, 5000)):
-        vox.InitFromArrays(vb, ib)
+        vox.InitDynamic(vb, ib)
         s = orc.Scene(vb, ib)
         for mode in (0, 1):
             vox.Voxelize(16, mode)
@@ -184,7 +192,7 @@ def test_single_triangle_and_duplicates(vox, orc):
 
 def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
     vb, ib, _ = dragon
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     want = orc.Scene(vb, ib).voxelize(64)
     for brick in range(8):
         for stack, morton, region, queue, subbox in ((0, 1, 9, 1, 1), (32, 0, 0, 0, 0), (64, 1, 3, 1, 0), (0, 0, 20, 0, 1),
@@ -229,7 +237,7 @@ def test_every_kernel_variant_gives_the_same_grid(vox, orc, dragon):
 def test_slabs_concatenate_to_the_full_grid(vox, bunny):
     """config 4's scheme on one GPU: 8 Z-slabs looped == the single-pass grid."""
     vb, ib, _ = bunny
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     vox.Voxelize(128)
     full = vox.Grid()
     parts = []
@@ -246,7 +254,7 @@ def test_interleaved_partition_equals_full_grid(vox, dragon):
     """The load-balanced partition bench.py uses for N > 1: block-cyclic Z blocks, ranks looped here."""
     from dxrvoxelizer_amd.slabs import interleaved_slices, scatter_interleaved
     vb, ib, _ = dragon
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     vox.Voxelize(128)
     full = vox.Grid()
     for world, block in ((8, 4), (4, 8), (2, 64), (1, 128)):
@@ -273,7 +281,7 @@ def test_refit_after_vertex_update_equals_rebuild(dxv, orc, bunny):
     pins[0, :3], pins[1, :3] = c - big, c + big              # unreferenced vertices pin the bound
     vb0 = np.concatenate([vb, pins]).astype(np.float32)
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb0, ib)
+    v.InitDynamic(vb0, ib)
     h0 = v.stats()["tree_height"]
     for phase in (0.7, 1.9):
         vb1 = vb0.copy()
@@ -285,7 +293,7 @@ def test_refit_after_vertex_update_equals_rebuild(dxv, orc, bunny):
         want = orc.Scene(vb1, ib).voxelize(64)
         assert np.array_equal(v.Grid(), want)
     fresh = dxv.Voxelizer(0)
-    fresh.InitFromArrays(vb1, ib)                            # full rebuild of the deformed mesh
+    fresh.InitDynamic(vb1, ib)                            # full rebuild of the deformed mesh
     fresh.Voxelize(64)
     assert np.array_equal(fresh.Grid(), v.Grid())
     with pytest.raises(dxv.DxvError):
@@ -303,7 +311,7 @@ def test_thin_and_offcentre_scenes_with_subbox_launch(vox, orc):
         vb[:, :3] = vb[:, :3] * np.float32(scale) + np.float32(shift)
         if any(shift):                                            # an unreferenced far vertex moves the bound centre
             vb = np.concatenate([vb, np.zeros((1, 6), np.float32)])
-        vox.InitFromArrays(vb, ib)
+        vox.InitDynamic(vb, ib)
         s = orc.Scene(vb, ib)
         for mode in (0, 1):
             want = s.voxelize(64, mode=mode)
@@ -328,7 +336,7 @@ def test_scene_blob_roundtrip_between_contexts(dxv, orc, dragon):
     vb, ib, _ = dragon
     a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
     a.set_option("wide", 0)                               # first a scene without the wide copy
-    a.InitFromArrays(vb, ib)
+    a.InitDynamic(vb, ib)
     n = a.scene_bytes()
     blob = torch.empty(n, dtype=torch.uint8, device="cuda")
     a.scene_export(blob.data_ptr(), n)
@@ -421,7 +429,7 @@ def test_frames_in_flight_share_one_scene(dxv, orc, bunny, dragon):
     v = dxv.Voxelizer(0)
     assert v.FrameCount == 3
     v.set_option("lists", 2)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     s = orc.Scene(vb, ib)
     jobs = [(64, 0), (96, 1), (128, 0)]
     for rounds in range(3):                                # back to back, no host sync in between
@@ -442,7 +450,7 @@ def test_frames_in_flight_share_one_scene(dxv, orc, bunny, dragon):
     for f in range(3):
         v.Voxelize(128, 0, sync=False, frameIndex=f)
     vb2, ib2, _ = dragon
-    v.InitFromArrays(vb2, ib2)
+    v.InitDynamic(vb2, ib2)
     want = orc.Scene(vb2, ib2).voxelize(64)
     for f in (2, 0, 1):
         v.Voxelize(64, 0, sync=False, frameIndex=f)
@@ -469,8 +477,8 @@ def test_import_over_a_built_context_drops_its_mesh_state(dxv, orc, bunny, drago
     small_vb, small_ib = meshes.tetrahedron()
     vb, ib, _ = dragon
     a, b = dxv.Voxelizer(0), dxv.Voxelizer(0)
-    a.InitFromArrays(vb, ib)
-    b.InitFromArrays(small_vb, small_ib)
+    a.InitDynamic(vb, ib)
+    b.InitDynamic(small_vb, small_ib)
     n = a.scene_bytes()
     blob = torch.empty(n, dtype=torch.uint8, device="cuda")
     a.scene_export(blob.data_ptr(), n)
@@ -482,7 +490,7 @@ def test_import_over_a_built_context_drops_its_mesh_state(dxv, orc, bunny, drago
             call()
     a.Voxelize(64), b.Voxelize(64)
     assert np.array_equal(a.Grid(), b.Grid())
-    b.InitFromArrays(small_vb, small_ib)                  # and the context is still usable for a mesh of its own
+    b.InitDynamic(small_vb, small_ib)                  # and the context is still usable for a mesh of its own
     b.Voxelize(16)
     assert np.array_equal(b.Grid(), orc.Scene(small_vb, small_ib).voxelize(16))
     a.close(), b.close()
@@ -495,8 +503,8 @@ def test_non_finite_vertices_are_rejected(dxv):
         w = vb.copy()
         w[5, 1] = bad
         with pytest.raises(dxv.DxvError, match="vertex 5"):
-            v.InitFromArrays(w, ib)
-    v.InitFromArrays(vb, ib)
+            v.InitDynamic(w, ib)
+    v.InitDynamic(vb, ib)
     v.close()
 
 
@@ -505,14 +513,14 @@ def test_errors_are_loud(dxv, bunny):
     v = dxv.Voxelizer(0)
     with pytest.raises(dxv.DxvError):
         v.Voxelize(64)                                    # before Init
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     for bad in ((63, 0, 63), (64, 60, 8), (64, 0, 0), (4096, 0, 1)):
         with pytest.raises(dxv.DxvError):
             v.Voxelize(bad[0], 0, bad[1], bad[2])
     with pytest.raises(dxv.DxvError):
-        v.InitFromArrays(vb, np.array([0, 1, 10 ** 6], np.uint32))
+        v.InitDynamic(vb, np.array([0, 1, 10 ** 6], np.uint32))
     with pytest.raises(dxv.DxvError):
-        v.InitFromArrays(np.zeros((3, 6), np.float32), np.arange(3, dtype=np.uint32))   # zero extent
+        v.InitDynamic(np.zeros((3, 6), np.float32), np.arange(3, dtype=np.uint32))   # zero extent
     # 2^17+ identical triangles: every ray that hits them descends both children at every level
     tri = np.zeros((5, 6), np.float32)
     tri[:3, :3] = [[-0.9, -0.9, 0.4], [0.9, -0.9, 0.4], [0.0, 0.9, 0.4]]
@@ -520,7 +528,7 @@ def test_errors_are_loud(dxv, bunny):
     tri[3, :3], tri[4, :3] = [-1, -1, -1], [1, 1, 1]
     deep = np.tile(np.arange(3, dtype=np.uint32), 140000)
     v.set_option("lists", 0)                              # this test is about the tree walks' columns
-    v.InitFromArrays(tri, deep)
+    v.InitDynamic(tri, deep)
     assert v.stats()["tree_height"] >= 17
     v.Voxelize(16)
     want16 = v.Grid()
@@ -541,7 +549,7 @@ def test_errors_are_loud(dxv, bunny):
         v.set_option("stack0", 20)
     v.set_option("wide", 2)
     one = dxv.Voxelizer(0)
-    one.InitFromArrays(tri, np.arange(3, dtype=np.uint32))
+    one.InitDynamic(tri, np.arange(3, dtype=np.uint32))
     one.Voxelize(16)
     assert np.array_equal(want16, one.Grid())             # 140000 coincident copies == one triangle
     one.close()
@@ -636,7 +644,7 @@ def test_cpp_multi_gpu_host(orc, bunny, grids_json, tmp_path):
 def test_full_size_properties_torus_1m_512(vox, orc):
     vb, ib = meshes.torus()                                # exactly 1,000,000 triangles
     assert len(ib) // 3 == 1_000_000
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     N = 512
     vox.Voxelize(N)
     g = vox.Grid()
@@ -670,7 +678,7 @@ def test_largest_grid_2048_indexing(vox, orc, dragon):
     """Maximum size: 2048^3 = 8.6 G voxels, ids beyond 2^32.  The full grid's solid count must equal
     the sum over 8 Z slabs (same voxels, small ids), and spot slices must equal the oracle."""
     vb, ib, _ = dragon
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     N = 2048
     s = orc.Scene(vb, ib)
     for mode in (1, 0):
@@ -697,7 +705,7 @@ def test_device_resident_full_grid_by_allgather(dxv, dragon, tmp_path):
     from dxrvoxelizer_amd.slabs import allgather_grid, device_grid_tensor, interleaved_slices
     vb, ib, _ = dragon
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.Voxelize(64)
     full = v.Grid()
     assert np.array_equal(device_grid_tensor(v, "cuda").cpu().numpy().reshape(64, 64, 64), full)   # zero-copy view
@@ -723,7 +731,7 @@ def test_device_resident_full_grid_by_allgather(dxv, dragon, tmp_path):
 def test_bit_packed_download_equals_packbits(vox, bunny, n, z0, nz):
     """dxv_grid_download_packed: voxel 8j+i in bit i of byte j, any slab size (ragged tails)."""
     vb, ib, _ = bunny
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     vox.Voxelize(n, 0, z0, nz)
     g = vox.Grid()
     bits = vox.GridBits()
@@ -740,7 +748,7 @@ def test_wide_walk_equals_binary_walk(vox, orc, request, name, n):
     vb, ib, _ = request.getfixturevalue(name)
     vox.set_option("wide", 0)
     vox.set_option("lists", 0)
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     vox.EnableTexels(True)
     vox.Voxelize(n)
     g0, t0 = vox.Grid(), vox.Texels()
@@ -775,7 +783,7 @@ def test_parity_row_blocks_equal_single_rows(vox, orc, request, name, wide):
     slice is repeated inside a block), offsets, and the block-cyclic partition."""
     vb, ib, _ = request.getfixturevalue(name)
     vox.set_option("wide", wide)                      # 0: the scene has no four-box nodes, the rows walk the binary ones
-    vox.InitFromArrays(vb, ib)
+    vox.InitDynamic(vb, ib)
     s = orc.Scene(vb, ib)
     want = s.voxelize(64, mode=1)
     try:
@@ -821,7 +829,7 @@ def test_pyramid_refit_equals_sweep_refit_word_for_word(dxv, bunny):
         for refit in (1, 2, 0):
             v = dxv.Voxelizer(0)
             v.set_option("refit", refit)
-            v.InitFromArrays(vb0, ib)
+            v.InitDynamic(vb0, ib)
             v.UpdateVertices(vb1)
             words.append((v.debug(DBG_NODES).copy(), v.debug(DBG_NODES32).copy(), v.stats()["tree_height"]))
             v.close()
@@ -844,7 +852,7 @@ def test_refit_defers_node_boxes_until_a_walk_needs_them(dxv, orc, bunny):
     now.set_option("deferboxes", 0)
     for v in (late, now):
         v.set_option("lists", 2)
-        v.InitFromArrays(vb0, ib)
+        v.InitDynamic(vb0, ib)
     for step in range(3):
         vb1 = vb0.copy()
         vb1[:-2, :3] += rng.uniform(-0.004, 0.004, size=(len(vb), 3)).astype(np.float32)
@@ -888,7 +896,7 @@ def test_vertex_upload_overlaps_a_launch_in_flight(dxv, orc, bunny):
     assert not np.array_equal(s0, s1)
     v = dxv.Voxelizer(0)
     v.set_option("lists", 2)
-    v.InitFromArrays(vb0, ib)
+    v.InitDynamic(vb0, ib)
     for frame in range(4):
         cur, nxt = (vb0, vb1) if frame % 2 == 0 else (vb1, vb0)
         v.Voxelize(96, sync=False)
@@ -916,7 +924,7 @@ def test_lists_equal_tree_walk_and_host_lists(dxv, orc, hostcheck, request, name
     equal, word for word, the lists the same footprint code builds on the host."""
     vb, ib, _ = request.getfixturevalue(name)
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     s = orc.Scene(vb, ib)
     for N, R in ((64, 256), (50, 64), (128, 1024)):
         v.set_option("lists", 0)
@@ -948,7 +956,7 @@ def test_lists_equal_tree_walk_and_host_lists(dxv, orc, hostcheck, request, name
 def test_lists_follow_the_scene_and_fall_back_over_the_cap(dxv, orc, bunny):
     vb, ib, _ = bunny
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.Voxelize(64)                                                    # default: the first launch of a scene walks the tree,
     assert v.stats()["list_entries"] == 0
     a = v.Grid().copy()
@@ -971,7 +979,7 @@ def test_lists_follow_the_scene_and_fall_back_over_the_cap(dxv, orc, bunny):
     pos = rng.uniform(-1, 1, (3 * T, 3)).astype(np.float32)
     big = np.hstack([pos, np.tile(np.array([[0, 0, 1]], np.float32), (3 * T, 1))])
     v.set_option("listres", 4096)
-    v.InitFromArrays(big, np.arange(3 * T, dtype=np.uint32))
+    v.InitDynamic(big, np.arange(3 * T, dtype=np.uint32))
     v.Voxelize(32)
     assert v.stats()["list_entries"] == 0
     assert np.array_equal(v.Grid(), orc.Scene(big, np.arange(3 * T, dtype=np.uint32)).voxelize(32, algo=orc.ALGO_BRUTE))
@@ -985,10 +993,10 @@ def test_first_launch_list_policy(dxv, dragon):
     from bench import make_mesh
     vb, ib, _ = dragon
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.Voxelize(128)                                                    # 2 M voxels: the tree walk is cheaper than any build
     assert v.stats()["list_entries"] == 0
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.Voxelize(416)                                                    # 72 M voxels, 2.7 M entries: the build pays at once
     st = v.stats()
     assert st["list_entries"] > 0 and st["list_res"] == 256
@@ -1001,7 +1009,7 @@ def test_first_launch_list_policy(dxv, dragon):
     assert v.stats()["list_entries"] == 0 and v.CountSolid() == solid
     v.set_option("lists", 1)
     vb9, ib9, _ = make_mesh("dragon9")                                  # a first-launch build keeps the base map (it must pay at once);
-    v.InitFromArrays(vb9, ib9)                                          # launched again, un-refitted, the scene is static: once, the 512 map
+    v.InitDynamic(vb9, ib9)                                          # launched again, un-refitted, the scene is static: once, the 512 map
     res, counts = [], []
     for _ in range(3):
         v.Voxelize(416)
@@ -1026,20 +1034,20 @@ def test_update_vertices_from_a_device_buffer(dxv, orc, bunny):
     moved[:, 1] *= 0.7
     moved[:, 0] += 0.1 * np.sin(7.0 * moved[:, 2])
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.Voxelize(64)
     d = torch.from_numpy(moved).cuda()
     torch.cuda.synchronize()
     v.UpdateVerticesDevice(d.data_ptr(), len(moved))
     v.Voxelize(64)
     a = v.Grid().copy()
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.UpdateVertices(moved)
     v.Voxelize(64)
     assert np.array_equal(a, v.Grid())
     s = orc.Scene(moved, ib)                                           # (the oracle normalises by the moved mesh's own bound: compare
     w = dxv.Voxelizer(0)                                               # with a context built on the moved mesh only when bounds agree)
-    w.InitFromArrays(moved, ib)
+    w.InitDynamic(moved, ib)
     w.Voxelize(64)
     if np.allclose(s.bound, orc.Scene(vb, ib).bound):
         assert np.array_equal(a, w.Grid())
@@ -1071,7 +1079,7 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
     v = dxv.Voxelizer(0)
     for vb, ib, _ in (bunny, dragon):
         s = orc.Scene(vb, ib)
-        v.InitFromArrays(vb, ib)
+        v.InitDynamic(vb, ib)
         for N in (64, 130):
             want = s.voxelize(N, mode=1)
             v.set_option("plists", 2)
@@ -1090,7 +1098,7 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
         assert np.array_equal(v.Grid(), s.voxelize(128, mode=1)[zs])
     # rows of 1024 voxels: two runs per row
     vb, ib, _ = dragon
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.set_option("plists", 2)
     v.Voxelize(1024, dxv.MODE_PARITY, 500, 24)
     a = v.Grid().copy()
@@ -1099,7 +1107,7 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
     assert a.sum() > 0 and np.array_equal(a, v.Grid())
     # policy of the default: a small first launch walks the tree, the second one has the lists; a refit starts over
     v.set_option("plists", 1)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.Voxelize(64, dxv.MODE_PARITY)
     assert v.stats()["list_entries"] == 0
     v.Voxelize(64, dxv.MODE_PARITY)
@@ -1120,7 +1128,7 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
     n0 = len(vb)
     wib = np.concatenate([ib, np.array([n0, n0 + 1, n0 + 2, n0, n0 + 2, n0 + 3], np.uint32)])
     v.set_option("plists", 2)
-    v.InitFromArrays(wvb, wib)
+    v.InitDynamic(wvb, wib)
     v.Voxelize(64, dxv.MODE_PARITY)
     assert v.stats()["list_entries"] == 0
     assert np.array_equal(v.Grid(), orc.Scene(wvb, wib).voxelize(64, mode=1))
@@ -1132,7 +1140,7 @@ def test_parity_row_lists_equal_tree_walk_and_oracle(dxv, orc, bunny, dragon):
     for n_tris, L, N in ((1, 8, 16), (7, 8, 32), (200, 16, 64), (30, 32, 96), (1500, 32, 64)):
         vb, ib = lattice_mesh(rng, n_tris, L)
         want = orc.Scene(vb, ib).voxelize(N, mode=1, algo=orc.ALGO_BRUTE)
-        v.InitFromArrays(vb, ib)
+        v.InitDynamic(vb, ib)
         v.Voxelize(N, dxv.MODE_PARITY)
         served += v.stats()["list_entries"] > 0
         assert np.array_equal(v.Grid(), want), (n_tris, L, N)
@@ -1156,7 +1164,7 @@ def test_kept_memset_of_partial_launches(dxv, orc):
     ref, par = s.voxelize(N, mode=0), s.voxelize(N, mode=1)
     assert int((par & (1 - ref))[:, :, : N // 2 - 8].sum()) > 100000          # parity ones far to the left of the quad's box
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     for lists, plan in ((2, 1), (2, 0), (0, 0)):                        # lists through the work queue / over the brick box, tree walk
@@ -1199,7 +1207,7 @@ def waves_persistent(v):
         w.set_option("plan", 2)
         import numpy as _np
         tri = _np.array([[-.5, -.5, 0, 0, 0, 1], [.5, -.5, 0, 0, 0, 1], [0, .5, .1, 0, 0, 1]], _np.float32)
-        w.InitFromArrays(tri, _np.arange(3, dtype=_np.uint32))
+        w.InitDynamic(tri, _np.arange(3, dtype=_np.uint32))
         w.Voxelize(32)
         return w.stats()["plan_waves"]
     finally:
@@ -1222,7 +1230,7 @@ def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, host
     exposed, grid_cap = False, 0
     for (vb, ib, _), sizes in ((bunny, (64, 50, 100, 256)), (dragon, (66, 128))):
         s = orc.Scene(vb, ib)
-        v.InitFromArrays(vb, ib)
+        v.InitDynamic(vb, ib)
         for N in sizes:
             want = s.voxelize(N)
             v.set_option("plan", 0)
@@ -1231,7 +1239,7 @@ def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, host
             for plan, dispatch in ((1, 1), (1, 0), (2, 1)):
                 v.set_option("plan", plan)
                 v.set_option("dispatch", dispatch)
-                v.InitFromArrays(vb, ib)                                # (a new queue: its first launch does not know its size)
+                v.InitDynamic(vb, ib)                                # (a new queue: its first launch does not know its size)
                 waves = []
                 for again in range(3):
                     v.Voxelize(N)
@@ -1268,7 +1276,7 @@ def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, host
     # the device's max-mip of the far radii is the host's, word for word
     vb, ib, _ = bunny
     s = orc.Scene(vb, ib)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)
     v.Voxelize(64)
     R = v.stats()["list_res"]
     h = hostcheck(vb, ib, s.bound)
@@ -1295,7 +1303,7 @@ def test_work_queue_equals_plain_launch_and_oracle(dxv, orc, bunny, dragon, host
     pins = np.zeros((2, 6), np.float32)
     pins[0, :3], pins[1, :3] = (lo + hi) / 2 - 1.25 * (hi - lo).max() / 2, (lo + hi) / 2 + 1.25 * (hi - lo).max() / 2
     vb0 = np.concatenate([vb, pins]).astype(np.float32)                 # (unreferenced vertices pin the bound through the refit)
-    v.InitFromArrays(vb0, ib)
+    v.InitDynamic(vb0, ib)
     v.Voxelize(N); v.Voxelize(N)
     b0 = v.stats()["plan_bricks"]
     assert b0 > 0
@@ -1345,17 +1353,17 @@ def test_deferred_list_verdict_and_queued_refit_frames(dxv, orc, bunny):
     ibp = np.arange(len(pos), dtype=np.uint32)
     t = dxv.Voxelizer(0)
     t.set_option("lists", 0)
-    t.InitFromArrays(vbp, ibp)
+    t.InitDynamic(vbp, ibp)
     t.Voxelize(64)
     want = t.Grid().copy()
     assert want.any()
     v = dxv.Voxelizer(0)
     v.set_option("lists", 2)
-    v.InitFromArrays(vbp, ibp)
+    v.InitDynamic(vbp, ibp)
     v.Voxelize(64)
     st = v.stats()
     assert np.array_equal(v.Grid(), want) and st["list_entries"] == 0 and st["list_ms"] > 0      # (built, then withdrawn)
-    v.InitFromArrays(vbp, ibp)
+    v.InitDynamic(vbp, ibp)
     for f in (0, 1, 0):
         v.Voxelize(64, sync=False, frameIndex=f)                       # queued behind the build, and behind each other
     v.SyncAll()
@@ -1374,7 +1382,7 @@ def test_deferred_list_verdict_and_queued_refit_frames(dxv, orc, bunny):
         m[:, 0] += np.float32(0.05) * np.sin(np.float32(5.0 + k) * m[:, 2])
         return m
 
-    v.InitFromArrays(base, ib)
+    v.InitDynamic(base, ib)
     v.Voxelize(128)
     e0 = v.stats()["list_entries"]
     assert e0 > 0
@@ -1389,7 +1397,7 @@ def test_deferred_list_verdict_and_queued_refit_frames(dxv, orc, bunny):
     v.SyncAll()
     w = dxv.Voxelizer(0)
     w.set_option("lists", 0)
-    w.InitFromArrays(base, ib)
+    w.InitDynamic(base, ib)
     w.UpdateVertices(pose(4))
     w.Voxelize(128)
     v.SetFrame(0)
