@@ -17,49 +17,91 @@ constexpr uint32_t kThreads = 256;
 
 __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R,
                                                          DirRecord* __restrict__ rec, uint32_t* __restrict__ counts,
-                                                         unsigned long long* __restrict__ total)
+                                                         unsigned long long* __restrict__ total, uint32_t* __restrict__ pairs)
 {
     // one thread per triangle, its six faces in turn: the triangle is loaded once, the 64 triangles of a wave are neighbours
     // in Morton order and mostly see the same one or two faces (the clip runs with nearly full waves), and a face that does
     // not see the triangle costs a dozen comparisons and no record -- its count of 0 is all k_dm_emit looks at
     const uint32_t tri = blockIdx.x * kThreads + threadIdx.x;
     unsigned long long n = 0;
-    if (tri < T) {
-        const TriPos tp = triPos[tri];
+    uint32_t seen = 0;                                                  // faces of this triangle that get entries
+    const uint32_t lane0 = threadIdx.x & 63u;
+    TriPos tp{};
+    if (tri < T) tp = triPos[tri];
 #pragma unroll 1
-        for (uint32_t face = 0; face < 6u; ++face) {
-            const uint32_t i = tri * 6u + face;
-            DirFootprint f;
-            uint32_t c = 0;
-            if (dm_footprint(tp, face, f)) {
-                DirRecord e = dm_record(f);
-                uint32_t i0, i1, j0, j1;
-                if (dm_rect(e, R, i0, i1, j0, j1)) {
-                    c = (i1 - i0 + 1u) * (j1 - j0 + 1u);
-                    dm_record_on_map(e, c);                             // (by the rectangle's area, like every other threshold of the record)
-                    // texels wholly outside an edge of the projected triangle get no entry (dm_texel_outside: k_dm_emit skips the same ones)
-                    const DirTexelTest tt = dm_texel_test(e, c);
-                    if (tt.on) {
-                        c = 0;
-                        for (uint32_t j = j0; j <= j1; ++j)
-                            for (uint32_t x = i0; x <= i1; ++x) c += dm_texel_outside(tt, R, x, j) ? 0u : 1u;
-                    }
+    for (uint32_t face = 0; face < 6u; ++face) {
+        const uint32_t i = tri * 6u + face;
+        DirFootprint f;
+        uint32_t c = 0, i0 = 0, i1 = 0, j0 = 0, j1 = 0;
+        DirTexelTest tt{};
+        bool wide = false;
+        if (tri < T && dm_footprint(tp, face, f)) {
+            DirRecord e = dm_record(f);
+            if (dm_rect(e, R, i0, i1, j0, j1)) {
+                c = (i1 - i0 + 1u) * (j1 - j0 + 1u);
+                dm_record_on_map(e, c);                                 // (by the rectangle's area, like every other threshold of the record)
+                // texels wholly outside an edge of the projected triangle get no entry (dm_texel_outside: k_dm_emit skips the same ones)
+                tt = dm_texel_test(e, c);
+                wide = tt.on && c > 32u;                                // (counted by the whole wave below)
+                if (tt.on && !wide) {
+                    c = 0;
+                    for (uint32_t j = j0; j <= j1; ++j)
+                        for (uint32_t x = i0; x <= i1; ++x) c += dm_texel_outside(tt, R, x, j) ? 0u : 1u;
                 }
-                rec[i] = e;
             }
+            rec[i] = e;
+        }
+        // rectangles of more than 32 texels (a coarse mesh, a soup: 27 texels per triangle on average, up to 1,024): the wave counts
+        // them together, 64 texels at a time -- one thread walking a thousand texels while its neighbours wait was a third of a
+        // 10 M-triangle list build
+        unsigned long long m = __ballot(wide);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1ull;
+            auto bf = [src](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+            auto bu = [src](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+            DirTexelTest t;
+            t.on = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { t.nx[k] = bf(tt.nx[k]); t.ny[k] = bf(tt.ny[k]); t.c[k] = bf(tt.c[k]); }
+            const uint32_t a0 = bu(i0), a1 = bu(i1), b0 = bu(j0), b1 = bu(j1), wdt = a1 - a0 + 1u, cnt = wdt * (b1 - b0 + 1u);
+            uint32_t kept = 0;
+            for (uint32_t first = 0; first < cnt; first += 64u) {
+                const uint32_t idx = first + lane0;
+                kept += (uint32_t)__builtin_popcountll(__ballot(idx < cnt && !dm_texel_outside(t, R, a0 + idx % wdt, b0 + idx / wdt)));
+            }
+            if ((int)lane0 == src) c = kept;
+        }
+        if (tri < T) {
             counts[i] = c;
             n += c;
+            seen |= c ? 1u << face : 0u;
         }
     }
+    // The (triangle, face) pairs that get entries, as a compact list for k_dm_emit: five pairs in six have none, and a thread per
+    // pair left k_dm_emit's waves with a sixth of their lanes in the loop over texels.  One add per workgroup; the order of the
+    // list is whatever the adds make it, the keys land at their pair's offset all the same.
+    const uint32_t mine = (uint32_t)__builtin_popcount(seen), lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t incl = mine;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if ((int)lane >= off) incl += o; }
     for (int off = 32; off; off >>= 1) n += __shfl_down(n, off);
     __shared__ unsigned long long part[kThreads / 64];
-    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = n;
+    __shared__ uint32_t pairPart[kThreads / 64], pairBase;
+    if (lane == 0u) part[w] = n;
+    if (lane == 63u) pairPart[w] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long s = 0;
-        for (uint32_t w = 0; w < kThreads / 64; ++w) s += part[w];
+        uint32_t np = 0;
+        for (uint32_t k = 0; k < kThreads / 64; ++k) { s += part[k]; np += pairPart[k]; }
         if (s) atomicAdd(total, s);
+        pairBase = np ? atomicAdd(reinterpret_cast<uint32_t*>(total + 1), np) : 0u;
     }
+    __syncthreads();
+    uint32_t at = pairBase + incl - mine;
+    for (uint32_t k = 0; k < w; ++k) at += pairPart[k];
+    for (uint32_t face = 0; face < 6u; ++face)
+        if (seen & (1u << face)) pairs[at++] = tri * 6u + face;
 }
 
 // exclusive scan of counts[0 .. n) in three launches: per-block sums, scan of the sums by one block, add
@@ -125,13 +167,17 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ counts,
-                                                      const uint32_t* __restrict__ offsets, uint32_t T, uint32_t R, uint64_t* __restrict__ keys)
+__global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ pairs,
+                                                      const unsigned long long* __restrict__ total,
+                                                      const uint32_t* __restrict__ offsets, uint32_t R, uint64_t* __restrict__ keys)
 {
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    // one thread per (triangle, face) pair that gets entries (k_dm_records' list; workgroups behind its end leave at once)
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x, numPairs = *reinterpret_cast<const uint32_t*>(total + 1);
+    if (blockIdx.x * kThreads >= numPairs) return;
+    const uint32_t i = t < numPairs ? pairs[t] : 0u;
     const DirKeyLayout lay = dm_key_layout(R);
     uint32_t i0 = 0, i1 = 0, j0 = 0, j1 = 0;
-    const bool valid = i < 6u * T && counts[i] != 0u && dm_rect(rec[i], R, i0, i1, j0, j1);     // (no record behind a count of 0)
+    const bool valid = t < numPairs && dm_rect(rec[i], R, i0, i1, j0, j1);
     const uint32_t area = valid ? (i1 - i0 + 1u) * (j1 - j0 + 1u) : 0u;
     // footprints of many texels (a triangle near the centre, the triangles of a coarse mesh) are written by the whole wave, 64
     // texels at a time: one thread walking thousands of texels, each with its own radial range, was the build's tail
@@ -210,40 +256,67 @@ __global__ __launch_bounds__(kThreads) void k_dm_hints(DirCell* __restrict__ cel
 // (all of a surface mesh's): one thread per texel; long ones (deep scenes: hundreds of entries): one wave per texel, 64
 // entries per step, the running minimum by a prefix scan across the lanes (lane 0 = the entry nearest the far end).
 constexpr uint32_t kStopsShort = 32u;
-__global__ __launch_bounds__(kThreads) void k_dm_stops(DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries,
-                                                       uint32_t* __restrict__ longCells, uint32_t* __restrict__ longCount)
+// (eight lanes per texel: lane j of a group takes the j-th entry from the far end of a chunk of eight -- the entries of a group lie
+// behind one another in memory, the running minimum is three shuffle steps; one thread walking its texel's list alone, twice, was
+// 0.15 ms of the 1.1 ms a 1 M-triangle list build takes)
+// texels with a long list go on k_dm_stops_long's work list (at most n / 33 of them): one thread per texel, one atomic per
+// workgroup of 1024 texels (one per texel on one address: 0.1 ms at 50 k long texels; one per wave of eight texels: 0.5 ms on a soup)
+__global__ __launch_bounds__(1024) void k_dm_long_cells(const DirCell* __restrict__ cells, uint32_t ncells, uint32_t* __restrict__ longCells,
+                                                        uint32_t* __restrict__ longCount)
 {
-    const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
+    __shared__ uint32_t waveCount[16], base;
+    const uint32_t c = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool isLong = c < ncells && cells[c].count > kStopsShort;
+    const unsigned long long m = __ballot(isLong);
+    if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t n = 0;
+        for (int k = 0; k < 16; ++k) n += waveCount[k];
+        base = n ? atomicAdd(longCount, n) : 0u;
+    }
+    __syncthreads();
+    if (!isLong) return;
+    uint32_t at = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    for (uint32_t k = 0; k < w; ++k) at += waveCount[k];
+    longCells[at] = c;
+}
+__global__ __launch_bounds__(kThreads) void k_dm_stops(DirCell* __restrict__ cells, uint32_t ncells, DirEntry* __restrict__ entries)
+{
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x, c = t >> 3, j = t & 7u;
     DirCell cell{};
     if (c < ncells) cell = cells[c];
-    // texels with a long list go on k_dm_stops_long's work list (at most n / 33 of them): one atomic per wave, consecutive
-    // slots for its lanes (one atomic per texel on one address: 0.1 ms at 50 k long texels)
-    const bool isLong = cell.count > kStopsShort;
-    const unsigned long long m = __ballot(isLong);
-    if (m) {
-        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(m);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(longCount, (uint32_t)__builtin_popcountll(m));
-        base = __shfl(base, (int)leader);
-        if (isLong) longCells[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = c;
-    }
-    if (c >= ncells || isLong || cell.count == 0u) return;
+    const bool isLong = cell.count > kStopsShort;                       // (k_dm_stops_long's: k_dm_long_cells has listed them)
+    if (c >= ncells || isLong || cell.count == 0u) return;              // (the eight lanes of a group leave together)
+    auto far = [](uint32_t rr) { return half_bits_to_float((rr >> 16) & 0x7fffu); };            // dm_entry_r1 / dm_entry_r0 of the radial word
+    auto near = [](uint32_t rr) { return half_bits_to_float(0x7fffu - (rr & 0x7fffu)); };
     // radial extent of the thickest entry of the texel: the unit of the stop codes (halfs convert and subtract exactly)
     uint32_t thick = 0;
-    for (uint32_t k = 0; k < cell.count; ++k) {
-        const DirEntry& e = entries[cell.begin + k];
-        const uint32_t th = half_up(dm_entry_r1(e) - dm_entry_r0(e));
-        if (th > thick) thick = th;
-    }
-    cells[c].thick = (uint16_t)thick;
-    cell.thick = (uint16_t)thick;
-    const float step = dm_stop_step(half_bits_to_float(cell.thick));
-    float s = 3.0e38f;
-    for (uint32_t k = cell.count; k-- > 0u;) {
-        DirEntry& e = entries[cell.begin + k];
-        const float r0 = dm_entry_r0(e);
-        if (r0 < s) s = r0;
-        e.tri = (e.tri & kDmTriMask) | (dm_stop_code(dm_entry_r1(e), s, step) << kDmTriBits);
+    for (uint32_t base = 0; base < cell.count; base += 8u)
+        if (base + j < cell.count) {
+            const uint32_t rr = entries[cell.begin + base + j].rr;
+            const uint32_t th = half_up(far(rr) - near(rr));
+            if (th > thick) thick = th;
+        }
+    for (int off = 1; off < 8; off <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)thick, off, 8); if (o > thick) thick = o; }
+    if (j == 0u) cells[c].thick = (uint16_t)thick;
+    const float step = dm_stop_step(half_bits_to_float((uint16_t)thick));
+    // from the far end: lane j of a chunk holds the earliest start among the chunk's entries 0 .. j (three shuffle steps), then
+    // among everything behind the chunk (carry)
+    float carry = 3.0e38f;
+    for (uint32_t base = 0; base < cell.count; base += 8u) {
+        const bool valid = base + j < cell.count;
+        const uint32_t k = valid ? cell.begin + cell.count - 1u - base - j : cell.begin;
+        const uint32_t rr = entries[k].rr, tri = entries[k].tri;
+        float v = valid ? near(rr) : 3.0e38f;
+        for (int off = 1; off < 8; off <<= 1) {
+            const float o = __shfl_up(v, off, 8);
+            if ((int)j >= off && o < v) v = o;
+        }
+        const float sofar = v < carry ? v : carry;
+        if (valid) entries[k].tri = (tri & kDmTriMask) | (dm_stop_code(far(rr), sofar, step) << kDmTriBits);
+        const float last = __shfl(v, 7, 8);
+        if (last < carry) carry = last;
     }
 }
 // (the texels with long lists were listed by k_dm_stops: longCount[0] of them in longCells)
@@ -409,19 +482,20 @@ size_t dirmap_scratch_bytes(uint32_t T, uint64_t entries)
 }
 
 // Pass 1: records, per-(triangle, face) counts and the total.  rec: 6T entries, counts: 6T words, total: one 64-bit word.
-hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, unsigned long long* total,
+// pairs: 6T words (the (triangle, face) pairs that get entries; their number lands in the word behind the total)
+hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, uint32_t* pairs, unsigned long long* total,
                         hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(total, 0, 2 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    k_dm_records<<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total);
+    k_dm_records<<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs);
     return hipGetLastError();
 }
 
 // Pass 2: lists.  offsets: 6T words, sums: ceil(6T / 1024) words, keys / keysTmp: n each, hist: radix_sort_hist_words(n),
 // cells: 6 R R, entries: n (n = the total of pass 1).
-hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint32_t* counts, uint32_t* offsets, uint32_t* sums,
-                       uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longestOut,
+hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint32_t* counts, const uint32_t* pairs, const unsigned long long* total,
+                       uint32_t* offsets, uint32_t* sums, uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longestOut,
                        hipStream_t s)
 {
     const uint32_t n6 = 6u * T, nb = (n6 + kScanBlock - 1) / kScanBlock;
@@ -431,7 +505,7 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_scan_apply<<<nb, 256, 0, s>>>(counts, n6, sums, offsets);
     if ((e = hipMemsetAsync(cells, 0, sizeof(DirCell) * 6 * (size_t)R * R, s)) != hipSuccess) return e;
     if (n == 0) return hipGetLastError();
-    k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, counts, offsets, T, R, keys);
+    k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, pairs, total, offsets, R, keys);
     // sort by (texel, far radius): the bits above the triangle field, in whole 8-bit digits
     const DirKeyLayout lay = dm_key_layout(R);
     const int passes = (int)((lay.cellBits + 16u + 7u) / 8u), loBit = 64 - 8 * passes;
@@ -446,7 +520,8 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums);
     const uint32_t ncells = 6u * R * R;
     k_dm_hints<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
-    k_dm_stops<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries, longCells, sums + 1);
+    k_dm_long_cells<<<(ncells + 1023u) / 1024u, 1024, 0, s>>>(cells, ncells, longCells, sums + 1);
+    k_dm_stops<<<(8u * ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
     k_dm_stops_long<<<4096, 64, 0, s>>>(cells, longCells, sums + 1, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     return hipGetLastError();

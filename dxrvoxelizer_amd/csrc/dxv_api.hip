@@ -401,14 +401,14 @@ int build_lists(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels = 0, 
 
 // scratch of the counting pass (records, counts, offsets, block sums, total), kept with the context up to 16 GiB: an allocation
 // costs ~0.1 ms, as much as a pass of the build -- and hundreds of ms for the gigabytes of a 10 M-triangle scene
-struct ListScratchA { DirRecord* rec; uint32_t *counts, *offsets, *sums; unsigned long long* total; size_t bytes; };
+struct ListScratchA { DirRecord* rec; uint32_t *counts, *offsets, *pairs, *sums; unsigned long long* total; size_t bytes; };
 ListScratchA list_scratch_a(uint8_t* base, uint32_t T)
 {
     const size_t n6 = 6 * (size_t)T, nb = (n6 + 1023) / 1024;
-    const size_t offCounts = align256(n6 * sizeof(DirRecord)), offOffsets = offCounts + align256(n6 * 4),
-                 offSums = offOffsets + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
+    const size_t offCounts = align256(n6 * sizeof(DirRecord)), offOffsets = offCounts + align256(n6 * 4), offPairs = offOffsets + align256(n6 * 4),
+                 offSums = offPairs + align256(n6 * 4), offTotal = offSums + align256((nb + 1) * 4);
     return {reinterpret_cast<DirRecord*>(base), reinterpret_cast<uint32_t*>(base + offCounts), reinterpret_cast<uint32_t*>(base + offOffsets),
-            reinterpret_cast<uint32_t*>(base + offSums), reinterpret_cast<unsigned long long*>(base + offTotal), offTotal + 256};
+            reinterpret_cast<uint32_t*>(base + offPairs), reinterpret_cast<uint32_t*>(base + offSums), reinterpret_cast<unsigned long long*>(base + offTotal), offTotal + 256};
 }
 
 // The verdict of a build whose caller did not wait for it: time, and the one thing only the host can act on -- a texel with
@@ -476,7 +476,7 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels,
     unsigned long long total = 0;
     auto recount = [&](uint32_t res) -> int {
         R = res;
-        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
+        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, sa.pairs, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
         (void)hipEventRecord(c->evList[1], stream);
         if ((e = hipMemcpyAsync(&c->pin->listTotal, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -540,7 +540,7 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels,
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratchB + 2 * keyBytes);
     (void)hipEventRecord(c->evList[2], stream);
     c->pin->listLongest = 0;
-    if ((e = dirmap_fill(T, R, rec, counts, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, &c->pin->listLongest, stream)) != hipSuccess)
+    if ((e = dirmap_fill(T, R, rec, counts, sa.pairs, dTotal, offsets, sums, keys, keysTmp, hist, n, c->dListCells, c->dListEntries, &c->pin->listLongest, stream)) != hipSuccess)
         return bail(e, "dirmap_fill");
 
     // the max-mip of the texels' far radii goes with the lists (a launch's work queue is probed against it)
@@ -1115,7 +1115,7 @@ int dxv_refit(dxv_ctx* c)
         spec = c->optListRes ? (uint32_t)c->optListRes : list_resolution(c);     // (the base map: a mesh that is being refitted gets its lists built for one launch)
         const ListScratchA sa = list_scratch_a(c->dListScratchA, c->hdr.numTris);
         DXV_HIP(c, hipEventRecord(c->evList[0], c->stream));
-        DXV_HIP(c, dirmap_count(scene_tripos(c), c->hdr.numTris, spec, sa.rec, sa.counts, sa.total, c->stream));
+        DXV_HIP(c, dirmap_count(scene_tripos(c), c->hdr.numTris, spec, sa.rec, sa.counts, sa.pairs, sa.total, c->stream));
         DXV_HIP(c, hipEventRecord(c->evList[1], c->stream));
         DXV_HIP(c, hipMemcpyAsync(&c->pin->listTotal, sa.total, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     }
