@@ -58,7 +58,7 @@ def main():
             continue
         v.set_option("wide", int(rng.integers(0, 3)))
         v.set_option("refit", int(rng.choice([1, 1, 2, 0])) if T < 30000 else int(rng.choice([1, 2])))   # box merge of the build
-        v.InitFromArrays(vb, ib)
+        (v.InitFromArrays if rng.integers(0, 2) else v.InitDynamic)(vb, ib)      # the mirrors' Init (lists built) or the C-ABI's own rules
         if rng.integers(0, 3) == 0:                       # same vertices again: the refit must reproduce the build's boxes
             v.set_option("deferboxes", int(rng.integers(0, 2)))       # ... at once, or when the first tree walk asks for them
             v.UpdateVertices(np.ascontiguousarray(vb, np.float32))
@@ -74,7 +74,8 @@ def main():
                     "lists": int(rng.integers(0, 3)), "listres": int(rng.choice([0, 0, 16, 64, 512, 2048])),
                     "plists": int(rng.integers(0, 3)), "plistres": int(rng.choice([0, 0, 16, 128, 1024])),
                     "plan": int(rng.integers(0, 3)), "queuewaves": int(rng.choice([0, 0, 8, 64, 1000])),
-                    "dispatch": int(rng.choice([1, 1, 0, 2]))}
+                    "dispatch": int(rng.choice([1, 1, 0, 2])), "planregion": int(rng.choice([0, 0, 6, 7, 8])),
+                    "planheavy": int(rng.choice([0, 0, 0, 3, 65535])), "fuse": int(rng.choice([1, 1, 0])), "queueheads": int(rng.choice([8, 8, 8, 1, 2, 4]))}
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))

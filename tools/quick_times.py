@@ -33,6 +33,8 @@ def main():
         out = {"mesh": mesh, "N": a.grid, "build_ms": round(v.stats()["build_ms"], 3)}
         for lists in ((2, 0) if a.tree else (2,)):
             v.set_option("lists", lists)
+            v.set_option("plan", 1)                        # lists_ms: the kept queue (from the third launch on dealt out by the hardware); fresh_ms: nothing carried
+            v.Voxelize(a.grid, 0)
             v.Voxelize(a.grid, 0)
             ts = []
             for _ in range(a.reps):
@@ -59,7 +61,7 @@ def main():
                     if plan == 2:
                         out["plan_ms"] = round(float(np.median(ps)), 4)
                     out[f"{name}_solid"] = v.CountSolid()
-                v.set_option("plan", 1)
+        v.set_option("plan", 2)
         v.set_option("lists", 2)
         if a.frames > 1:
             import time

@@ -20,7 +20,7 @@ def main():
     vb, ib, _ = make_mesh(mesh)
     vb = np.ascontiguousarray(vb, np.float32)
     v = dxv.Voxelizer(0)
-    v.InitFromArrays(vb, ib)
+    v.InitDynamic(vb, ib)                    # (a mesh that is refitted every frame: LBVH only, the lists are built per frame)
     # the vertices once on the GPU as well (a mesh animated there never crosses PCIe): a plain hipMalloc through ctypes, no torch
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
