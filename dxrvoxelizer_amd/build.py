@@ -16,8 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "csrc", "build")
 LIB = os.path.join(HERE, "libdxv.so")
 
-SOURCES = ["dxv_api.hip", "lbvh.hip", "radix_sort.hip", "traverse.hip", "raycast.hip", "dirmap.hip", "obj_ingest.cpp"]
-HEADERS = ["dxv_device.h", "dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_raycast.h", "dxv_dirmap.h", os.path.join("..", "..", "include", "dxv.h")]
+SOURCES = ["dxv_api.hip", "dxv_lists.hip", "dxv_frames.hip", "dxv_blob.hip", "dxv_debug.hip", "lbvh.hip", "radix_sort.hip", "traverse.hip", "raycast.hip", "dirmap.hip",
+           "obj_ingest.cpp"]
+HEADERS = ["dxv_device.h", "dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_raycast.h", "dxv_dirmap.h", "dxv_ctx.h", "dxv_policy.h", os.path.join("..", "..", "include", "dxv.h")]
 
 # -ffp-contract=off: the arithmetic of the path has a fixed operation order; the only fused
 # operations are the explicit fmaf calls in dxv_math.h (hipcc contracts by default).
@@ -68,7 +69,7 @@ def build(force=False, save_temps=False, verbose=False, ablate=False, defines=()
         return lib
     os.makedirs(objdir, exist_ok=True)
     extra = (["-save-temps=obj"] if save_temps else []) + (["-DDXV_ABLATE"] if ablate else []) + ["-D" + d for d in defines]
-    with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         results = list(ex.map(lambda s: _compile(s, extra, objdir), SOURCES))
     for _, err in results:
         if verbose and err.strip():

@@ -96,7 +96,7 @@ def hostcheck():
     """The product's __host__ __device__ code compiled for the CPU (tests/hostcheck)."""
     src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
     so = os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so")
-    deps = [src] + [os.path.join(ROOT, "dxrvoxelizer_amd", "csrc", h) for h in ("dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_dirmap.h", "dxv_raycast.h")]
+    deps = [src] + [os.path.join(ROOT, "dxrvoxelizer_amd", "csrc", h) for h in ("dxv_math.h", "dxv_trace.h", "dxv_types.h", "dxv_dirmap.h", "dxv_raycast.h", "dxv_policy.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
                                "-mavx2", "-mfma", "-Wno-unknown-pragmas", "-o", so, src])

@@ -907,3 +907,32 @@ __attribute__((visibility("default"))) void hc_render(const uint8_t* grid, uint3
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The host side's decisions (dxrvoxelizer_amd/csrc/dxv_policy.h: pure functions, the same header the library compiles), for
+// tests/test_policy.py: the launch-history rules of the lists and the work queue as a table walked on the CPU.
+// ---------------------------------------------------------------------------------------------
+#include "../../dxrvoxelizer_amd/csrc/dxv_policy.h"
+struct HcListsState { int32_t optLists, optListRes, listOpt, listState; uint32_t listRes, numTris, launchesOfScene, refitted, floorTried; uint64_t listEntries; };
+static ListsState hc_ls(const HcListsState* h)
+{
+    ListsState s{};
+    s.optLists = h->optLists; s.optListRes = h->optListRes; s.listOpt = h->listOpt; s.listState = h->listState; s.listRes = h->listRes;
+    s.numTris = h->numTris; s.launchesOfScene = h->launchesOfScene; s.refitted = h->refitted != 0; s.floorTried = h->floorTried != 0; s.listEntries = h->listEntries;
+    return s;
+}
+extern "C" {
+__attribute__((visibility("default"))) int hc_lists_step(const HcListsState* h, uint64_t voxels, int relaunch) { return (int)lists_step(hc_ls(h), voxels, relaunch != 0); }
+__attribute__((visibility("default"))) int hc_lists_used(const HcListsState* h, int relaunch) { return lists_used(hc_ls(h), relaunch != 0) ? 1 : 0; }
+__attribute__((visibility("default"))) int hc_lists_static_fine(const HcListsState* h, uint32_t floorNow) { return lists_static_scene_takes_fine_map(hc_ls(h), floorNow) ? 1 : 0; }
+__attribute__((visibility("default"))) uint32_t hc_lists_base_map(uint32_t numTris, int optListRes) { return lists_base_map(numTris, optListRes); }
+__attribute__((visibility("default"))) uint32_t hc_lists_recount_on(uint32_t R, uint64_t entries, int oneLaunch, int optListRes, int coarser) { return lists_recount_on(R, entries, oneLaunch != 0, optListRes, coarser != 0); }
+__attribute__((visibility("default"))) int hc_lists_over_the_caps(uint64_t entries, uint32_t numTris) { return lists_over_the_caps(entries, numTris) ? 1 : 0; }
+__attribute__((visibility("default"))) int hc_lists_pay(uint64_t voxels, uint64_t entries, uint32_t R) { return lists_pay_on_first_launch(voxels, entries, R) ? 1 : 0; }
+__attribute__((visibility("default"))) int hc_queue_policy(int optPlan, int optDispatch, int ptrExposed, uint64_t keptSig, uint64_t lensSig, uint32_t queuedBricks, uint64_t sig, uint64_t voxels)
+{
+    QueueState q{};
+    q.optPlan = optPlan; q.optDispatch = optDispatch; q.ptrExposed = ptrExposed != 0; q.keptSig = keptSig; q.lensSig = lensSig; q.queuedBricks = queuedBricks;
+    return (int)queue_policy(q, sig, voxels);
+}
+}
