@@ -590,6 +590,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "queuewaves")) {
         if (value < 0 || value > (1 << 20)) return fail(c, "option queuewaves: %lld not in [0, 2^20]", (long long)value);
         c->optQueueWaves = (int)value;
+    } else if (!strcmp(key, "queuemin")) {
+        if (value < 0 || value > 4096) return fail(c, "option queuemin: %lld not in [0, 4096]", (long long)value);
+        c->optQueueMin = (int)value;
     } else if (!strcmp(key, "queueheads")) {
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, "option queueheads: %lld not in {1,2,4,8}", (long long)value);
         c->optQueueHeads = (int)value;

@@ -157,6 +157,8 @@ struct dxv_ctx {
     int optPlan = 2;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch (opt-in), 2 = on every launch (default: nothing carried)
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
+    int optQueueMin = 12;            // persistent waves: at least this many bricks per wave (surplus waves leave at once: -11 ... -14 % at 256^3,
+                                     // nothing at 512^3; 16 costs a rank's share 13 %: profiles/r05/ab_surplus_waves_leave.jsonl); 0 = every wave stays
     int optQueueHeads = 8;           // heads per queue (persistent waves): 1, 2, 4, 8
     int optPlanRegion = 0;           // log2 of the run of Morton bricks dealt to one queue: 6, 7, 8; 0 = by the partition's size (plan_region_bits)
     int optPlanHeavy = 0;            // list length beyond which a brick starts early; 0 = long for this scene (k_dm_heavy_thresholds), 65535: no brick does

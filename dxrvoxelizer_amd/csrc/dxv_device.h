@@ -100,6 +100,7 @@ struct VoxelizeParams {
     uint32_t planClear;     // 1: k_plan_bricks also clears the grid (and the texel image): no memset in front of it
     uint32_t queueWaves;    // persistent waves to launch; 0 = what the device holds at once
     uint32_t queueHeads;    // heads per queue the persistent waves draw from: 1, 2, 4 or 8
+    uint32_t queueMinBricks; // persistent waves beyond one per this many bricks of an XCD's share leave at once (0: all stay)
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);

@@ -408,7 +408,21 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
     // h = w (mod 8) of queue x -- to h = w (mod W) when fewer than eight waves per XCD were launched, so that no head is without
     // one (which XCD a block really runs on is a matter of speed only).
     const uint32_t nh = p.queueHeads;                                   // heads per queue in use: 1, 2, 4 or 8 (head h hands out the items = h mod nh)
-    const uint32_t x0 = blockIdx.x & 7u, wx = blockIdx.x >> 3, perXcd = gridDim.x >> 3, homes = perXcd < nh ? perXcd : nh;
+    const uint32_t x0 = blockIdx.x & 7u, wx = blockIdx.x >> 3;
+    uint32_t perXcd = gridDim.x >> 3;
+    // A short launch does not want every wave the GPU holds: with fewer than p.queueMinBricks bricks per wave the bricks of a wave
+    // contend with seven times as many neighbours as they need to fill the launch's few rounds, and each wave holds one brick in
+    // reserve at the end (256^3, 60 k bricks: 0.192 ms with 7,168 waves, 0.166 with 5,120: profiles/r05/ab_persistent_waves.jsonl).
+    // The launch cannot know its size on the host; its waves can: the surplus ones leave before they touch the queue.
+    if (p.queueMinBricks) {
+        uint32_t share, heavy;
+        (void)queue_lens(p.queue, share, heavy);
+        uint32_t want = ((share + p.queueMinBricks - 1u) / p.queueMinBricks + 7u) & ~7u;      // (a multiple of 8: every head keeps its home waves)
+        want = want < 64u ? 64u : want;
+        if (want < perXcd) perXcd = want;
+        if (wx >= perXcd) return;
+    }
+    const uint32_t homes = perXcd < nh ? perXcd : nh;
     uint64_t homeMask = 0;
     for (uint32_t h = wx % homes; h < nh; h += homes) homeMask |= 1ull << (8u * x0 + h);
     uint32_t cur = 8u * x0 + wx % homes;
