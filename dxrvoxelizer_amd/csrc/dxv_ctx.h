@@ -157,8 +157,9 @@ struct dxv_ctx {
     int optPlan = 2;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch (opt-in), 2 = on every launch (default: nothing carried)
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
-    int optQueueMin = 12;            // persistent waves: at least this many bricks per wave (surplus waves leave at once: -11 ... -14 % at 256^3,
-                                     // nothing at 512^3; 16 costs a rank's share 13 %: profiles/r05/ab_surplus_waves_leave.jsonl); 0 = every wave stays
+    int optQueueMin = 0;             // persistent waves: at least this many bricks per wave (surplus waves leave at once); 0 (default) = every wave stays.
+                                     // 12: torus-1M / bunny x16 at 256^3 -13 / -11 %, but dragon x9 +11 % at 256^3 and +35 % on a rank's share: not a
+                                     // rule a launch can apply blind (profiles/r05/ab_surplus_waves_leave.jsonl, short_launches_queuemin12.jsonl)
     int optQueueHeads = 8;           // heads per queue (persistent waves): 1, 2, 4, 8
     int optPlanRegion = 0;           // log2 of the run of Morton bricks dealt to one queue: 6, 7, 8; 0 = by the partition's size (plan_region_bits)
     int optPlanHeavy = 0;            // list length beyond which a brick starts early; 0 = long for this scene (k_dm_heavy_thresholds), 65535: no brick does

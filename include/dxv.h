@@ -308,8 +308,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 and a half times the scene's mean at the level of a brick's patch of texels; 65535: no brick does)
  *   fuse   0|1    the queue build clears the grid (1, default) or memsets stand in front of it (0)
  *   queueheads 1|2|4|8  heads per queue the persistent waves draw from (default 8)
- *   queuemin 0..4096  persistent waves beyond one per this many bricks of an XCD's share leave before they touch the queue (default
- *                 12: a short launch is faster with fewer waves -- 256^3 -13 % -- and cannot know its size on the host; 0: all stay)
+ *   queuemin 0..4096  persistent waves beyond one per this many bricks of an XCD's share leave before they touch the queue (0,
+ *                 default: all stay; 12 helps 1 M-triangle meshes at 256^3 by 11 - 13 % and costs thin ones as much: a caller's knob)
  *   events 0|1    bracket every launch with two HIP events for stats.voxelize_ms (default 1); 0 for a caller that times its own
  *                 loop of back-to-back launches (the events cost ~8 us of stream time per launch)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
