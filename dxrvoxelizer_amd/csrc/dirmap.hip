@@ -506,11 +506,12 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     if ((e = hipMemsetAsync(cells, 0, sizeof(DirCell) * 6 * (size_t)R * R, s)) != hipSuccess) return e;
     if (n == 0) return hipGetLastError();
     k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, pairs, total, offsets, R, keys);
-    // sort by (texel, far radius): the bits above the triangle field, in whole 8-bit digits
+    // sort by (texel, far radius): the bits above the triangle field (keys of one texel and radius are emitted in triangle order
+    // and the sort is stable)
     const DirKeyLayout lay = dm_key_layout(R);
-    const int passes = (int)((lay.cellBits + 16u + 7u) / 8u), loBit = 64 - 8 * passes;
+    const int numBits = (int)(lay.cellBits + 16u), loBit = 64 - numBits;
     uint64_t* sorted = keys;
-    if (n > 1 && (e = radix_sort_keys_bits(keys, keysTmp, n, hist, loBit, passes, &sorted, s)) != hipSuccess) return e;
+    if (n > 1 && (e = radix_sort_keys_bits(keys, keysTmp, n, hist, loBit, numBits, &sorted, s)) != hipSuccess) return e;
     k_dm_cells<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, rec, R, cells, entries);
     // the texel words count entries in 16 bits: the caller reads `*longest` (sums[0] is free by now) when it synchronises
     // and keeps the tree walk for a scene with a longer list

@@ -593,6 +593,10 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "queuemin")) {
         if (value < 0 || value > 4096) return fail(c, "option queuemin: %lld not in [0, 4096]", (long long)value);
         c->optQueueMin = (int)value;
+    } else if (!strcmp(key, "sortbits")) {
+        if (value < 0 || value > 63 || ((value & 15) != 0 && ((value & 15) < 8 || (value & 15) > 11)))
+            return fail(c, "option sortbits: %lld not 0 or 8..11 (+16 / +32)", (long long)value);
+        radix_sort_set_plan((int)value);
     } else if (!strcmp(key, "queueheads")) {
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, "option queueheads: %lld not in {1,2,4,8}", (long long)value);
         c->optQueueHeads = (int)value;
@@ -624,7 +628,7 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
         c->optDispatch = (int)value;
     } else if (!strcmp(key, "ablate")) {
 #if defined(DXV_ABLATE)
-        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8 && value != 16 && value != 18) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8,16,18}", (long long)value);
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 6 && value != 8 && value != 16 && value != 18 && value != 32 && value != 64) return fail(c, "option ablate: %lld not in {0,1,2,4,6,8,16,18,32,64}", (long long)value);
         c->optAblate = (int)value;
 #else
         // the timing-only variants of the lists kernel write wrong grids by design: they exist only in the library that

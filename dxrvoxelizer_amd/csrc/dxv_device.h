@@ -8,10 +8,11 @@
 namespace dxv {
 
 // radix_sort.hip
-hipError_t radix_sort_keys(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, hipStream_t s);
-hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int passes, uint64_t** result,
+hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int numBits, uint64_t** result,
                                 hipStream_t s);
+int radix_sort_passes(uint32_t n, int numBits);     // how many times that sort swaps keys and tmp
 uint32_t radix_sort_hist_words(uint32_t n);
+void radix_sort_set_plan(int v);                    // diagnostic (option sortbits)
 
 // lbvh.hip -- device-side build of the scene blob.
 struct BuildBuffers {

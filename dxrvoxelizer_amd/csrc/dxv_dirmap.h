@@ -748,7 +748,8 @@ DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32
 // and tested when some lane's queue is full or every lane has finished scanning -- all lanes with
 // work test together.
 // ABL (timing-only builds, tools/ablate.py; 0 in every shipped path): 8 = stop before the texel lookup, 1 = stop after it,
-// 2 = scan the entries but test no triangle, 16 = the scan's loads wave-uniform (with 2: 18)
+// 2 = scan the entries but test no triangle, 16 = the scan's loads wave-uniform (with 2: 18), 32 / 64 = two / four more loads per scan
+// round with their results unused: what one of the scan's load instructions costs
 // (split at the ray's first step: the work-queue kernel makes that step for all 64 lanes of a brick at once and collects the brick
 // it asked for in advance behind it -- k_voxelize_queue, traverse.hip)
 template <class Stack, int ABL = 0>
@@ -804,6 +805,15 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
             const DirEntry e0 = p[0], e1 = p[1];
             DirEntry e2, e3;
             if (wide && i + 2u <= last) { e2 = p[2]; e3 = p[3]; }       // (lanes whose list ends here issue no access for what they would not look at)
+#if defined(DXV_ABLATE) && defined(__HIP_DEVICE_COMPILE__)
+            // (timing only, 32 / 64: two / four MORE 16-byte loads per round, of the entries the next round loads anyway, results
+            // unused: the slope is what one of the scan's load instructions costs)
+            if (ABL & (32 | 64)) {
+                const DirEntry x0 = p[4], x1 = p[5];
+                asm volatile("" :: "v"(x0.box), "v"(x1.box));
+                if (ABL & 64) { const DirEntry x2 = p[6], x3 = p[7]; asm volatile("" :: "v"(x2.box), "v"(x3.box)); }
+            }
+#endif
             // The list is sorted by far radius and every entry knows (in 63rds of the texel's thickest entry) how far behind
             // its far radius the earliest start of any LATER entry lies: once that point is beyond the closest hit so far,
             // this entry and everything behind it start beyond the hit.  (Surface meshes have short lists and gain

@@ -3,7 +3,7 @@
 //
 //   K1  k_tri_keys     per triangle: gather 3 positions through the index buffer, map to the
 //                      reference's normalised space, padded box, 30-bit Morton key | index
-//   K2  radix sort     radix_sort.hip
+//   K2  radix sort     radix_sort.hip (three passes of 10-bit digits)
 //   K2b k_tri_gather   per Morton slot: write the 48-B position and normal records
 //   K3  k_hierarchy    Karras 2012, one thread per internal node, parent links
 //   K4  k_refit_*      bottom-up box merge; a node stores the boxes of BOTH children
@@ -294,10 +294,16 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
 
     (void)hipEventRecord(ev[0], s);
     const uint32_t keyBlocks = blocks_for(T);
-    k_tri_keys<<<keyBlocks, kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.rootInfo, keyBlocks > 256u ? keyBlocks / 256u : 1u);
+    // the Morton half of the keys, bits [32, 62), is sorted; the index half starts ascending and every pass is stable, so the whole
+    // key ends up ordered.  The keys are written where the sort's passes (three of 10 bits) bring them back to b.keys.
+    const bool odd = T > 1 && (radix_sort_passes(T, 30) & 1);
+    uint64_t* unsorted = odd ? b.keysTmp : b.keys;
+    k_tri_keys<<<keyBlocks, kThreads, 0, s>>>(b.vb, b.ib, T, bnd, unsorted, b.rootInfo, keyBlocks > 256u ? keyBlocks / 256u : 1u);
     (void)hipEventRecord(ev[1], s);
     if (T > 1) {
-        if ((e = radix_sort_keys(b.keys, b.keysTmp, T, b.hist, s)) != hipSuccess) return e;
+        uint64_t* sorted = nullptr;
+        if ((e = radix_sort_keys_bits(unsorted, odd ? b.keys : b.keysTmp, T, b.hist, 32, 30, &sorted, s)) != hipSuccess) return e;
+        if (sorted != b.keys) return hipErrorUnknown;
     }
     (void)hipEventRecord(ev[2], s);
     k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo);

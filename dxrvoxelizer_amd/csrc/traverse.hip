@@ -1232,6 +1232,8 @@ static hipError_t launch_shape(const VoxelizeParams& pin, hipStream_t s)
                 case 8: k_voxelize<B, 16, 0, false, 4, 8><<<g, b, 0, s>>>(p); return hipGetLastError();
                 case 16: k_voxelize<B, 16, 0, false, 4, 16><<<g, b, 0, s>>>(p); return hipGetLastError();
                 case 18: k_voxelize<B, 16, 0, false, 4, 18><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 32: k_voxelize<B, 16, 0, false, 4, 32><<<g, b, 0, s>>>(p); return hipGetLastError();
+                case 64: k_voxelize<B, 16, 0, false, 4, 64><<<g, b, 0, s>>>(p); return hipGetLastError();
                 default: return hipErrorInvalidValue;
                 }
             }

@@ -310,6 +310,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   queueheads 1|2|4|8  heads per queue the persistent waves draw from (default 8)
  *   queuemin 0..4096  persistent waves beyond one per this many bricks of an XCD's share leave before they touch the queue (0,
  *                 default: all stay; 12 helps 1 M-triangle meshes at 256^3 by 11 - 13 % and costs thin ones as much: a caller's knob)
+ *   sortbits 0|8..11 (+16, +32)  diagnostic, process-wide: widest digit of the builds' radix sort (0, default: 10 or 11 bits -- three
+ *                 passes for the LBVH's keys, four for the lists'); +16 / +32: tiles of 4 / 16 waves whatever the size.  Same results.
  *   events 0|1    bracket every launch with two HIP events for stats.voxelize_ms (default 1); 0 for a caller that times its own
  *                 loop of back-to-back launches (the events cost ~8 us of stream time per launch)
  *   skipempty 0|1 dxv_render: skip the samples of empty 8^3 bricks (default 1; same image)
