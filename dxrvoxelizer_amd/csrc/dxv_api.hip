@@ -74,6 +74,59 @@ int alloc_scratch(dxv_ctx* c, uint32_t T)
     return 0;
 }
 
+// dxv_set_mesh's look at the caller's arrays: largest index, position bounds, whether every position is finite.  Chunks of the
+// arrays go to up to eight threads; the chunks' results are merged in order with the strict comparisons of a sequential sweep, so
+// the bounds are the sequential sweep's bit for bit (signs of zero included).
+struct MeshScan { uint32_t maxIndex; float mn[3], mx[3]; bool finite; };
+static void scan_mesh_range(const float* vb, size_t v0, size_t v1, const uint32_t* ib, size_t i0, size_t i1, MeshScan* out)
+{
+    uint32_t m = 0;
+    for (size_t i = i0; i < i1; ++i) m = ib[i] > m ? ib[i] : m;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, probe = 0.0f;
+    for (size_t v = v0; v < v1; ++v) {
+        const float* p = vb + 6 * v;
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = p[a] < mn[a] ? p[a] : mn[a];
+            mx[a] = p[a] > mx[a] ? p[a] : mx[a];
+            probe += p[a] - p[a];                 // 0 for every finite value, NaN for NaN and +-Inf
+        }
+    }
+    out->maxIndex = m;
+    for (int a = 0; a < 3; ++a) { out->mn[a] = mn[a]; out->mx[a] = mx[a]; }
+    out->finite = probe == 0.0f;
+}
+static MeshScan scan_mesh(const float* vb, uint32_t V, const uint32_t* ib, uint32_t T)
+{
+    const size_t nIdx = 3 * (size_t)T;
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = nIdx + V < 200000u ? 1u : hw >= 8u ? 8u : hw ? hw : 1u;
+    if (nt > V) nt = 1;
+    MeshScan part[8];
+    std::thread th[8];
+    unsigned started = 1;
+    auto lo = [&](size_t n, unsigned k) { return n * k / nt; };
+    for (unsigned k = 1; k < nt; ++k) {
+        try { th[k] = std::thread(scan_mesh_range, vb, lo(V, k), lo(V, k + 1), ib, lo(nIdx, k), lo(nIdx, k + 1), &part[k]); ++started; }
+        catch (...) { break; }                 // (no thread to be had: the caller's thread does the rest)
+    }
+    if (started < nt) {                        // what the threads that did not start would have covered
+        scan_mesh_range(vb, lo(V, started), V, ib, lo(nIdx, started), nIdx, &part[started]);
+        for (unsigned k = started + 1; k < nt; ++k) { part[k] = part[started]; }
+    }
+    scan_mesh_range(vb, 0, lo(V, 1), ib, 0, lo(nIdx, 1), &part[0]);
+    for (unsigned k = 1; k < started; ++k) th[k].join();
+    MeshScan r = part[0];
+    for (unsigned k = 1; k < nt; ++k) {
+        r.maxIndex = part[k].maxIndex > r.maxIndex ? part[k].maxIndex : r.maxIndex;
+        for (int a = 0; a < 3; ++a) {
+            if (part[k].mn[a] < r.mn[a]) r.mn[a] = part[k].mn[a];
+            if (part[k].mx[a] > r.mx[a]) r.mx[a] = part[k].mx[a];
+        }
+        r.finite = r.finite && part[k].finite;
+    }
+    return r;
+}
+
 } // namespace dxvhost
 
 extern "C" {
@@ -185,20 +238,21 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     if (!c) return 1;
     if (!vb || !ib || !V || !T) return fail(c, "dxv_set_mesh: empty mesh (V=%u, T=%u)", V, T);
     if (T > 0x7fffffffu / 2) return fail(c, "dxv_set_mesh: too many triangles (%u)", T);
-    for (size_t i = 0; i < 3 * (size_t)T; ++i)
-        if (ib[i] >= V) return fail(c, "dxv_set_mesh: index %u at position %zu out of range (V=%u)", ib[i], i, V);
-    // bound: AABB over every VB position (XUSGObjLoader.cpp:386-416), centre and half max extent
-    // (Content/Voxelizer.cpp:52-57)
-    float mn[3] = {vb[0], vb[1], vb[2]}, mx[3] = {vb[0], vb[1], vb[2]};
-    for (uint32_t i = 0; i < V; ++i) {
-        const float* p = vb + 6 * (size_t)i;
-        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]))   // (a NaN would slip through both comparisons below)
-            return fail(c, "dxv_set_mesh: vertex %u has a non-finite position (%g, %g, %g)", i, (double)p[0], (double)p[1], (double)p[2]);
-        for (int a = 0; a < 3; ++a) {
-            if (p[a] < mn[a]) mn[a] = p[a];
-            else if (p[a] > mx[a]) mx[a] = p[a];
+    // One sweep over the caller's arrays, in up to eight threads: the largest index, and the AABB over every VB position
+    // (XUSGObjLoader.cpp:386-416) -- branch-free, so the compiler vectorises the index half; the slow loops that name the
+    // offending element run only when the sweep has found one.  Centre and half max extent: Content/Voxelizer.cpp:52-57.
+    const MeshScan scan = scan_mesh(vb, V, ib, T);
+    if (scan.maxIndex >= V)
+        for (size_t i = 0; i < 3 * (size_t)T; ++i)
+            if (ib[i] >= V) return fail(c, "dxv_set_mesh: index %u at position %zu out of range (V=%u)", ib[i], i, V);
+    if (!scan.finite)
+        for (uint32_t i = 0; i < V; ++i) {
+            const float* p = vb + 6 * (size_t)i;
+            if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2]))
+                return fail(c, "dxv_set_mesh: vertex %u has a non-finite position (%g, %g, %g)", i, (double)p[0], (double)p[1], (double)p[2]);
         }
-    }
+    const float* mn = scan.mn;
+    const float* mx = scan.mx;
     const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
     c->bound[0] = (mx[0] + mn[0]) / 2.0f;
     c->bound[1] = (mx[1] + mn[1]) / 2.0f;
@@ -213,11 +267,19 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     if (sync_frames(c)) return 1;
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->vbCopyQueued = false;
-    (void)hipFree(c->dVb); (void)hipFree(c->dIb);
-    c->dVb = nullptr; c->dIb = nullptr;
     c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->refitted = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
-    DXV_HIP(c, hipMalloc(&c->dVb, sizeof(float) * 6 * (size_t)V));
-    DXV_HIP(c, hipMalloc(&c->dIb, sizeof(uint32_t) * 3 * (size_t)T));
+    // (a mesh of the size of the last one moves into its buffers: two frees and two allocations less on the way to the first launch)
+    const size_t vbBytes = sizeof(float) * 6 * (size_t)V, ibBytes = sizeof(uint32_t) * 3 * (size_t)T;
+    if (!c->dVb || c->vbCap < vbBytes || c->vbCap > 2 * vbBytes) {
+        (void)hipFree(c->dVb); c->dVb = nullptr; c->vbCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dVb, vbBytes));
+        c->vbCap = vbBytes;
+    }
+    if (!c->dIb || c->ibCap < ibBytes || c->ibCap > 2 * ibBytes) {
+        (void)hipFree(c->dIb); c->dIb = nullptr; c->ibCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dIb, ibBytes));
+        c->ibCap = ibBytes;
+    }
     DXV_HIP(c, hipEventRecord(c->ev[8], c->stream));
     DXV_HIP(c, hipMemcpyAsync(c->dVb, vb, sizeof(float) * 6 * (size_t)V, hipMemcpyHostToDevice, c->stream));
     DXV_HIP(c, hipMemcpyAsync(c->dIb, ib, sizeof(uint32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, c->stream));

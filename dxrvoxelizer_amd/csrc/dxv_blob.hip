@@ -118,7 +118,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     // triangle count over the old, smaller buffers.
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->dVb); (void)hipFree(c->dIb);
-    c->dVb = nullptr; c->dIb = nullptr; c->haveMesh = false; c->haveHierarchy = false;
+    c->dVb = nullptr; c->dIb = nullptr; c->vbCap = c->ibCap = 0; c->haveMesh = false; c->haveHierarchy = false;
     free_scratch(c);
     if (alloc_scene(c, h.numTris, h.numVerts, h.hasWide != 0)) return 1;
     DXV_HIP(c, hipMemcpyAsync(c->dScene, src, want.totalBytes, hipMemcpyDeviceToDevice, c->stream));

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace dxvhost {
@@ -40,6 +41,7 @@ struct dxv_ctx {
     // mesh (caller's layout)
     float* dVb = nullptr;
     uint32_t* dIb = nullptr;
+    size_t vbCap = 0, ibCap = 0;     // bytes allocated behind them (dxv_set_mesh moves a mesh of about the same size into the same buffers)
     uint32_t T = 0, V = 0;
     float bound[4] = {0, 0, 0, 0};
     bool haveMesh = false;

@@ -40,6 +40,47 @@ def sha(a):
 
 
 # ---------------------------------------------------------------------------------------------
+# dxv_set_mesh: the host's look at the caller's arrays (in threads from 200 k elements up)
+# ---------------------------------------------------------------------------------------------
+def test_set_mesh_scan_in_threads_gives_the_sequential_bound_and_names_the_offender(dxv, orc):
+    """A mesh large enough for the threaded sweep: the bound is the oracle's (a sequential sweep) bit for bit -- signed zeros at
+    chunk borders included; an index out of range and a non-finite position are reported with their own position, wherever in
+    the arrays they sit; a failed call leaves the context's earlier mesh alone."""
+    from dxrvoxelizer_amd import meshes
+    vb, ib = meshes.torus(400, 200)                                           # 160,000 triangles, 80,000 vertices
+    vb = vb.copy()
+    vb[::7919, 0] *= 0.0                                                       # zeros of either sign spread over the chunks
+    vb[3::7919, 2] = -0.0
+    v = dxv.Voxelizer(0)
+    v.InitDynamic(vb, ib)
+    s = orc.Scene(vb, ib)
+    assert np.array_equal(np.asarray(v.stats()["bound"], np.float32).view(np.uint32), s.bound.view(np.uint32))
+    v.Voxelize(64)
+    want = v.Grid().copy()
+    for pos in (0, len(ib) // 2 + 1, len(ib) - 1):
+        bad = ib.copy()
+        bad[pos] = len(vb) + 5
+        with pytest.raises(dxv.DxvError, match=f"index {len(vb) + 5} at position {pos} out of range"):
+            v.InitDynamic(vb, bad)
+    for vert in (0, len(vb) // 3, len(vb) - 1):
+        for val in (np.nan, np.inf, -np.inf):
+            bad = vb.copy()
+            bad[vert, 1] = val
+            with pytest.raises(dxv.DxvError, match=f"vertex {vert} has a non-finite position"):
+                v.InitDynamic(bad, ib)
+    v.Voxelize(64)                                                             # the earlier mesh is still there
+    assert np.array_equal(v.Grid(), want)
+    small = meshes.torus(40, 20)                                               # a much smaller mesh: new buffers, not the old ones
+    v.InitDynamic(*small)
+    v.Voxelize(64)
+    assert np.array_equal(v.Grid(), orc.Scene(*small).voxelize(64))
+    v.InitDynamic(vb, ib)
+    v.Voxelize(64)
+    assert np.array_equal(v.Grid(), want)
+    v.close()
+
+
+# ---------------------------------------------------------------------------------------------
 # build stages
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
