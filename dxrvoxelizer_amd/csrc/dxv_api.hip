@@ -44,8 +44,10 @@ int alloc_scene(dxv_ctx* c, uint32_t T, uint32_t V, bool wide)
 {
     SceneHeader h;
     layout_scene(h, T, V, wide);
-    if (c->dScene && c->sceneBytes != h.totalBytes) { (void)hipFree(c->dScene); c->dScene = nullptr; }
-    if (!c->dScene) DXV_HIP(c, hipMalloc(&c->dScene, h.totalBytes));
+    // (a scene of up to the size of the last one, and not under half of it, moves into its allocation: a free and an allocation
+    // of a hundred megabytes less on the way to the first launch)
+    if (c->dScene && (h.totalBytes > c->sceneCap || c->sceneCap > 2 * h.totalBytes)) { (void)hipFree(c->dScene); c->dScene = nullptr; c->sceneCap = 0; }
+    if (!c->dScene) { DXV_HIP(c, hipMalloc(&c->dScene, h.totalBytes)); c->sceneCap = h.totalBytes; }
     c->sceneBytes = h.totalBytes;
     c->hdr = h;
     return 0;
@@ -54,15 +56,21 @@ int alloc_scene(dxv_ctx* c, uint32_t T, uint32_t V, bool wide)
 void free_scratch(dxv_ctx* c)
 {
     (void)hipFree(c->dKeys); (void)hipFree(c->dKeysTmp); (void)hipFree(c->dHist); (void)hipFree(c->dParents);
-    (void)hipFree(c->dPyramid); c->dPyramid = nullptr;
+    (void)hipFree(c->dPyramid); c->dPyramid = nullptr; c->pyramidSlots = 0;
     (void)hipFree(c->dFlags); (void)hipFree(c->dFlags2);
     c->dKeys = c->dKeysTmp = nullptr; c->dHist = c->dParents = c->dFlags = c->dFlags2 = nullptr;
-    c->scratchT = 0;
+    c->scratchT = 0; c->scratchCap = 0; c->histCapWords = 0;
 }
 
 int alloc_scratch(dxv_ctx* c, uint32_t T)
 {
     if (c->scratchT == T) return 0;
+    // (scratch made for a mesh of up to twice the triangles serves this one too)
+    if (c->scratchCap >= T && c->scratchCap / 2 <= T && radix_sort_hist_words(T) <= c->histCapWords) {
+        if (c->dPyramid && c->pyramidSlots < pyramid_slots(T)) { (void)hipFree(c->dPyramid); c->dPyramid = nullptr; c->pyramidSlots = 0; }   // (alloc_pyramid makes the larger one)
+        c->scratchT = T;
+        return 0;
+    }
     free_scratch(c);
     DXV_HIP(c, hipMalloc(&c->dKeys, sizeof(uint64_t) * (size_t)T));
     DXV_HIP(c, hipMalloc(&c->dKeysTmp, sizeof(uint64_t) * (size_t)T));
@@ -70,7 +78,7 @@ int alloc_scratch(dxv_ctx* c, uint32_t T)
     DXV_HIP(c, hipMalloc(&c->dParents, sizeof(uint32_t) * (2 * (size_t)T)));
     DXV_HIP(c, hipMalloc(&c->dFlags, sizeof(uint32_t) * (size_t)T));
     DXV_HIP(c, hipMalloc(&c->dFlags2, sizeof(uint32_t) * (size_t)T));
-    c->scratchT = T;
+    c->scratchT = T; c->scratchCap = T; c->histCapWords = radix_sort_hist_words(T);
     return 0;
 }
 
@@ -322,8 +330,10 @@ int ensure_nodes(dxv_ctx* c, hipStream_t stream)
 // min/max pyramid of the box merge (refit = 1): 24 B box + 4 B deepest leaf per slot
 int alloc_pyramid(dxv_ctx* c)
 {
-    if (!c->dPyramid && c->optRefit == 1 && c->T > 1)      // refit=2 keeps the level sweeps, refit=0 the atomic pass
+    if (!c->dPyramid && c->optRefit == 1 && c->T > 1) {    // refit=2 keeps the level sweeps, refit=0 the atomic pass
         DXV_HIP(c, hipMalloc(&c->dPyramid, 28 * (size_t)pyramid_slots(c->T)));
+        c->pyramidSlots = pyramid_slots(c->T);
+    }
     return 0;
 }
 

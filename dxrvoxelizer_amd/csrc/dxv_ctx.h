@@ -48,7 +48,7 @@ struct dxv_ctx {
 
     // scene blob
     uint8_t* dScene = nullptr;
-    size_t sceneBytes = 0;
+    size_t sceneBytes = 0, sceneCap = 0;   // bytes of the scene / of the allocation behind it
     SceneHeader hdr{};
     bool haveScene = false;
     bool haveHierarchy = false;      // dxv_build ran for the resident mesh: keys, links and parent words are in place for dxv_refit
@@ -63,7 +63,10 @@ struct dxv_ctx {
     uint32_t* dFlags = nullptr;
     uint32_t* dFlags2 = nullptr;
     uint32_t* dRootInfo = nullptr;
-    uint32_t scratchT = 0;
+    uint32_t scratchT = 0;           // triangles the build scratch is in use for (0: none)
+    uint32_t scratchCap = 0;         // ... and the number it was allocated for (alloc_scratch keeps it for meshes of half to all of that)
+    size_t histCapWords = 0;
+    uint32_t pyramidSlots = 0;       // slots dPyramid holds
 
     // outputs: FrameCount sets of grid / texel image / status words / redo list / stream, the way the reference's
     // Voxelizer owns FrameCount grids (Content/Voxelizer.h:24, :110); one scene and one set of lists serve them all

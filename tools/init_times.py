@@ -34,4 +34,30 @@ for rep in range(reps):
     print(json.dumps({"mesh": mesh, "N": N, "set_mesh_wall_ms": round(ms[0], 3), "build_wall_ms": round(ms[1], 3), "lists_wall_ms": round(ms[2], 3),
                       "first_voxelize_wall_ms": round(ms[3], 3), "init_wall_ms": round(sum(ms[:3]), 3),
                       "gpu_ms": {"upload": round(st["upload_ms"], 3), "lbvh": round(st["build_ms"], 3), "lists": round(st["list_ms"], 3), "voxelize": round(st["voxelize_ms"], 3)}}))
+# ... and through the Python mirror, as bench.py's config.first_voxelize_after_init does it
+for rep in range(3):
+    t0 = time.perf_counter()
+    v.InitFromArrays(vb, ib)
+    t1 = time.perf_counter()
+    v.Voxelize(N)
+    t2 = time.perf_counter()
+    print(json.dumps({"mesh": mesh, "N": N, "InitFromArrays_wall_ms": round((t1 - t0) * 1e3, 3), "first_Voxelize_wall_ms": round((t2 - t1) * 1e3, 3)}))
+# the same after the context has used its other frames and kept queues (what bench.py has done by then)
+v.set_option("plan", 1)
+for f in (0, 1, 2):
+    v.Voxelize(N, frameIndex=f)
+    v.Voxelize(N, frameIndex=f)
+v.set_option("plan", 2)
+v.SetFrame(0)
+from dxrvoxelizer_amd import meshes  # noqa: E402
+other = meshes.torus(900, 500)                  # 900,000 triangles: another mesh of about the size in between, as in bench.py
+for rep in range(3):
+    v.InitFromArrays(*other)
+    v.Voxelize(N)
+    t0 = time.perf_counter()
+    v.InitFromArrays(vb, ib)
+    t1 = time.perf_counter()
+    v.Voxelize(N)
+    t2 = time.perf_counter()
+    print(json.dumps({"mesh": mesh, "N": N, "after": "three frames used, another mesh of 900,000 triangles resident", "InitFromArrays_wall_ms": round((t1 - t0) * 1e3, 3), "first_Voxelize_wall_ms": round((t2 - t1) * 1e3, 3)}))
 v.close()
