@@ -5,7 +5,7 @@
 //                      reference's normalised space, padded box, 30-bit Morton key | index
 //   K2  radix sort     radix_sort.hip (three passes of 10-bit digits)
 //   K2b k_tri_gather   per Morton slot: write the 48-B position and normal records
-//   K3  k_hierarchy    Karras 2012, one thread per internal node, parent links
+//   K3  hierarchy      Karras 2012, one thread per internal node, parent links (k_gather_and_hierarchy: K2b and K3 share a launch)
 //   K4  k_refit_*      bottom-up box merge; a node stores the boxes of BOTH children
 //   K5  32-B traversal copy of every node (outward-rounded half-float boxes): written by k_refit_ranges from the registers
 //       that hold the exact boxes (k_compress_nodes for the sweep / atomic variants of K4)
@@ -66,12 +66,11 @@ __global__ __launch_bounds__(kThreads) void k_tri_keys(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
-                                                         uint32_t T, Bound4 bnd, const uint64_t* __restrict__ keys,
-                                                         TriPos* __restrict__ triPos, TriNrm* __restrict__ triNrm,
-                                                         uint32_t* __restrict__ rootInfo)
+__device__ __forceinline__ void tri_gather(uint32_t i, const float* __restrict__ vb, const uint32_t* __restrict__ ib,
+                                           uint32_t T, const Bound4& bnd, const uint64_t* __restrict__ keys,
+                                           TriPos* __restrict__ triPos, TriNrm* __restrict__ triNrm,
+                                           uint32_t* __restrict__ rootInfo)
 {
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T) return;
     const uint32_t k = (uint32_t)(keys[i] & 0xffffffffull);
     F4 a, b, c;
@@ -95,23 +94,52 @@ __global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict
     tp.v1.w = __builtin_bit_cast(float, normal_class(a, b, c, tn.n0, tn.n1, tn.n2) << kClassShift);   // spare word of the record
     triPos[i] = tp;
 }
+__global__ __launch_bounds__(kThreads) void k_tri_gather(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
+                                                         uint32_t T, Bound4 bnd, const uint64_t* __restrict__ keys,
+                                                         TriPos* __restrict__ triPos, TriNrm* __restrict__ triNrm,
+                                                         uint32_t* __restrict__ rootInfo)
+{
+    tri_gather(blockIdx.x * kThreads + threadIdx.x, vb, ib, T, bnd, keys, triPos, triNrm, rootInfo);
+}
 
 // parents[0 .. T-2]: internal nodes, parents[T-1 .. 2T-2]: leaves; word = (parent << 1) | side.
-__global__ __launch_bounds__(kThreads) void k_hierarchy(const uint64_t* __restrict__ keys, uint32_t T,
-                                                        Node* __restrict__ nodes, uint32_t* __restrict__ parents,
-                                                        uint32_t* __restrict__ rangeEnd)
+// splits != NULL (a build whose boxes come from the pyramid): the node's split position goes there -- 4 bytes from which
+// k_refit_ranges, which knows the node's range, makes both links -- and the 64-byte node is not touched here at all: it is written
+// once, whole, by k_refit_ranges, instead of 8 bytes now and the rest later with the line read back in between.
+__device__ __forceinline__ void hierarchy_node(uint32_t i, const uint64_t* __restrict__ keys, uint32_t T,
+                                               Node* __restrict__ nodes, uint32_t* __restrict__ parents,
+                                               uint32_t* __restrict__ rangeEnd, uint32_t* __restrict__ splits)
 {
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T - 1) return;
     int32_t l, r;
     uint32_t other;
     karras_node(keys, (int64_t)T, (int64_t)i, l, r, other);
-    nodes[i].c0 = l;
-    nodes[i].c1 = r;
+    if (splits) splits[i] = l >= 0 ? (uint32_t)l : (uint32_t)~l;
+    else { nodes[i].c0 = l; nodes[i].c1 = r; }
     rangeEnd[i] = other;              // node i covers the leaves between i and rangeEnd[i] (pyramid refit)
     parents[l >= 0 ? (uint32_t)l : (T - 1) + (uint32_t)~l] = (i << 1);
     parents[r >= 0 ? (uint32_t)r : (T - 1) + (uint32_t)~r] = (i << 1) | 1u;
     if (i == 0) parents[0] = 0xffffffffu;
+}
+__global__ __launch_bounds__(kThreads) void k_hierarchy(const uint64_t* __restrict__ keys, uint32_t T,
+                                                        Node* __restrict__ nodes, uint32_t* __restrict__ parents,
+                                                        uint32_t* __restrict__ rangeEnd, uint32_t* __restrict__ splits)
+{
+    hierarchy_node(blockIdx.x * kThreads + threadIdx.x, keys, T, nodes, parents, rangeEnd, splits);
+}
+// K2b and K3 in one launch: both read the sorted keys and nothing of each other, each is a chain of dependent gathers (index ->
+// vertices; key -> key -> key) that leaves the memory system mostly waiting -- even workgroups gather triangle records, odd ones
+// make hierarchy nodes, and the two chains fill each other's gaps (37.8 + 42.1 us as two launches at 1 M triangles).
+__global__ __launch_bounds__(kThreads) void k_gather_and_hierarchy(const float* __restrict__ vb, const uint32_t* __restrict__ ib,
+                                                                   uint32_t T, Bound4 bnd, const uint64_t* __restrict__ keys,
+                                                                   TriPos* __restrict__ triPos, TriNrm* __restrict__ triNrm,
+                                                                   uint32_t* __restrict__ rootInfo, Node* __restrict__ nodes,
+                                                                   uint32_t* __restrict__ parents, uint32_t* __restrict__ rangeEnd,
+                                                                   uint32_t* __restrict__ splits)
+{
+    const uint32_t i = (blockIdx.x >> 1) * kThreads + threadIdx.x;
+    if (blockIdx.x & 1u) hierarchy_node(i, keys, T, nodes, parents, rangeEnd, splits);
+    else tri_gather(i, vb, ib, T, bnd, keys, triPos, triNrm, rootInfo);
 }
 
 __device__ __forceinline__ void store_child(Node* node, uint32_t side, const float lo[3], const float hi[3], uint32_t h)
@@ -288,8 +316,12 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     for (int a = 0; a < 4; ++a) bnd.c[a] = b.bound[a];
     const uint32_t numNodes = T > 1 ? T - 1 : 1;
     hipError_t e;
-    // poison the nodes (all-ones = NaN boxes): a box that was never merged cannot pass a slab test
-    if ((e = hipMemsetAsync(b.nodes, 0xff, sizeof(Node) * (size_t)numNodes, s)) != hipSuccess) return e;
+    // boxes from the min/max pyramid: every node is written once and whole by k_refit_ranges, links included (made from the split
+    // positions k_hierarchy leaves in b.flags -- the arrival counters of the other box merges, free here)
+    const bool pyramid = b.pyramid && refitMode == 1 && T > 1;
+    uint32_t* splits = pyramid ? b.flags : nullptr;
+    // the other merges fill the nodes in piecemeal: poison them first (all-ones = NaN boxes: a box that was never merged cannot pass a slab test)
+    if (!pyramid && (e = hipMemsetAsync(b.nodes, 0xff, sizeof(Node) * (size_t)numNodes, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(b.rootInfo, 0, 16 * sizeof(uint32_t), s)) != hipSuccess) return e;
 
     (void)hipEventRecord(ev[0], s);
@@ -306,10 +338,16 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
         if (sorted != b.keys) return hipErrorUnknown;
     }
     (void)hipEventRecord(ev[2], s);
-    k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo);
-    if (T > 1) k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents, b.flags2);
+    // (one launch for both up to 2 M triangles: -9 us at 1 M; at 10 M the two are bound by bytes, not by latency, and get in each
+    // other's way: 1.34 ms together against 0.79 + 0.36 apart)
+    if (T > 1 && T <= (2u << 20))
+        k_gather_and_hierarchy<<<2u * blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo, b.nodes, b.parents, b.flags2, splits);
+    else {
+        k_tri_gather<<<blocks_for(T), kThreads, 0, s>>>(b.vb, b.ib, T, bnd, b.keys, b.triPos, b.triNrm, b.rootInfo);
+        if (T > 1) k_hierarchy<<<blocks_for(T - 1), kThreads, 0, s>>>(b.keys, T, b.nodes, b.parents, b.flags2, splits);
+    }
     (void)hipEventRecord(ev[3], s);
-    if (b.pyramid && refitMode == 1 && T > 1) e = refit_pyramid(b, true, s);
+    if (pyramid) e = refit_pyramid(b, true, s);
     else e = refit_stage(b, refitMode, s);
     if (e != hipSuccess) return e;
     (void)hipEventRecord(ev[4], s);
@@ -442,29 +480,50 @@ __global__ __launch_bounds__(kThreads) void k_refit_ranges(const TriPos* __restr
                                                            const Box6* __restrict__ pyr, const uint32_t* __restrict__ rangeEnd,
                                                            Node* __restrict__ nodes, const uint32_t* __restrict__ depthLeaf,
                                                            const uint32_t* __restrict__ depthNode, const uint32_t* __restrict__ pyrD,
-                                                           Node32* __restrict__ nodes32)
+                                                           Node32* __restrict__ nodes32, uint32_t* __restrict__ rootInfo, uint32_t knownHeight,
+                                                           const uint32_t* __restrict__ splits)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= T - 1) return;
     const uint32_t j = rangeEnd[i], lo = i < j ? i : j, hi = i < j ? j : i;
-    const int32_t c0 = nodes[i].c0;
-    const uint32_t gamma = c0 >= 0 ? (uint32_t)c0 : (uint32_t)~c0;
+    // the build (splits): both links from the split position and the range (karras_node's last lines); a refit: the node's own
+    int32_t c0, c1;
+    uint32_t gamma;
+    if (splits) {
+        gamma = splits[i];
+        c0 = lo == gamma ? ~(int32_t)gamma : (int32_t)gamma;
+        c1 = hi == gamma + 1u ? ~(int32_t)(gamma + 1u) : (int32_t)(gamma + 1u);
+    } else {
+        c0 = nodes[i].c0; c1 = nodes[i].c1;
+        gamma = c0 >= 0 ? (uint32_t)c0 : (uint32_t)~c0;
+    }
     uint32_t deep0, deep1;
     const Box6 b0 = range_box<DEPTH>(triPos, T, P, pyr, lo, gamma, depthLeaf, pyrD, deep0);
     const Box6 b1 = range_box<DEPTH>(triPos, T, P, pyr, gamma + 1u, hi, depthLeaf, pyrD, deep1);
-    float* w = reinterpret_cast<float*>(&nodes[i]);      // words 0..5: child 0 box, 6..11: child 1 box; links stay
+    float* w = reinterpret_cast<float*>(&nodes[i]);      // words 0..5: child 0 box, 6..11: child 1 box; a refit's links and heights stay
     w[0] = b0.lo[0]; w[1] = b0.lo[1]; w[2] = b0.lo[2]; w[3] = b0.hi[0]; w[4] = b0.hi[1]; w[5] = b0.hi[2];
     w[6] = b1.lo[0]; w[7] = b1.lo[1]; w[8] = b1.lo[2]; w[9] = b1.hi[0]; w[10] = b1.hi[1]; w[11] = b1.hi[2];
+    if (splits) { nodes[i].c0 = c0; nodes[i].c1 = c1; }
+    uint32_t h0 = 0, h1 = 0;
     if (DEPTH) {                                         // a child sits one level below node i; a leaf child has height 0
         const uint32_t below = depthNode[i] + 1u;
-        nodes[i].h0 = deep0 - below;
-        nodes[i].h1 = deep1 - below;
+        nodes[i].h0 = h0 = deep0 - below;
+        nodes[i].h1 = h1 = deep1 - below;
+    }
+    if (i == 0u && rootInfo) {                           // rootInfo (k_root_info's words) from the root's own thread: a launch less
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            rootInfo[a] = __builtin_bit_cast(uint32_t, min_(b0.lo[a], b1.lo[a]));
+            rootInfo[3 + a] = __builtin_bit_cast(uint32_t, max_(b0.hi[a], b1.hi[a]));
+        }
+        rootInfo[6] = DEPTH ? (h0 > h1 ? h0 : h1) + 1u : knownHeight;
+        rootInfo[7] = 1u;
     }
     if (nodes32) {
         Node n;                                          // (compress_node reads boxes and links only)
         n.lo0x = b0.lo[0]; n.lo0y = b0.lo[1]; n.lo0z = b0.lo[2]; n.hi0x = b0.hi[0]; n.hi0y = b0.hi[1]; n.hi0z = b0.hi[2];
         n.lo1x = b1.lo[0]; n.lo1y = b1.lo[1]; n.lo1z = b1.lo[2]; n.hi1x = b1.hi[0]; n.hi1y = b1.hi[1]; n.hi1z = b1.hi[2];
-        n.c0 = c0; n.c1 = nodes[i].c1; n.h0 = n.h1 = 0;
+        n.c0 = c0; n.c1 = c1; n.h0 = n.h1 = 0;
         nodes32[i] = compress_node(n);
     }
 }
@@ -537,7 +596,7 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
         k_depths<<<blocks_for(T), kThreads, 0, s>>>(b.parents, T, depthLeaf, depthNode);
         k_pyramid_low<true><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, depthLeaf, pyrD);
         if (P > kPyrLeaves) k_pyramid_high<true><<<1, 1024, 0, s>>>(P, pyr, pyrD);
-        k_refit_ranges<true><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, depthLeaf, depthNode, pyrD, b.nodes32);
+        k_refit_ranges<true><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, depthLeaf, depthNode, pyrD, b.nodes32, b.rootInfo, 0u, b.flags);
     } else {
         k_pyramid_low<false><<<P / kPyrLeaves, kThreads, 0, s>>>(b.triPos, T, P, pyr, nullptr, nullptr);
         if (P > kPyrLeaves) k_pyramid_high<false><<<1, 1024, 0, s>>>(P, pyr, nullptr);
@@ -545,11 +604,14 @@ static hipError_t refit_pyramid(const BuildBuffers& b, bool withHeights, hipStre
             k_root_info_pyramid<<<1, 1, 0, s>>>(pyr, knownHeight, b.rootInfo);
             return hipGetLastError();
         }
-        k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr, b.nodes32);
+        // (a refit keeps the hierarchy's height: the nodes' own height words are the build's.  knownHeight 0 -- a caller without
+        // it -- reads them back through k_root_info)
+        k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, pyr, b.flags2, b.nodes, nullptr, nullptr, nullptr, b.nodes32,
+                                                                     knownHeight ? b.rootInfo : nullptr, knownHeight, nullptr);
     }
     // (the half-float copy came out of k_refit_ranges' registers; the four-box copy is a re-arrangement of it)
     if (!b.deferCopies && b.nodes64) k_widen_from32<<<blocks_for(numNodes), kThreads, 0, s>>>(b.nodes32, numNodes, b.nodes64);
-    k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
+    if (!withHeights && !knownHeight) k_root_info<<<1, 1, 0, s>>>(b.nodes, b.rootInfo, nullptr);
     return hipGetLastError();
 }
 
@@ -569,7 +631,7 @@ hipError_t lbvh_refit_boxes(const BuildBuffers& b, hipStream_t s)
     const uint32_t T = b.T, P = pyramid_slots(T);
     if (T < 2 || !b.pyramid) return hipErrorInvalidValue;
     k_refit_ranges<false><<<blocks_for(T - 1), kThreads, 0, s>>>(b.triPos, T, P, reinterpret_cast<const Box6*>(b.pyramid), b.flags2, b.nodes,
-                                                                 nullptr, nullptr, nullptr, b.nodes32);
+                                                                 nullptr, nullptr, nullptr, b.nodes32, nullptr, 0u, nullptr);
     return lbvh_traversal_copies(b, s);
 }
 
