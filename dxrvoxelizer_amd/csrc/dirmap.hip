@@ -1,12 +1,15 @@
 // dirmap.hip -- device build of the direction-space lists (dxv_dirmap.h) from a scene's triangle
 // records.  One-off per scene (and per refit), HBM-bound passes:
-//   k_dm_records  one thread per triangle: footprint records of the faces that see it + number of texels each covers
-//   k_dm_emit     one thread per (triangle, face): (texel | far radius | triangle) keys for its texels
+//   k_dm_records  one thread per triangle (per triangle and face for meshes of few triangles): footprint records of the faces
+//                 that see it + number of texels each covers; rectangles of more than 32 texels are counted by a wave
+//                 (k_dm_count_waves: one wave each)
+//   k_dm_emit     one thread per (triangle, face): (texel | far radius | triangle) keys for its texels -- by size: up to 32 texels
+//                 by that thread, up to 16,384 by a wave of k_dm_emit_waves, more (a triangle at the grid's centre: up to a whole
+//                 face of the map) by the whole GPU, k_dm_emit_whole
 //   radix sort    by texel, then far radius (stable: then triangle)
 //   k_dm_cells    first / last entry of every texel
 //   (k_dm_cells also writes the 16-byte entries in list order: each record cut to its texel, dm_local_entry)
-// The keys of one (triangle, face) are written by one thread: footprints are a few texels unless a
-// triangle passes close to the grid centre, and the total is capped (the caller then keeps the tree).
+// The total is capped (the caller then keeps the tree).
 #include "dxv_device.h"
 #include "dxv_dirmap.h"
 
@@ -14,22 +17,41 @@ namespace dxv {
 
 namespace {
 constexpr uint32_t kThreads = 256;
+constexpr uint32_t kDmWholeFrom = 16384u;            // footprints of more texels than this are filled by the whole GPU (k_dm_emit_whole)
+constexpr uint32_t kDmFewTriangles = 300000u;       // up to here the record and key kernels spread their work over more waves (below)
 
+// slot of this lane's item in a list whose length sits in *count: one add per wave for all its lanes with `mine` set (an add per
+// item on one word is ~3 ns each, serialised: 90 k items were 0.27 ms)
+__device__ __forceinline__ uint32_t wave_append(uint32_t* count, bool mine)
+{
+    const unsigned long long m = __ballot(mine);
+    if (!m) return 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+
+// PER_FACE = false: one thread per triangle, its six faces in turn -- the triangle is loaded once, the 64 triangles of a wave are
+// neighbours in Morton order and mostly see the same one or two faces (the clip runs with nearly full waves), and a face that does
+// not see the triangle costs a dozen comparisons and no record: its count of 0 is all k_dm_emit looks at.
+// PER_FACE = true: one thread per (triangle, face) -- for meshes of few, large triangles (the bunny on the 512 map: 70 k triangles
+// of 50 - 100 texels each): a wave of 64 triangles there is a chain of ~80 footprints counted one after the other by the whole
+// wave while three quarters of the GPU have no wave at all (0.24 ms for 274 waves); six times the waves, a sixth of the chain.
+template <bool PER_FACE>
 __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R,
                                                          DirRecord* __restrict__ rec, uint32_t* __restrict__ counts,
-                                                         unsigned long long* __restrict__ total, uint32_t* __restrict__ pairs)
+                                                         unsigned long long* __restrict__ total, uint32_t* __restrict__ pairs,
+                                                         uint32_t* __restrict__ wideList)
 {
-    // one thread per triangle, its six faces in turn: the triangle is loaded once, the 64 triangles of a wave are neighbours
-    // in Morton order and mostly see the same one or two faces (the clip runs with nearly full waves), and a face that does
-    // not see the triangle costs a dozen comparisons and no record -- its count of 0 is all k_dm_emit looks at
-    const uint32_t tri = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x, tri = PER_FACE ? t / 6u : t;
     unsigned long long n = 0;
-    uint32_t seen = 0;                                                  // faces of this triangle that get entries
-    const uint32_t lane0 = threadIdx.x & 63u;
+    uint32_t seen = 0;                                                  // faces of this triangle that get entries (PER_FACE: this face or none)
     TriPos tp{};
     if (tri < T) tp = triPos[tri];
 #pragma unroll 1
-    for (uint32_t face = 0; face < 6u; ++face) {
+    for (uint32_t face = PER_FACE ? t % 6u : 0u, last = PER_FACE ? face + 1u : 6u; face < last; ++face) {
         const uint32_t i = tri * 6u + face;
         DirFootprint f;
         uint32_t c = 0, i0 = 0, i1 = 0, j0 = 0, j1 = 0;
@@ -51,31 +73,43 @@ __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restric
             }
             rec[i] = e;
         }
-        // rectangles of more than 32 texels (a coarse mesh, a soup: 27 texels per triangle on average, up to 1,024): the wave counts
-        // them together, 64 texels at a time -- one thread walking a thousand texels while its neighbours wait was a third of a
-        // 10 M-triangle list build
-        unsigned long long m = __ballot(wide);
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1ull;
-            auto bf = [src](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
-            auto bu = [src](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
-            DirTexelTest t;
-            t.on = true;
+        // rectangles of more than 32 texels with a texel test (a coarse mesh, a soup: 27 texels per triangle on average, up to 1,024)
+        // are counted by a wave, 64 texels at a time (one thread walking a thousand texels while its neighbours wait was a third of a
+        // 10 M-triangle list build) -- a wave of k_dm_count_waves each: this kernel's own waves counting their 64 x 6 rectangles one
+        // after the other were the tail of a region of large triangles (dragon x9).  Their count here: 0; their pair is listed for
+        // k_dm_emit all the same.
+        if (!PER_FACE) {
+            const uint32_t slot = wave_append(reinterpret_cast<uint32_t*>(total) + 6, wide);
+            if (wide) { wideList[slot] = i; c = 0; }
+        } else {
+            // (a mesh of few triangles: its waves hold a dozen rectangles each, not 64 x 6, and count them themselves -- the second
+            // kernel would cost such a build more than the chain does: bunny 0.75 against 0.66 ms, dragon 1.03 against 0.90)
+            unsigned long long m = __ballot(wide);
+            const uint32_t lane0 = threadIdx.x & 63u;
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1ull;
+                auto bf = [src](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+                auto bu = [src](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+                DirTexelTest t;
+                t.on = true;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { t.nx[k] = bf(tt.nx[k]); t.ny[k] = bf(tt.ny[k]); t.c[k] = bf(tt.c[k]); }
-            const uint32_t a0 = bu(i0), a1 = bu(i1), b0 = bu(j0), b1 = bu(j1), wdt = a1 - a0 + 1u, cnt = wdt * (b1 - b0 + 1u);
-            uint32_t kept = 0;
-            for (uint32_t first = 0; first < cnt; first += 64u) {
-                const uint32_t idx = first + lane0;
-                kept += (uint32_t)__builtin_popcountll(__ballot(idx < cnt && !dm_texel_outside(t, R, a0 + idx % wdt, b0 + idx / wdt)));
+                for (int k = 0; k < 3; ++k) { t.nx[k] = bf(tt.nx[k]); t.ny[k] = bf(tt.ny[k]); t.c[k] = bf(tt.c[k]); }
+                const uint32_t a0 = bu(i0), a1 = bu(i1), b0 = bu(j0), b1 = bu(j1), wdt = a1 - a0 + 1u, cnt = wdt * (b1 - b0 + 1u);
+                const uint32_t stepX = 64u % wdt, stepJ = 64u / wdt;
+                uint32_t x = a0 + lane0 % wdt, j = b0 + lane0 / wdt, kept = 0;
+                for (uint32_t first = 0; first < cnt; first += 64u) {
+                    kept += (uint32_t)__builtin_popcountll(__ballot(first + lane0 < cnt && !dm_texel_outside(t, R, x, j)));
+                    x += stepX; j += stepJ;
+                    if (x > a1) { x -= wdt; ++j; }
+                }
+                if ((int)lane0 == src) c = kept;
             }
-            if ((int)lane0 == src) c = kept;
         }
         if (tri < T) {
             counts[i] = c;
             n += c;
-            seen |= c ? 1u << face : 0u;
+            seen |= (c || wide) ? 1u << face : 0u;
         }
     }
     // The (triangle, face) pairs that get entries, as a compact list for k_dm_emit: five pairs in six have none, and a thread per
@@ -102,6 +136,40 @@ __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restric
     for (uint32_t k = 0; k < w; ++k) at += pairPart[k];
     for (uint32_t face = 0; face < 6u; ++face)
         if (seen & (1u << face)) pairs[at++] = tri * 6u + face;
+}
+
+// counts of the rectangles k_dm_records listed: a fixed number of waves, each takes every (number of waves)-th
+__global__ __launch_bounds__(kThreads) void k_dm_count_waves(const DirRecord* __restrict__ rec, uint32_t R, const uint32_t* __restrict__ wideList,
+                                                             uint32_t* __restrict__ counts, unsigned long long* __restrict__ total)
+{
+    const uint32_t n = reinterpret_cast<const uint32_t*>(total)[6], lane = threadIdx.x & 63u, waves = gridDim.x * (kThreads / 64u);
+    unsigned long long sum = 0;
+    for (uint32_t p = (blockIdx.x * kThreads + threadIdx.x) >> 6; p < n; p += waves) {
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)wideList[p]);
+        const DirRecord rc = rec[k];
+        uint32_t a0, a1, b0, b1;
+        (void)dm_rect(rc, R, a0, a1, b0, b1);
+        const uint32_t w = a1 - a0 + 1u, cnt = w * (b1 - b0 + 1u);
+        const DirTexelTest tt = dm_texel_test(rc, cnt);
+        const uint32_t stepX = 64u % w, stepJ = 64u / w;
+        uint32_t x = a0 + lane % w, j = b0 + lane / w, kept = 0;
+        for (uint32_t first = 0; first < cnt; first += 64u) {
+            kept += (uint32_t)__builtin_popcountll(__ballot(first + lane < cnt && !dm_texel_outside(tt, R, x, j)));
+            x += stepX; j += stepJ;
+            if (x > a1) { x -= w; ++j; }
+        }
+        if (lane == 0u) counts[k] = kept;
+        sum += kept;
+    }
+    // (one add per workgroup: 16 k waves adding to the one 64-bit word were 0.2 ms of a 0.21 ms kernel)
+    __shared__ unsigned long long part[kThreads / 64];
+    if (lane == 0u) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        unsigned long long s4 = 0;
+        for (uint32_t q = 0; q < kThreads / 64u; ++q) s4 += part[q];
+        if (s4) atomicAdd(total, s4);
+    }
 }
 
 // exclusive scan of counts[0 .. n) in three launches: per-block sums, scan of the sums by one block, add
@@ -167,58 +235,111 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     }
 }
 
+// Keys of one (triangle, face) footprint of more than 32 texels, written by a whole wave, 64 texels at a time (one thread walking a
+// thousand texels, each with its own radial range, was the build's tail).  rc, the rectangle and `out` are wave-uniform.
+__device__ __forceinline__ void emit_footprint(const DirRecord& rc, uint32_t R, const DirKeyLayout& lay, uint32_t k, uint32_t a0, uint32_t a1,
+                                               uint32_t b0, uint32_t b1, uint64_t* __restrict__ out, uint32_t lane)
+{
+    const uint32_t w = a1 - a0 + 1u, n = w * (b1 - b0 + 1u), tri = k / 6u, face = k % 6u;
+    const DirTexelTest tt = dm_texel_test(rc, n);
+    uint32_t base = 0;                                              // texels with an entry so far (wave-uniform)
+    // (the lane's texel moves on by 64 per round: column and row by the remainder and quotient of 64 / w -- one division per
+    // footprint instead of two per texel)
+    const uint32_t stepX = 64u % w, stepJ = 64u / w;
+    uint32_t x = a0 + lane % w, j = b0 + lane / w;
+    for (uint32_t first = 0; first < n; first += 64u) {
+        const bool keep = first + lane < n && !dm_texel_outside(tt, R, x, j);
+        const unsigned long long km = __ballot(keep);
+        if (keep) {
+            uint32_t r0h, r1h;
+            dm_local_radial(rc, R, x, j, r0h, r1h);
+            out[base + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
+        }
+        base += (uint32_t)__builtin_popcountll(km);
+        x += stepX; j += stepJ;
+        if (x > a1) { x -= w; ++j; }
+    }
+}
+
+// one thread per (triangle, face) pair that gets entries (k_dm_records' list; workgroups behind its end leave at once): footprints
+// of up to 32 texels are written here, by their thread; larger ones go on two lists --
+//   wave list  (33 .. wholeFrom texels): k_dm_emit_waves gives each a wave of its own.  Written here by the pair's wave one after
+//              the other they were a chain of up to 64 x 3 rounds in the waves of a region of large triangles (the dragon around
+//              the centre of dragon x9: 0.7 ms of a 1.9 ms build) while the rest of the GPU had long finished;
+//   whole list (more: a triangle close to the grid's centre, up to a whole face of the map): every texel gets an entry with the
+//              footprint's own radial range (no texel test, no local range: dm_texel_test, dm_record_on_map), a plain fill that
+//              k_dm_emit_whole spreads over the GPU.
+// Lists: (pair, first key) x 2 words from the front / pairs from the back of `lists` (the counts, which nobody reads after the scan).
 __global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ pairs,
                                                       const unsigned long long* __restrict__ total,
-                                                      const uint32_t* __restrict__ offsets, uint32_t R, uint64_t* __restrict__ keys)
+                                                      const uint32_t* __restrict__ offsets, uint32_t R, uint64_t* __restrict__ keys,
+                                                      uint32_t* __restrict__ lists, uint32_t listWords, uint32_t* __restrict__ listCounts, uint32_t wholeFrom)
 {
-    // one thread per (triangle, face) pair that gets entries (k_dm_records' list; workgroups behind its end leave at once)
     const uint32_t t = blockIdx.x * kThreads + threadIdx.x, numPairs = *reinterpret_cast<const uint32_t*>(total + 1);
     if (blockIdx.x * kThreads >= numPairs) return;
     const uint32_t i = t < numPairs ? pairs[t] : 0u;
     const DirKeyLayout lay = dm_key_layout(R);
     uint32_t i0 = 0, i1 = 0, j0 = 0, j1 = 0;
-    const bool valid = t < numPairs && dm_rect(rec[i], R, i0, i1, j0, j1);
+    DirRecord rc{};
+    if (t < numPairs) rc = rec[i];
+    const bool valid = t < numPairs && dm_rect(rc, R, i0, i1, j0, j1);
     const uint32_t area = valid ? (i1 - i0 + 1u) * (j1 - j0 + 1u) : 0u;
-    // footprints of many texels (a triangle near the centre, the triangles of a coarse mesh) are written by the whole wave, 64
-    // texels at a time: one thread walking thousands of texels, each with its own radial range, was the build's tail
-    const bool big = area > 32u;
-    if (valid && !big) {
-        const uint32_t tri = i / 6u, face = i % 6u;
-        uint64_t* out = keys + offsets[i];
-        const DirRecord rc = rec[i];
-        const DirTexelTest tt = dm_texel_test(rc, area);
-        for (uint32_t j = j0; j <= j1; ++j)
-            for (uint32_t x = i0; x <= i1; ++x) {
-                if (dm_texel_outside(tt, R, x, j)) continue;            // (not counted either: k_dm_records)
-                uint32_t r0h, r1h;                                      // (the entry's own far radius: the record cut to this texel)
-                dm_local_radial(rc, R, x, j, r0h, r1h);
-                *out++ = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
-            }
+    const bool toWhole = area > wholeFrom, toWaves = area > 32u && !toWhole;
+    {
+        const uint32_t slot = wave_append(listCounts, toWaves);
+        if (toWaves) lists[slot] = i;
+        const uint32_t back = wave_append(listCounts + 1, toWhole);
+        if (toWhole) lists[listWords - 1u - back] = i;
     }
-    unsigned long long m = __ballot(big);
-    const uint32_t lane = threadIdx.x & 63u;
-    while (m) {
-        const int src = __builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)i, src);
+    if (!valid || area > 32u) return;
+    const uint32_t tri = i / 6u, face = i % 6u;
+    uint64_t* out = keys + offsets[i];
+    const DirTexelTest tt = dm_texel_test(rc, area);
+    for (uint32_t j = j0; j <= j1; ++j)
+        for (uint32_t x = i0; x <= i1; ++x) {
+            if (dm_texel_outside(tt, R, x, j)) continue;            // (not counted either: k_dm_records)
+            uint32_t r0h, r1h;                                      // (the entry's own far radius: the record cut to this texel)
+            dm_local_radial(rc, R, x, j, r0h, r1h);
+            *out++ = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
+        }
+}
+
+// the wave list: a fixed number of waves, each takes every (number of waves)-th footprint
+__global__ __launch_bounds__(kThreads) void k_dm_emit_waves(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ lists,
+                                                            const uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ offsets,
+                                                            uint32_t R, uint64_t* __restrict__ keys)
+{
+    const uint32_t n = *listCounts, lane = threadIdx.x & 63u, waves = gridDim.x * (kThreads / 64u);
+    const DirKeyLayout lay = dm_key_layout(R);
+    for (uint32_t p = (blockIdx.x * kThreads + threadIdx.x) >> 6; p < n; p += waves) {
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)lists[p]);
         const DirRecord rc = rec[k];
         uint32_t a0, a1, b0, b1;
         (void)dm_rect(rc, R, a0, a1, b0, b1);
-        const uint32_t w = a1 - a0 + 1u, n = w * (b1 - b0 + 1u), tri = k / 6u, face = k % 6u;
-        uint64_t* out = keys + offsets[k];
-        const DirTexelTest tt = dm_texel_test(rc, n);
-        uint32_t base = 0;                                              // texels with an entry so far (wave-uniform)
-        for (uint32_t first = 0; first < n; first += 64u) {
-            const uint32_t idx = first + lane;
+        emit_footprint(rc, R, lay, k, a0, a1, b0, b1, keys + offsets[k], lane);
+    }
+}
+
+// the keys of the rectangles k_dm_emit put on its list: texel idx of a rectangle -> key idx of its run, so any thread can write any
+// of them; every workgroup walks the (short) list and takes its stride of each rectangle
+__global__ __launch_bounds__(kThreads) void k_dm_emit_whole(const DirRecord* __restrict__ rec, const uint32_t* __restrict__ lists, uint32_t listWords,
+                                                            const uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ offsets,
+                                                            uint32_t R, uint64_t* __restrict__ keys)
+{
+    const uint32_t n = listCounts[1];
+    const DirKeyLayout lay = dm_key_layout(R);
+    for (uint32_t h = 0; h < n; ++h) {
+        const uint32_t i = lists[listWords - 1u - h], tri = i / 6u, face = i % 6u;
+        const DirRecord rc = rec[i];
+        uint32_t a0, a1, b0, b1;
+        (void)dm_rect(rc, R, a0, a1, b0, b1);
+        const uint32_t w = a1 - a0 + 1u, cnt = w * (b1 - b0 + 1u);
+        uint64_t* out = keys + offsets[i];
+        for (uint32_t idx = blockIdx.x * kThreads + threadIdx.x; idx < cnt; idx += gridDim.x * kThreads) {
             const uint32_t x = a0 + idx % w, j = b0 + idx / w;
-            const bool keep = idx < n && !dm_texel_outside(tt, R, x, j);
-            const unsigned long long km = __ballot(keep);
-            if (keep) {
-                uint32_t r0h, r1h;
-                dm_local_radial(rc, R, x, j, r0h, r1h);
-                out[base + (uint32_t)__builtin_popcountll(km & ((1ull << lane) - 1ull))] = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
-            }
-            base += (uint32_t)__builtin_popcountll(km);
+            uint32_t r0h, r1h;
+            dm_local_radial(rc, R, x, j, r0h, r1h);                     // (the record's own range: its flag for a local one is not set)
+            out[idx] = dm_key(lay, (face * R + j) * R + x, (uint16_t)r1h, tri);
         }
     }
 }
@@ -483,12 +604,15 @@ size_t dirmap_scratch_bytes(uint32_t T, uint64_t entries)
 
 // Pass 1: records, per-(triangle, face) counts and the total.  rec: 6T entries, counts: 6T words, total: one 64-bit word.
 // pairs: 6T words (the (triangle, face) pairs that get entries; their number lands in the word behind the total)
-hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, uint32_t* pairs, unsigned long long* total,
-                        hipStream_t s)
+// wideList: 6T words of scratch (the offsets of pass 2, not made yet)
+hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, uint32_t* pairs, uint32_t* wideList,
+                        unsigned long long* total, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(total, 0, 2 * sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(total, 0, 4 * sizeof(unsigned long long), s);      // (entries, pairs; three list lengths)
     if (e != hipSuccess) return e;
-    k_dm_records<<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs);
+    if (T <= kDmFewTriangles) k_dm_records<true><<<(6u * T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs, wideList);
+    else k_dm_records<false><<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs, wideList);
+    if (T > kDmFewTriangles) k_dm_count_waves<<<2048, kThreads, 0, s>>>(rec, R, wideList, counts, total);
     return hipGetLastError();
 }
 
@@ -505,7 +629,13 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     k_scan_apply<<<nb, 256, 0, s>>>(counts, n6, sums, offsets);
     if ((e = hipMemsetAsync(cells, 0, sizeof(DirCell) * 6 * (size_t)R * R, s)) != hipSuccess) return e;
     if (n == 0) return hipGetLastError();
-    k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, pairs, total, offsets, R, keys);
+    // (the two lists of large footprints: in the counts, which nobody reads after the scan above; their lengths: two words behind
+    // the totals that dirmap_count has zeroed)
+    uint32_t* lists = const_cast<uint32_t*>(counts);
+    uint32_t* listCounts = reinterpret_cast<uint32_t*>(const_cast<unsigned long long*>(total)) + 4;
+    k_dm_emit<<<(n6 + kThreads - 1) / kThreads, kThreads, 0, s>>>(rec, pairs, total, offsets, R, keys, lists, n6, listCounts, kDmWholeFrom);
+    k_dm_emit_waves<<<4096, kThreads, 0, s>>>(rec, lists, listCounts, offsets, R, keys);     // (1,024 or 16,384 workgroups: the same times)
+    k_dm_emit_whole<<<1024, kThreads, 0, s>>>(rec, lists, n6, listCounts, offsets, R, keys);
     // sort by (texel, far radius): the bits above the triangle field (keys of one texel and radius are emitted in triangle order
     // and the sort is stable)
     const DirKeyLayout lay = dm_key_layout(R);

@@ -446,7 +446,7 @@ int dxv_refit(dxv_ctx* c)
         spec = c->optListRes ? (uint32_t)c->optListRes : list_resolution(c);     // (the base map: a mesh that is being refitted gets its lists built for one launch)
         const ListScratchA sa = list_scratch_a(c->dListScratchA, c->hdr.numTris);
         DXV_HIP(c, hipEventRecord(c->evList[0], c->stream));
-        DXV_HIP(c, dirmap_count(scene_tripos(c), c->hdr.numTris, spec, sa.rec, sa.counts, sa.pairs, sa.total, c->stream));
+        DXV_HIP(c, dirmap_count(scene_tripos(c), c->hdr.numTris, spec, sa.rec, sa.counts, sa.pairs, sa.offsets, sa.total, c->stream));
         DXV_HIP(c, hipEventRecord(c->evList[1], c->stream));
         DXV_HIP(c, hipMemcpyAsync(&c->pin->listTotal, sa.total, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     }

@@ -132,7 +132,7 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels,
     unsigned long long total = 0;
     auto recount = [&](uint32_t res) -> int {
         R = res;
-        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, sa.pairs, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
+        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, sa.pairs, offsets, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
         (void)hipEventRecord(c->evList[1], stream);
         if ((e = hipMemcpyAsync(&c->pin->listTotal, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
