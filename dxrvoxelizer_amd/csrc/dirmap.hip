@@ -43,9 +43,10 @@ template <bool PER_FACE>
 __global__ __launch_bounds__(kThreads) void k_dm_records(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R,
                                                          DirRecord* __restrict__ rec, uint32_t* __restrict__ counts,
                                                          unsigned long long* __restrict__ total, uint32_t* __restrict__ pairs,
-                                                         uint32_t* __restrict__ wideList)
+                                                         uint32_t* __restrict__ wideList, uint32_t stride)
 {
-    const uint32_t t = blockIdx.x * kThreads + threadIdx.x, tri = PER_FACE ? t / 6u : t;
+    // (stride > 1: every stride-th triangle only -- dirmap_count's estimate of a scene's entries on a map)
+    const uint32_t t = blockIdx.x * kThreads + threadIdx.x, tri = (PER_FACE ? t / 6u : t) * stride;
     unsigned long long n = 0;
     uint32_t seen = 0;                                                  // faces of this triangle that get entries (PER_FACE: this face or none)
     TriPos tp{};
@@ -605,13 +606,15 @@ size_t dirmap_scratch_bytes(uint32_t T, uint64_t entries)
 // Pass 1: records, per-(triangle, face) counts and the total.  rec: 6T entries, counts: 6T words, total: one 64-bit word.
 // pairs: 6T words (the (triangle, face) pairs that get entries; their number lands in the word behind the total)
 // wideList: 6T words of scratch (the offsets of pass 2, not made yet)
+// stride > 1: every stride-th triangle only (an estimate: total x stride; what it leaves in the arrays is of no use to pass 2)
 hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, uint32_t* pairs, uint32_t* wideList,
-                        unsigned long long* total, hipStream_t s)
+                        unsigned long long* total, hipStream_t s, uint32_t stride)
 {
     hipError_t e = hipMemsetAsync(total, 0, 4 * sizeof(unsigned long long), s);      // (entries, pairs; three list lengths)
     if (e != hipSuccess) return e;
-    if (T <= kDmFewTriangles) k_dm_records<true><<<(6u * T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs, wideList);
-    else k_dm_records<false><<<(T + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs, wideList);
+    const uint32_t Ts = (T + stride - 1u) / stride;
+    if (T <= kDmFewTriangles) k_dm_records<true><<<(6u * Ts + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs, wideList, stride);
+    else k_dm_records<false><<<(Ts + kThreads - 1) / kThreads, kThreads, 0, s>>>(triPos, T, R, rec, counts, total, pairs, wideList, stride);
     if (T > kDmFewTriangles) k_dm_count_waves<<<2048, kThreads, 0, s>>>(rec, R, wideList, counts, total);
     return hipGetLastError();
 }

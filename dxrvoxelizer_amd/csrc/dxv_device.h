@@ -49,7 +49,7 @@ hipError_t lbvh_refit_boxes(const BuildBuffers& b, hipStream_t s);        // wha
 struct DirEntry;
 struct DirRecord;
 struct DirCell;
-hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, uint32_t* pairs, uint32_t* wideList, unsigned long long* total, hipStream_t s);
+hipError_t dirmap_count(const TriPos* triPos, uint32_t T, uint32_t R, DirRecord* rec, uint32_t* counts, uint32_t* pairs, uint32_t* wideList, unsigned long long* total, hipStream_t s, uint32_t stride = 1);
 hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint32_t* counts, const uint32_t* pairs, const unsigned long long* total,
                        uint32_t* offsets, uint32_t* sums, uint64_t* keys, uint64_t* keysTmp, uint32_t* hist, uint32_t n, DirCell* cells, DirEntry* entries, uint32_t* longest,
                        hipStream_t s);

@@ -130,18 +130,27 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels,
     uint32_t *counts = sa.counts, *offsets = sa.offsets, *sums = sa.sums;
     unsigned long long* dTotal = sa.total;
     unsigned long long total = 0;
-    auto recount = [&](uint32_t res) -> int {
+    auto recount = [&](uint32_t res, uint32_t stride = 1u) -> int {
         R = res;
-        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, sa.pairs, offsets, dTotal, stream)) != hipSuccess) return bail(e, "dirmap_count");
+        if ((e = dirmap_count(scene_tripos(c), T, R, rec, counts, sa.pairs, offsets, dTotal, stream, stride)) != hipSuccess) return bail(e, "dirmap_count");
         (void)hipEventRecord(c->evList[1], stream);
         if ((e = hipMemcpyAsync(&c->pin->listTotal, dTotal, sizeof(total), hipMemcpyDeviceToHost, stream)) != hipSuccess) return bail(e, "hipMemcpyAsync");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
         total = c->pin->listTotal;
         return 0;
     };
+    const bool oneLaunch = firstLaunchVoxels != 0 || c->refitted;
     if (counted) total = c->pin->listTotal;
     else {
         (void)hipEventRecord(c->evList[0], stream);
+        // A scene of millions of triangles is first counted on every 16th of them: a soup's count on the 512 map only says that
+        // the scene is deep and the 256 map it is -- 4.7 ms of a 24 ms build for that -- and a sixteenth of the triangles says so too
+        // (lists_sample_first; what the estimate decides is checked against the full count below like any other choice of map)
+        if (lists_sample_first(T, c->optListRes)) {
+            if (recount(R, kListsSampleStride)) return 1;
+            const uint32_t next = lists_recount_on(R, total * kListsSampleStride, oneLaunch, c->optListRes, false);
+            if (next && next < R) R = next;
+        }
         if (recount(R)) return 1;
     }
     // automatic resolution, from the mean list length A = entries per texel (it hardly depends on the map: it is the
@@ -159,7 +168,6 @@ int build_lists_into(dxv_ctx* c, hipStream_t stream, uint64_t firstLaunchVoxels,
     // 128^3 to 1024^3, by 5 - 22 % -- profiles/r04/ab_texels_outside_the_outline.jsonl -- so every scene that is presumed static
     // takes it; a mesh that is being refitted, or a first launch that must pay for its build at once, keeps the base map; deep
     // scenes -- over 32 entries per texel: soups -- take the 256 map while it stays below 320 M entries, else the 128 map)
-    const bool oneLaunch = firstLaunchVoxels != 0 || c->refitted;
     for (int again = 0; again < 2; ++again) {
         const uint32_t next = lists_recount_on(R, total, oneLaunch, c->optListRes, again != 0);
         if (!next || next == R || (again && next > R)) break;

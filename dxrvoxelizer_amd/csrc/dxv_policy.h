@@ -82,6 +82,9 @@ inline uint32_t lists_recount_on(uint32_t R, uint64_t entries, bool oneLaunch, i
     }
     return 0u;
 }
+// a build of this many triangles counts every kListsSampleStride-th of them first and lets the estimate pick the map
+constexpr uint32_t kListsSampleFrom = 3000000u, kListsSampleStride = 16u;
+inline bool lists_sample_first(uint32_t numTris, int optListRes) { return !optListRes && numTris >= kListsSampleFrom; }
 // scenes whose lists would exceed 256 entries per triangle + 64 M, or 2^31, keep the tree walk
 inline bool lists_over_the_caps(uint64_t entries, uint32_t numTris) { return entries > 256ull * numTris + (64ull << 20) || entries > 0x7fffffffull; }
 // a first-launch build goes on only when what the lists save on THIS launch exceeds what the rest of the build costs

@@ -110,6 +110,15 @@ def test_maps_and_caps(pol):
     assert pol.hc_lists_recount_on(256, 400_000_000, 0, 0, 1) == 128
     assert pol.hc_lists_recount_on(256, 400_000_000, 0, 0, 0) == 128
     assert pol.hc_lists_recount_on(256, 3_300_000, 0, 0, 1) == 0                    # (never back up to a finer map after a step down)
+    # a scene of millions of triangles is counted on a sample first, and the estimate picks the map the full count is made on:
+    # config 5 (10 M triangles, ~600 M entries on the 512 map) goes straight to the 256 map, a 4 M-triangle surface stays
+    pol.hc_lists_sample_first.argtypes = [C.c_uint32, C.c_int]
+    pol.hc_lists_sample_stride.restype = C.c_uint32
+    assert pol.hc_lists_sample_first(10_000_000, 0) == 1 and pol.hc_lists_sample_first(1_000_000, 0) == 0
+    assert pol.hc_lists_sample_first(10_000_000, 256) == 0                          # (an explicit listres: nothing to pick)
+    k = pol.hc_lists_sample_stride()
+    assert pol.hc_lists_recount_on(512, (600_000_000 // k) * k, 0, 0, 0) == 256
+    assert pol.hc_lists_recount_on(512, (26_000_000 // k) * k, 0, 0, 0) == 0
     assert pol.hc_lists_recount_on(256, 3_300_000, 0, 256, 0) == 0                  # an explicit listres: no recount at all
     assert pol.hc_lists_over_the_caps(256 * 1_000_000 + (64 << 20) + 1, 1_000_000) == 1 and pol.hc_lists_over_the_caps(6_400_000, 1_000_000) == 0
     assert pol.hc_lists_over_the_caps(0x80000000, 100_000_000) == 1
