@@ -492,43 +492,83 @@ __global__ __launch_bounds__(kThreads) void k_dm_close(const uint64_t* __restric
     if (count > 0xffffu) atomicMax(longest, count);                    // (only what does not fit is reported: one address, 300 k texels)
 }
 
-// Max-mip of the texels' far radii (dm_mip_max, dxv_dirmap.h).  k_dm_mip_tiles: one workgroup per TILE x TILE texels of a face
-// (TILE = min(R, 32)): level 0 from the cells, levels 1 .. log2(TILE) through LDS.  k_dm_mip_top: the levels above, one
-// workgroup, each level from the one below (a few hundred words at R = 256).
-template <bool COUNTS>
+// Max-mips of the texels' far radii and of their entry counts (dm_mip_max, dm_box_max_count, dxv_dirmap.h), and the count
+// levels' "long list" words.  Two launches:
+//   k_dm_mip_tiles  one workgroup per TILE x TILE texels of a face (TILE = min(R, 32)): level 0 of both mips from the cells (read
+//                   once), levels 1 .. log2(TILE) through LDS; for the levels that get a "long list" word, the tile's sum of counts
+//                   and number of non-empty cells into the scratch behind the mips
+//   k_dm_mip_top    two workgroups, one per mip: the levels above, each from the one below (a few hundred words at R = 256); the
+//                   counts' workgroup then makes the "long list" words (below)
+// (until round 5 five launches -- tiles and top per mip, then the words, one workgroup per level walking up to 98 k cells: 75 us of a
+// 0.94 ms build at 1 M triangles)
+__device__ __forceinline__ void wg_sum2(unsigned long long& s, uint32_t& c, unsigned long long* sumLds, uint32_t* numLds, uint32_t waves)
+{
+    for (int off = 32; off; off >>= 1) { s += __shfl_down(s, off); c += __shfl_down(c, off); }
+    __syncthreads();                                                    // (the arrays may still be read from the last call)
+    if ((threadIdx.x & 63u) == 0u) { sumLds[threadIdx.x >> 6] = s; numLds[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    s = 0; c = 0;
+    for (uint32_t k = 0; k < waves; ++k) { s += sumLds[k]; c += numLds[k]; }
+}
 __global__ __launch_bounds__(256) void k_dm_mip_tiles(const DirCell* __restrict__ cells, uint32_t R, uint32_t tile, uint16_t* __restrict__ mip)
 {
-    __shared__ uint16_t lds[2][32 * 32];
+    __shared__ uint16_t lds[2][2][32 * 32];                             // [mip][ping-pong]
+    __shared__ unsigned long long sumLds[4];
+    __shared__ uint32_t numLds[4];
+    uint16_t* counts = mip + dm_mip_words(R);
+    uint32_t* partials = reinterpret_cast<uint32_t*>(mip + dm_mip_partials_at(R));
     const uint32_t tilesPerSide = R / tile, face = blockIdx.x / (tilesPerSide * tilesPerSide), in = blockIdx.x % (tilesPerSide * tilesPerSide);
     const uint32_t ti0 = (in % tilesPerSide) * tile, tj0 = (in / tilesPerSide) * tile;
     for (uint32_t k = threadIdx.x; k < tile * tile; k += 256u) {
         const uint32_t i = ti0 + k % tile, j = tj0 + k / tile;
-        const uint32_t key = COUNTS ? dm_mip_count_key(cells[(face * R + j) * R + i]) : dm_mip_key(cells[(face * R + j) * R + i]);
-        lds[0][k] = (uint16_t)key;
-        mip[(face * R + j) * R + i] = (uint16_t)key;
+        const DirCell c = cells[(face * R + j) * R + i];
+        lds[0][0][k] = mip[(face * R + j) * R + i] = (uint16_t)dm_mip_key(c);
+        lds[1][0][k] = counts[(face * R + j) * R + i] = (uint16_t)dm_mip_count_key(c);
     }
     __syncthreads();
     uint32_t side = tile, cur = 0, off = 0, r = R;
     for (uint32_t l = 1; side > 1u; ++l) {
         off += 6u * r * r; r >>= 1;
         const uint32_t half = side >> 1;
+        unsigned long long sum = 0;
+        uint32_t num = 0;
         for (uint32_t k = threadIdx.x; k < half * half; k += 256u) {
             const uint32_t x = k % half, y = k / half;
-            const uint16_t* a = lds[cur] + (2u * y) * side + 2u * x;
-            uint16_t m = a[0];
-            if (a[1] > m) m = a[1];
-            if (a[side] > m) m = a[side];
-            if (a[side + 1u] > m) m = a[side + 1u];
-            lds[cur ^ 1u][y * half + x] = m;
-            mip[off + (face * r + (tj0 >> l) + y) * r + (ti0 >> l) + x] = m;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const uint16_t* a = lds[which][cur] + (2u * y) * side + 2u * x;
+                uint16_t m = a[0];
+                if (a[1] > m) m = a[1];
+                if (a[side] > m) m = a[side];
+                if (a[side + 1u] > m) m = a[side + 1u];
+                lds[which][cur ^ 1u][y * half + x] = m;
+                (which ? counts : mip)[off + (face * r + (tj0 >> l) + y) * r + (ti0 >> l) + x] = m;
+                if (which) { sum += m; num += m ? 1u : 0u; }
+            }
+        }
+        if (l >= kDmHeavyLevelMin) {                                     // (uniform: every thread of the workgroup takes part)
+            wg_sum2(sum, num, sumLds, numLds, 4u);
+            if (threadIdx.x == 0u) {
+                uint32_t* p = partials + 2u * ((size_t)(l - kDmHeavyLevelMin) * gridDim.x + blockIdx.x);
+                p[0] = (uint32_t)sum; p[1] = num;                       // (at most 64 cells of at most 65,535 entries)
+            }
         }
         __syncthreads();
         side = half; cur ^= 1u;
     }
 }
-__global__ __launch_bounds__(1024) void k_dm_mip_top(uint32_t R, uint32_t fromLevel, uint16_t* mip)
+// "A long list", per level of the count mip: one and a half times the mean of the level's non-empty cells (at least 8).  A brick's
+// rays look into a patch of texels whose size depends on the grid (4 voxels of 2 / N against texels of 2 / R); the launch picks the
+// level whose cells are about that patch (dm_heavy_level) and calls a brick heavy when the longest list it can look into is
+// longer than that level's word -- a scene of 13 entries per direction and one of 8 draw the line in different places.
+// (levels kDmHeavyLevelMin and up: the two levels below would cost more than the rest of the mip build and no grid of up to 2048^3
+// asks for them, dm_heavy_level)
+__global__ __launch_bounds__(1024) void k_dm_mip_top(uint32_t R, uint32_t fromLevel, uint16_t* mipBase, uint32_t tiles)
 {
+    __shared__ unsigned long long sumLds[16];
+    __shared__ uint32_t numLds[16];
     const uint32_t levels = dm_mip_levels(R);
+    uint16_t* mip = mipBase + (blockIdx.x ? dm_mip_words(R) : 0u);      // workgroup 0: far radii, 1: counts
     for (uint32_t l = fromLevel + 1u; l < levels; ++l) {
         const uint32_t r = R >> l, rp = r << 1;
         const uint16_t* below = mip + dm_mip_offset(R, l - 1u);
@@ -544,6 +584,26 @@ __global__ __launch_bounds__(1024) void k_dm_mip_top(uint32_t R, uint32_t fromLe
         }
         __threadfence();
         __syncthreads();
+    }
+    if (blockIdx.x == 0u) return;
+    const uint32_t* partials = reinterpret_cast<const uint32_t*>(mipBase + dm_mip_partials_at(R));
+    uint16_t* thr = mipBase + 2u * dm_mip_words(R);
+    for (uint32_t l = kDmHeavyLevelMin; l < levels; ++l) {
+        unsigned long long s = 0;
+        uint32_t c = 0;
+        if (l <= fromLevel) {                                           // made inside the tiles: their sums
+            const uint32_t* p = partials + 2u * (size_t)(l - kDmHeavyLevelMin) * tiles;
+            for (uint32_t k = threadIdx.x; k < tiles; k += 1024u) { s += p[2u * k]; c += p[2u * k + 1u]; }
+        } else {                                                        // made above: the level's own cells (a few hundred)
+            const uint32_t r = R >> l, n = 6u * r * r;
+            const uint16_t* lc = mip + dm_mip_offset(R, l);
+            for (uint32_t k = threadIdx.x; k < n; k += 1024u) { const uint32_t v = lc[k]; s += v; c += v ? 1u : 0u; }
+        }
+        wg_sum2(s, c, sumLds, numLds, 16u);
+        if (threadIdx.x == 0u) {
+            const unsigned long long t = c ? (3ull * s + 2ull * c - 1ull) / (2ull * c) : 8ull;
+            thr[l] = (uint16_t)(t < 8ull ? 8ull : t > 65535ull ? 65535ull : t);
+        }
     }
 }
 
@@ -661,46 +721,14 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     return hipGetLastError();
 }
 
-// "A long list", per level of the count mip: one and a half times the mean of the level's non-empty cells (at least 8).  A brick's
-// rays look into a patch of texels whose size depends on the grid (4 voxels of 2 / N against texels of 2 / R); the launch picks the
-// level whose cells are about that patch (dm_heavy_level) and calls a brick heavy when the longest list it can look into is
-// longer than that level's word -- a scene of 13 entries per direction and one of 8 draw the line in different places.
-// (levels kDmHeavyLevelMin and up: one workgroup each -- the finest of them has 98 k cells at R = 512; the two levels below would
-// cost more than the rest of the mip build and no grid of up to 2048^3 asks for them, dm_heavy_level)
-__global__ __launch_bounds__(1024) void k_dm_heavy_thresholds(uint32_t R, const uint16_t* __restrict__ counts, uint16_t* __restrict__ thr)
-{
-    __shared__ unsigned long long sum[16];
-    __shared__ uint32_t num[16];
-    const uint32_t l = blockIdx.x + kDmHeavyLevelMin, r = R >> l, n = 6u * r * r;
-    const uint16_t* cells = counts + dm_mip_offset(R, l);
-    unsigned long long s = 0;
-    uint32_t c = 0;
-    for (uint32_t k = threadIdx.x; k < n; k += 1024u) { const uint32_t v = cells[k]; s += v; c += v ? 1u : 0u; }
-    for (int off = 32; off; off >>= 1) { s += __shfl_down(s, off); c += __shfl_down(c, off); }
-    if ((threadIdx.x & 63u) == 0u) { sum[threadIdx.x >> 6] = s; num[threadIdx.x >> 6] = c; }
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        unsigned long long st = 0;
-        uint32_t ct = 0;
-        for (int k = 0; k < 16; ++k) { st += sum[k]; ct += num[k]; }
-        const unsigned long long t = ct ? (3ull * st + 2ull * ct - 1ull) / (2ull * ct) : 8ull;
-        thr[l] = (uint16_t)(t < 8ull ? 8ull : t > 65535ull ? 65535ull : t);
-    }
-}
-
-// mip: dm_mip_buffer_words(R) 16-bit words (far radii, then entry counts, then the count levels' "long list" words)
+// mip: dm_mip_buffer_words(R) 16-bit words (far radii, then entry counts, then the count levels' "long list" words, then scratch)
 hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream_t s)
 {
-    const uint32_t tile = R < 32u ? R : 32u;
+    const uint32_t tile = R < 32u ? R : 32u, tiles = 6u * (R / tile) * (R / tile);
     uint32_t tileLevel = 0;
     while ((1u << tileLevel) < tile) ++tileLevel;
-    k_dm_mip_tiles<false><<<6u * (R / tile) * (R / tile), 256, 0, s>>>(cells, R, tile, mip);
-    if (tileLevel + 1u < dm_mip_levels(R)) k_dm_mip_top<<<1, 1024, 0, s>>>(R, tileLevel, mip);
-    // ... and the max-mip of the texels' entry counts behind it (dm_box_max_count: which bricks a launch starts with)
-    uint16_t* counts = mip + dm_mip_words(R);
-    k_dm_mip_tiles<true><<<6u * (R / tile) * (R / tile), 256, 0, s>>>(cells, R, tile, counts);
-    if (tileLevel + 1u < dm_mip_levels(R)) k_dm_mip_top<<<1, 1024, 0, s>>>(R, tileLevel, counts);
-    if (dm_mip_levels(R) > kDmHeavyLevelMin) k_dm_heavy_thresholds<<<dm_mip_levels(R) - kDmHeavyLevelMin, 1024, 0, s>>>(R, counts, counts + dm_mip_words(R));
+    k_dm_mip_tiles<<<tiles, 256, 0, s>>>(cells, R, tile, mip);
+    k_dm_mip_top<<<2, 1024, 0, s>>>(R, tileLevel, mip, tiles);
     return hipGetLastError();
 }
 

@@ -306,8 +306,14 @@ DXV_HD uint32_t dm_box_max_count(float x0, float x1, float y0, float y1, float z
     });
     return most;
 }
-// memory of the two mips and the per-level "long list" words behind them (dirmap.hip: k_dm_heavy_thresholds), 16-bit words
-DXV_HD uint32_t dm_mip_buffer_words(uint32_t R) { return 2u * dm_mip_words(R) + 16u; }
+// memory of the two mips, the per-level "long list" words behind them (16 words) and the build's scratch behind those (dirmap.hip:
+// k_dm_mip_tiles leaves (sum, non-empty cells) per tile and level there for k_dm_mip_top), 16-bit words
+DXV_HD uint32_t dm_mip_partials_at(uint32_t R) { return (2u * dm_mip_words(R) + 16u + 3u) & ~3u; }
+DXV_HD uint32_t dm_mip_buffer_words(uint32_t R)
+{
+    const uint32_t tile = R < 32u ? R : 32u, tiles = 6u * (R / tile) * (R / tile);
+    return dm_mip_partials_at(R) + 4u * tiles * 8u;                   // (two 32-bit words per tile and level, up to 8 levels inside a tile)
+}
 // the level of the count mip whose cells are about the patch of texels a 4^3-voxel brick of an N^3 grid looks into
 // (4 voxels of 2 / N at a typical distance of 0.7 from the centre: ~5.6 R / N texels across)
 constexpr uint32_t kDmHeavyLevelMin = 2u;           // (the levels below have no "long list" word: k_dm_heavy_thresholds)
