@@ -70,7 +70,7 @@ def algorithmic_bytes(N, nz, T, V):
     return N * N * nz * 1 + (2 * T - 1) * 32 + T * 12 + V * 24
 
 
-def build_bytes(T, passes=4):
+def build_bytes(T, passes=3):
     """SURVEY.md section 8(d), B_build: three positions per triangle read, one 64-bit key written, `passes` radix passes of
     8 B read + 8 B written per key, every 32-byte node written once, two child boxes read per internal node."""
     return T * 36 + T * 8 + passes * 16 * T + (2 * T - 1) * 32 + (T - 1) * 64
@@ -549,7 +549,7 @@ def main():
                        "build_roofline": {"bound": "hbm", "bytes": build_bytes(T), "ms": st0["build_ms"],
                                           "achieved": build_bytes(T) / (st0["build_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                           "frac": build_bytes(T) / (st0["build_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                          "note": "LBVH build of this mesh (keys, 4-pass radix sort, hierarchy, boxes, half-float node copy), "
+                                          "note": "LBVH build of this mesh (keys, radix sort in three passes of 10-bit digits, hierarchy, boxes, half-float node copy), "
                                                   "B_build of SURVEY.md 8(d)"},
                        "upload_ms": st0["upload_ms"], "scene_broadcast_ms": bcast_ms,
                        "scene_broadcast": ({"bytes": bcast.get("bytes"), "collective_ms": bcast.get("broadcast_ms"),
