@@ -99,7 +99,8 @@ struct VoxelizeParams {
     uint32_t planRegionBits; // log2 of the run of consecutive Morton bricks that goes to one queue (6, 7 or 8)
     uint32_t planHeavy;     // a brick that can look into a list of more entries than this goes to the front of its queue; 0: the scene's own "long list" (k_dm_heavy_thresholds)
     uint32_t planClear;     // 1: k_plan_bricks also clears the grid (and the texel image): no memset in front of it
-    uint32_t queueWaves;    // persistent waves to launch; 0 = what the device holds at once
+    uint32_t queueWaves;    // persistent waves to launch; 0 = queueSevenths / 7 of what the device holds at once
+    uint32_t queueSevenths; // (dxv_policy.h: queue_waves_sevenths; 0 = 7)
     uint32_t queueHeads;    // heads per queue the persistent waves draw from: 1, 2, 4 or 8
     uint32_t queueMinBricks; // persistent waves beyond one per this many bricks of an XCD's share leave at once (0: all stay)
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against

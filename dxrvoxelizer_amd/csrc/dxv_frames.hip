@@ -146,7 +146,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
                 }
                 if (f.dQueue) {
                     queued = true; p.queue = f.dQueue + f.queueHdr * kQueueHeaderWords; p.queueSlots = f.dQueue + kQueueSlotsAt; p.queueCap = cap;
-                    p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves; p.queueHeads = (uint32_t)c->optQueueHeads; p.queueMinBricks = (uint32_t)c->optQueueMin;
+                    p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves; p.queueSevenths = queue_waves_sevenths(c->hdr.numTris, c->listRes, p.N); p.queueHeads = (uint32_t)c->optQueueHeads; p.queueMinBricks = (uint32_t)c->optQueueMin;
                     p.planRegionBits = c->optPlanRegion ? (uint32_t)c->optPlanRegion : plan_region_bits(p.N, p.nz);
                     p.planClear = c->optFuse ? 1u : 0u;
                     p.planHeavy = (uint32_t)c->optPlanHeavy;

@@ -105,6 +105,21 @@ struct QueueState {
     uint64_t lensSig;        // signature of the queue whose lengths a dxv_sync has read (0: none)
     uint32_t queuedBricks;   // ... their sum
 };
+// Persistent waves of a launch through the queue, in sevenths of what the device holds at once (7 waves per SIMD).  A brick of a
+// coarse grid looks into a large patch of the map (5.6 R / N texels across), and on a mesh of many small triangles the rays of
+// one brick meet dozens of different triangles: seven such waves per SIMD get in each other's way in the vector caches, five or four
+// finish the launch sooner (256^3 on the 512 map, nothing carried: torus-1M 0.190 -> 0.166 ms, bunny x16 0.217 -> 0.183, dragon x9
+// 0.145 -> 0.138; 128^3: 0.069 -> 0.064 with four).  Meshes of few triangles lose (bunny 256^3: +5 % with five), and so does every
+// mesh on a grid as fine as the map (512^3: +12 %): all waves there.  (profiles/r05/ab_waves_by_grid.jsonl; option queuewaves
+// overrides.)
+constexpr uint32_t kQueueFineMeshFrom = 500000u;
+inline uint32_t queue_waves_sevenths(uint32_t numTris, uint32_t R, uint32_t N)
+{
+    if (numTris < kQueueFineMeshFrom) return 7u;
+    if (4ull * N <= R) return 4u;
+    if (2ull * N <= R) return 5u;
+    return 7u;
+}
 enum class QueueLaunch { build_and_persistent, kept_persistent, kept_hardware };
 inline QueueLaunch queue_policy(const QueueState& q, uint64_t sig, uint64_t voxels)
 {

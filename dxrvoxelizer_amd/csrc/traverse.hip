@@ -686,7 +686,8 @@ hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32
         if ((e = plan_build(p, s)) != hipSuccess) return e;
         if (planEvents && (e = hipEventRecord(planEvents[1], s)) != hipSuccess) return e;
     } else if ((e = hipMemsetAsync(p.queue + queue_head_word(0, 0), 0, sizeof(uint32_t) * (queue_len_word(0) - queue_head_word(0, 0)), s)) != hipSuccess) return e;   // the 64 heads
-    const uint32_t waves = p.queueWaves ? (p.queueWaves + 7u) & ~7u : queue_waves(p.texels != nullptr);     // (a multiple of 8, at least 8: every head has a home wave)
+    const uint32_t held = queue_waves(p.texels != nullptr), sevenths = p.queueSevenths && p.queueSevenths < 7u ? p.queueSevenths : 7u;
+    const uint32_t waves = p.queueWaves ? (p.queueWaves + 7u) & ~7u : (held * sevenths / 7u + 7u) & ~7u;     // (a multiple of 8, at least 8: every head has a home wave)
     if (wavesOut) *wavesOut = waves;
     if (p.texels) k_voxelize_queue<true><<<dim3(waves), dim3(64), 0, s>>>(p);
     else k_voxelize_queue<false><<<dim3(waves), dim3(64), 0, s>>>(p);

@@ -929,6 +929,7 @@ __attribute__((visibility("default"))) uint32_t hc_lists_base_map(uint32_t numTr
 __attribute__((visibility("default"))) uint32_t hc_lists_recount_on(uint32_t R, uint64_t entries, int oneLaunch, int optListRes, int coarser) { return lists_recount_on(R, entries, oneLaunch != 0, optListRes, coarser != 0); }
 __attribute__((visibility("default"))) int hc_lists_sample_first(uint32_t numTris, int optListRes) { return lists_sample_first(numTris, optListRes) ? 1 : 0; }
 __attribute__((visibility("default"))) uint32_t hc_lists_sample_stride(void) { return kListsSampleStride; }
+__attribute__((visibility("default"))) uint32_t hc_queue_waves_sevenths(uint32_t numTris, uint32_t R, uint32_t N) { return queue_waves_sevenths(numTris, R, N); }
 __attribute__((visibility("default"))) int hc_lists_over_the_caps(uint64_t entries, uint32_t numTris) { return lists_over_the_caps(entries, numTris) ? 1 : 0; }
 __attribute__((visibility("default"))) int hc_lists_pay(uint64_t voxels, uint64_t entries, uint32_t R) { return lists_pay_on_first_launch(voxels, entries, R) ? 1 : 0; }
 __attribute__((visibility("default"))) int hc_queue_policy(int optPlan, int optDispatch, int ptrExposed, uint64_t keptSig, uint64_t lensSig, uint32_t queuedBricks, uint64_t sig, uint64_t voxels)

@@ -119,6 +119,12 @@ def test_maps_and_caps(pol):
     k = pol.hc_lists_sample_stride()
     assert pol.hc_lists_recount_on(512, (600_000_000 // k) * k, 0, 0, 0) == 256
     assert pol.hc_lists_recount_on(512, (26_000_000 // k) * k, 0, 0, 0) == 0
+    # persistent waves by mesh and grid: all the device holds unless a mesh of many small triangles is launched on a grid much
+    # coarser than its map
+    pol.hc_queue_waves_sevenths.restype = C.c_uint32
+    assert [pol.hc_queue_waves_sevenths(1_000_000, 512, n) for n in (64, 128, 256, 384, 512, 1024)] == [4, 4, 5, 7, 7, 7]
+    assert [pol.hc_queue_waves_sevenths(100_000, 512, n) for n in (64, 128, 256, 512)] == [7, 7, 7, 7]
+    assert pol.hc_queue_waves_sevenths(10_000_000, 256, 256) == 7 and pol.hc_queue_waves_sevenths(10_000_000, 256, 128) == 5
     assert pol.hc_lists_recount_on(256, 3_300_000, 0, 256, 0) == 0                  # an explicit listres: no recount at all
     assert pol.hc_lists_over_the_caps(256 * 1_000_000 + (64 << 20) + 1, 1_000_000) == 1 and pol.hc_lists_over_the_caps(6_400_000, 1_000_000) == 0
     assert pol.hc_lists_over_the_caps(0x80000000, 100_000_000) == 1
