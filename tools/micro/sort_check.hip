@@ -20,7 +20,7 @@ int main(int argc, char** argv)
     struct Case { uint32_t n; int loBit, numBits; };
     std::vector<Case> cases = {{1, 32, 30}, {63, 32, 30}, {4097, 32, 30}, {70000, 32, 30}, {1000000, 32, 30}, {6403636, 27, 37}, {5000000, 29, 35}};
     if (timing) cases = {{1000000, 32, 30}, {10000000, 32, 30}, {6403636, 27, 37}, {150000000, 29, 35}};
-    std::vector<int> plans = {0, 8, 9, 10, 11, 16 + 10, 32 + 10, 32 + 8, 16 + 8};
+    std::vector<int> plans = {0, 8, 9, 10, 11, 16 + 10, 32 + 10, 32 + 8, 16 + 8, 48 + 11};
     if (argc > 2) { plans.clear(); for (int a = 2; a < argc; ++a) plans.push_back(atoi(argv[a])); if (!strcmp(argv[1], "time1")) cases.resize(1); else if (!strcmp(argv[1], "time6")) cases = {cases[2]}; }
     int bad = 0;
     for (const Case& c : cases) {
@@ -58,11 +58,7 @@ int main(int argc, char** argv)
                 hipMemcpy(got.data(), res, 8ull * c.n, hipMemcpyDeviceToHost);
                 diff = 0; long long first = -1;
                 for (uint32_t i = 0; i < c.n; ++i) if (got[i] != want[i]) { if (first < 0) first = i; ++diff; }
-                if (diff) { ++bad; printf("{\"n\": %u, \"plan\": %d, \"first_diff\": %lld}\n", c.n, plan, first);
-                    if (c.n <= 64 && plan == 0) { std::vector<uint32_t> hh(4096); hipMemcpy(hh.data(), dh, 4 * 4096, hipMemcpyDeviceToHost);
-                        uint32_t nz = 0, tot = 0; for (int b = 0; b < 1024; ++b) { nz += hh[b] != 0; tot += hh[1024 + b]; }
-                        printf("  hist (after the last pass' scan): nonzero offsets %u, sum of totals %u, totals[0..7] %u %u %u %u %u %u %u %u\n", nz, tot, hh[1024], hh[1025], hh[1026], hh[1027], hh[1028], hh[1029], hh[1030], hh[1031]); }
-                    if (0) for (uint32_t i = 0; i < c.n; ++i) printf("  %2u want %016llx got %016llx in %016llx\n", i, (unsigned long long)want[i], (unsigned long long)got[i], (unsigned long long)h[i]); }
+                if (diff) { ++bad; printf("{\"n\": %u, \"plan\": %d, \"first_diff\": %lld}\n", c.n, plan, first); }
             }
             printf("{\"n\": %u, \"loBit\": %d, \"numBits\": %d, \"plan\": %d, \"passes\": %d, \"ms\": %.4f, \"differences\": %lld}\n", c.n, c.loBit, c.numBits, plan,
                    radix_sort_passes(c.n, c.numBits), best, diff);
