@@ -25,6 +25,11 @@ python tools/build_once.py torus1m 4 > $OUT/build_torus1m.jsonl 2>&1
 python tools/build_bench.py bunny torus1m soup10m > $OUT/build_bench.jsonl 2>&1
 python tools/refit_loop.py torus1m 512 60 > $OUT/refit_loop.jsonl 2>&1
 python tools/refit_loop.py bunny16 512 30 >> $OUT/refit_loop.jsonl 2>&1
+python tools/waves_by_grid.py torus1m,bunny16,dragon9,bunny,dragon 128,256,512 > $OUT/waves_by_grid.jsonl 2>&1
+python tools/init_times.py torus1m 512 3 > $OUT/init_times.jsonl 2>&1
+python tools/init_times.py bunny 256 3 >> $OUT/init_times.jsonl 2>&1
+for m in bunny dragon dragon9 bunny16; do python tools/build_once.py $m 3 | tail -1; done > $OUT/build_other_meshes.jsonl 2>&1
+tools/micro/sort_check time 0 8 10 > $OUT/sort_times.jsonl 2>&1
 python tools/cpu_baseline.py > $OUT/cpu_baseline.jsonl 2>&1
 python tools/pcie_bench.py 512 > $OUT/pcie.jsonl 2>&1
 python tools/gpu_soak.py 600 50505 > $OUT/soak_50505.jsonl 2>&1
