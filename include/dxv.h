@@ -141,7 +141,7 @@ DXV_API int dxv_update_vertices(dxv_ctx* ctx, const float* vb, uint32_t num_vert
  *    only the host can act on (a texel with more than 65,535 entries: tree walk) is read when the frame is next
  *    synchronised -- dxv_sync, any dxv_grid_* call, the next dxv_refit -- and a frame launched with lists that fail it is
  *    launched again through the tree there.
- * 1 M triangles at 512^3 from a device buffer: 630 frames/s (four round trips per frame: 576). */
+ * 1 M triangles at 512^3 from a device buffer: 650 - 660 frames/s (four round trips per frame: 576). */
 DXV_API int dxv_update_vertices_device(dxv_ctx* ctx, const void* device_vb, uint32_t num_verts);
 DXV_API int dxv_refit(dxv_ctx* ctx);
 
@@ -273,7 +273,7 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 box are current, the node boxes are written when a tree walk, an export or a debug download first needs them
  *                 (1, default: a refit at 1 M triangles 0.14 -> 0.07 ms); 0 = every refit writes them
  *   lists  0|1|2  reference rule through direction-space lists (dxv_dirmap.h) or the tree walk (0).  The
- *                 lists are built from the scene's triangle records (0.65 ms at 1 M triangles): at the second
+ *                 lists are built from the scene's triangle records (0.59 ms at 1 M triangles): at the second
  *                 launch after a build / refit / import, or at the first when that launch is large enough for
  *                 the build to pay for itself at once -- 2^26 voxels or more and the estimate after the build's
  *                 counting pass says so (1, default: a mesh refitted every frame takes whichever is faster), or
@@ -307,9 +307,12 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   planheavy 0..65535  a brick that can look into a list of more entries than this goes to the front of its queue (0, default: one
  *                 and a half times the scene's mean at the level of a brick's patch of texels; 65535: no brick does)
  *   fuse   0|1    the queue build clears the grid (1, default) or memsets stand in front of it (0)
+ *   queuewaves 0..2^20  persistent waves of a launch through the queue (0, default: what the device holds at once -- 7 per SIMD -- or
+ *                 five / four sevenths of that for a mesh of 500,000 triangles or more on a grid of at most half / a quarter of its
+ *                 lists' map: 256^3 on the 512 map, nothing carried, -13 % for 1 M-triangle meshes)
  *   queueheads 1|2|4|8  heads per queue the persistent waves draw from (default 8)
  *   queuemin 0..4096  persistent waves beyond one per this many bricks of an XCD's share leave before they touch the queue (0,
- *                 default: all stay; 12 helps 1 M-triangle meshes at 256^3 by 11 - 13 % and costs thin ones as much: a caller's knob)
+ *                 default: all stay; a caller's knob from before queuewaves picked its own default on coarse grids)
  *   sortbits 0|8..11 (+16, +32)  diagnostic, process-wide: widest digit of the builds' radix sort (0, default: 10 or 11 bits -- three
  *                 passes for the LBVH's keys, four for the lists'); +16 / +32: tiles of 4 / 16 waves whatever the size.  Same results.
  *   events 0|1    bracket every launch with two HIP events for stats.voxelize_ms (default 1); 0 for a caller that times its own
