@@ -360,20 +360,6 @@ __global__ __launch_bounds__(kThreads) void k_dm_cells(const uint64_t* __restric
     const uint32_t inFace = cell % (R * R);
     entries[i] = dm_local_entry(rc, R, inFace % R, inFace / R, tri);    // the record cut to this texel
 }
-// the far radii the start search of a texel looks at first (dm_search_hints): one thread per texel, after k_dm_cells
-__global__ __launch_bounds__(kThreads) void k_dm_hints(DirCell* __restrict__ cells, uint32_t ncells, const DirEntry* __restrict__ entries)
-{
-    const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= ncells) return;
-    const DirCell cell = cells[c];
-    if (cell.count <= 8u) return;
-    const DirSearchHints h = dm_search_hints(cell.count);
-    auto r1 = [&](uint32_t k) { return (uint16_t)((entries[cell.begin + k].rr >> 16) & 0x7fffu); };
-    cells[c].q2 = r1(h.m2);
-    if (h.has1) cells[c].q1 = r1(h.m1);
-    if (h.has3) cells[c].q3 = r1(h.m3);
-}
-
 // stop codes (dm_stop_code): the list is walked from the far end, carrying the earliest start seen so far.  Short lists
 // (all of a surface mesh's): one thread per texel; long ones (deep scenes: hundreds of entries): one wave per texel, 64
 // entries per step, the running minimum by a prefix scan across the lanes (lane 0 = the entry nearest the far end).
@@ -383,12 +369,23 @@ constexpr uint32_t kStopsShort = 32u;
 // 0.15 ms of the 1.1 ms a 1 M-triangle list build takes)
 // texels with a long list go on k_dm_stops_long's work list (at most n / 33 of them): one thread per texel, one atomic per
 // workgroup of 1024 texels (one per texel on one address: 0.1 ms at 50 k long texels; one per wave of eight texels: 0.5 ms on a soup)
-__global__ __launch_bounds__(1024) void k_dm_long_cells(const DirCell* __restrict__ cells, uint32_t ncells, uint32_t* __restrict__ longCells,
-                                                        uint32_t* __restrict__ longCount)
+// ... in the same launch (one thread per texel, after k_dm_close): the far radii the start search of a texel looks at first
+// (dm_search_hints)
+__global__ __launch_bounds__(1024) void k_dm_hints_and_long_cells(DirCell* __restrict__ cells, uint32_t ncells, const DirEntry* __restrict__ entries,
+                                                                  uint32_t* __restrict__ longCells, uint32_t* __restrict__ longCount)
 {
     __shared__ uint32_t waveCount[16], base;
     const uint32_t c = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const bool isLong = c < ncells && cells[c].count > kStopsShort;
+    DirCell cell{};
+    if (c < ncells) cell = cells[c];
+    if (cell.count > 8u) {
+        const DirSearchHints h = dm_search_hints(cell.count);
+        auto r1 = [&](uint32_t k) { return (uint16_t)((entries[cell.begin + k].rr >> 16) & 0x7fffu); };
+        cells[c].q2 = r1(h.m2);
+        if (h.has1) cells[c].q1 = r1(h.m1);
+        if (h.has3) cells[c].q3 = r1(h.m3);
+    }
+    const bool isLong = cell.count > kStopsShort;
     const unsigned long long m = __ballot(isLong);
     if (lane == 0u) waveCount[w] = (uint32_t)__builtin_popcountll(m);
     __syncthreads();
@@ -713,8 +710,7 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     uint32_t* longCells = reinterpret_cast<uint32_t*>(sorted == keys ? keysTmp : keys);
     k_dm_close<<<(n + kThreads - 1) / kThreads, kThreads, 0, s>>>(sorted, n, R, cells, entries, sums);
     const uint32_t ncells = 6u * R * R;
-    k_dm_hints<<<(ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
-    k_dm_long_cells<<<(ncells + 1023u) / 1024u, 1024, 0, s>>>(cells, ncells, longCells, sums + 1);
+    k_dm_hints_and_long_cells<<<(ncells + 1023u) / 1024u, 1024, 0, s>>>(cells, ncells, entries, longCells, sums + 1);
     k_dm_stops<<<(8u * ncells + kThreads - 1) / kThreads, kThreads, 0, s>>>(cells, ncells, entries);
     k_dm_stops_long<<<4096, 64, 0, s>>>(cells, longCells, sums + 1, entries);
     if ((e = hipMemcpyAsync(longestOut, sums, sizeof(uint32_t), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;

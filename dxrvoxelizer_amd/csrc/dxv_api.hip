@@ -177,6 +177,33 @@ int dxv_create(dxv_ctx** out, int device)
         return fail(nullptr, "dxv_create: hipMalloc failed");
     }
     *out = c;
+    // A process's first build and first launch on a device pay for what the runtime sets up lazily -- the library's code object, the
+    // first host-to-device copy's staging, the kernels' first dispatch: 11 ms for the first Init of a 1 M-triangle mesh against 3.3
+    // for one that follows anything at all (LBVH 1.3 against 0.29 ms, lists 1.6 against 0.95, upload 7 against 0.7).  The first
+    // context of a process on a device therefore sends a four-triangle scene through every step once, on a context of its own that is
+    // gone when dxv_create returns (DXV_WARMUP=0: not at all).  Errors of the warm-up are nobody's: the caller's own calls will report.
+    static std::atomic<uint64_t> warmed{0};
+    const uint64_t bit = 1ull << (device & 63);
+    const char* wu = getenv("DXV_WARMUP");
+    if (!(warmed.fetch_or(bit) & bit) && !(wu && wu[0] == '0')) {
+        dxv_ctx* w = nullptr;
+        if (dxv_create(&w, device) == 0) {
+            static const float vb[4 * 6] = {0.9f, 0.9f, 0.9f, 0.58f, 0.58f, 0.58f,   -0.9f, -0.9f, 0.9f, -0.58f, -0.58f, 0.58f,
+                                            -0.9f, 0.9f, -0.9f, -0.58f, 0.58f, -0.58f,   0.9f, -0.9f, -0.9f, 0.58f, -0.58f, -0.58f};
+            static const uint32_t ib[4 * 3] = {0, 1, 2, 0, 3, 1, 0, 2, 3, 1, 3, 2};
+            if (dxv_set_mesh(w, vb, 4, ib, 4) == 0 && dxv_build(w) == 0 && dxv_build_lists_for_grid(w, 0) == 0) {
+                (void)dxv_voxelize(w, 32, DXV_MODE_REFERENCE, 0, 32);
+                (void)dxv_voxelize(w, 32, DXV_MODE_PARITY, 0, 32);
+                std::vector<uint8_t> host(32 * 32 * 32);
+                (void)dxv_grid_download(w, host.data(), host.size());
+            }
+            std::vector<uint8_t> mb(1u << 20);                       // (a copy of a size the staging path handles in pieces)
+            void* d = nullptr;
+            if (hipMalloc(&d, mb.size()) == hipSuccess) { (void)hipMemcpy(d, mb.data(), mb.size(), hipMemcpyHostToDevice); (void)hipFree(d); }
+            dxv_destroy(w);
+            (void)hipGetLastError();
+        }
+    }
     return 0;
 }
 
