@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """First-in-process cost of a build: (a) cold, (b) after a tiny mesh has gone through the same kernels (code loaded, nothing of the size allocated)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import dxrvoxelizer_amd as dxv
 from dxrvoxelizer_amd import meshes

@@ -3,7 +3,7 @@
 queue (plan = 1, dispatch 0 / 1), and the step with nothing carried (plan = 2), one process, interleaved."""
 import json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import dxrvoxelizer_amd as dxv
 from bench import make_mesh
 
