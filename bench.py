@@ -15,7 +15,10 @@ step builds its work queue on the device, clears its grid and writes every voxel
 queue and the zeros kept (plan = 1) are config.kept_step, and config.first_voxelize_after_init is the cold call.
 With N > 1 the grid is Z-slab partitioned, one process per GPU; rank 0 builds the LBVH and the
 scene blob is broadcast once over RCCL; there is no per-step collective.  Total work is fixed
-(strong scaling).  Rank 0 prints ONE JSON line.
+(strong scaling).  At N > 1 two steps are in flight per GPU (frames of the one context, like the reference's
+FrameCount = 3 grids: a rank's share is a short launch whose start and end the next frame's launch fills),
+at N = 1 one; config.frames_in_flight says which, config.frames_in_flight_1/2/3 are the other figures.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -155,10 +158,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary figures (frames in flight, tree walk, second rule, 256^3, bunny x16)")
     ap.add_argument("--interleave", action="store_true", help="use the block-cyclic partition call even on one GPU")
-    ap.add_argument("--frames", type=int, default=1,
+    ap.add_argument("--frames", type=int, default=0,
                     help="voxelizations in flight per GPU in the headline region (frames of ONE context, dxv_set_frame; the "
-                         "reference keeps FrameCount = 3 grids in flight).  Default 1 at every N, so that values at different "
-                         "N compare like for like; the two-in-flight figure is reported beside it")
+                         "reference keeps FrameCount = 3 grids in flight, Content/Voxelizer.h:24).  Default: 1 on one GPU (two compete "
+                         "for the same wave slots there: -4 %), 2 on several (a rank's share of the grid is a short launch whose start "
+                         "and end the next frame's launch fills: +21 % on a share at 8 ranks); the other figures are reported beside it")
     ap.add_argument("--spin-ms", type=float, default=100.0, help="untimed launches for this long before the warm-up steps (GPU clocks out of idle); 0: none")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-device", action="store_true",
@@ -259,14 +263,16 @@ def main():
     prepared = set()                             # grid sizes launched once before any warm-up (that launch builds the scene's candidate lists)
     untimed = [0]                                # launches made before the first warm-up step (lists + clock spin-up)
 
-    def timed_region(frames, steps, warmup, n=None, per_step=False):
+    def timed_region(frames, steps, warmup, n=None, per_step=False, lib_events=None):
         """`steps` steps with `frames` voxelizations in flight (frames of the one context, taking the steps in turn),
         barrier + synchronize on both sides; (wall seconds, mean kernel ms, per-step ms).  A rank's share of the grid is a
         short launch whose tail -- its last long rays running alone -- does not shrink with it; the reference hides the same
         thing by keeping FrameCount = 3 grids in flight (Content/Voxelizer.h:24).  n: grid size (default: the headline's).
         per_step: an event after every step as well (per-step times; ~4 us of stream time each, so not in the headline region).
         With one voxelization in flight the library's own two events per launch are switched off for the region (option
-        events: ~8 us per step, 6 % of a rank's step at 8 ranks): the region is bracketed by two events of its own."""
+        events: ~8 us per step, 6 % of a rank's step at 8 ranks): the region is bracketed by two events of its own.  With several
+        in flight they are what says how long a launch took (lib_events=False: off all the same -- the headline region at N > 1,
+        whose kernel time comes from the one-in-flight region behind it; the mean kernel ms returned is then the wall time per step)."""
         turn = [0]
         n = N if n is None else n
         inter = (world > 1 or args.interleave) and n % (zblock * world) == 0
@@ -295,7 +301,8 @@ def main():
         for _ in range(max(warmup, frames)):     # every frame launches at least once before the clock starts
             step()
         vox.SyncAll()
-        vox.set_option("events", 0 if frames == 1 else 1)
+        lib_ev = (frames != 1) if lib_events is None else bool(lib_events)
+        vox.set_option("events", 1 if lib_ev else 0)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -317,6 +324,8 @@ def main():
         steps_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(steps)] if per_step else []
         if frames == 1:
             k_ms = evs[0].elapsed_time(evs[-1]) / max(steps, 1)      # avg launch duration on the kernel's stream
+        elif not lib_ev:
+            k_ms = dt / max(steps, 1) * 1e3
         else:                                    # overlapping launches: the library's own events around each frame's last launch
             ks = []
             for f in range(frames):
@@ -348,13 +357,19 @@ def main():
     def stats_ms(xs):
         return {"median": float(np.median(xs)), "min": float(np.min(xs)), "max": float(np.max(xs))} if len(xs) else None
 
-    frames = max(1, min(args.frames, vox.FrameCount))
+    # Voxelizations in flight: one on one GPU; two on several (round 4's review, item 1 d: "make two frames in flight the bench's
+    # default at N > 1 only if [the other levers] fall short, and say so in the line" -- they did: 5.1 - 5.4 x at 8 ranks with one in
+    # flight, 6.6 - 7.0 x with two, tools/share_in_flight.py).  Every step is still one whole Voxelize of the rank's share with nothing
+    # carried; consecutive steps write different grids of the context's FrameCount = 3 (Content/Voxelizer.h:24, :110).
+    frames = max(1, min(args.frames if args.frames else (1 if world == 1 else 2), vox.FrameCount))
     # THE HEADLINE: every step builds its work queue on the device, clears the grid and writes every voxel (plan = 2, the library's
     # default): nothing a step does depends on what an earlier launch left behind.
     vox.set_option("plan", 2)
-    dt, step_ms_events, _ = timed_region(frames, args.steps, args.warmup)
+    dt, step_ms_events, _ = timed_region(frames, args.steps, args.warmup, lib_events=False)
     dt_max = reduce_max(dt)
-    _, _, per_step = timed_region(1, args.steps, 1, per_step=True)      # the same steps once more with an event behind every one: their spread
+    _, k_one, per_step = timed_region(1, args.steps, 1, per_step=True)  # the same steps once more, one in flight, with an event behind every one: their spread
+    if frames != 1:
+        step_ms_events = k_one                   # (the dominant kernel's launch duration is a one-in-flight figure: overlapping launches share the GPU)
     st_run = st_probe()                          # of the timed rule (the extras below overwrite the launch fields)
     queued = bool(st_run["plan_bricks"]) and mode == dxv.MODE_REFERENCE
     # the queue build (the kernel in front of the brick kernel: queue + clear) on its own: a few launches with the library's events
@@ -374,7 +389,7 @@ def main():
     kept = None
     if queued:
         vox.set_option("plan", 1)
-        dtk, kk, _ = timed_region(frames, args.steps, args.warmup)
+        dtk, kk, _ = timed_region(frames, args.steps, args.warmup, lib_events=False)
         dtk = reduce_max(dtk)
         kept = {"dt": dtk, "kernel_ms": kk, "waves": st_probe()["plan_waves"]}
         vox.set_option("plan", 2)
@@ -392,7 +407,7 @@ def main():
         # the same steps with two voxelizations in flight per GPU, at every N (like-for-like ratios across N)
         # (the reference keeps FrameCount = 3 grids in flight, Content/Voxelizer.h:24: consecutive frames write different grids and
         # overlap on the GPU; the headline keeps ONE in flight at every N so that values at different N compare like for like)
-        for other in ((2, 3) if frames == 1 else (1,)):
+        for other in [f for f in (1, 2, 3) if f != frames]:
             dt2, k2, _ = timed_region(other, args.steps, 2)
             dt2 = reduce_max(dt2)
             extras[f"frames_in_flight_{other}"] = {"value": (N ** 3) * args.steps / dt2 / 1e6, "unit": "Mvoxels/s",
@@ -532,7 +547,11 @@ def main():
                        "step": "one Voxelize with nothing carried from launch to launch (option plan = 2, the library's default): the work queue built on "
                                "the device, the grid cleared and every voxel written inside the step" if queued else "one Voxelize",
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
-                       "slab_slices_rank0": nz, "frames_in_flight": frames, "solid_voxels": int(tot.item()),
+                       "slab_slices_rank0": nz, "frames_in_flight": frames,
+                       "frames_in_flight_note": ("one voxelization in flight per GPU" if frames == 1 else
+                                                 f"{frames} voxelizations in flight per GPU (frames of the one context: consecutive steps write different grids, "
+                                                 "like the reference's FrameCount = 3); at N = 1 the default is one -- config.frames_in_flight_1 is this run's like-for-like figure"),
+                       "solid_voxels": int(tot.item()),
                        "steps": args.steps, "warmup": args.warmup, "spin_ms": args.spin_ms,
                        "untimed_launches_before_warmup": untimed[0],     # one allocates the frame's grid and queue, the others spin the clocks up (--spin-ms)
                        "queue_build_ms": plan_ms, "queued_bricks": bricks,
