@@ -18,6 +18,7 @@ namespace dxv {
 namespace {
 constexpr uint32_t kThreads = 256;
 constexpr uint32_t kDmWholeFrom = 16384u;            // footprints of more texels than this are filled by the whole GPU (k_dm_emit_whole)
+constexpr uint32_t kDmWholeMax = 256u;               // ... the first this many of them: the kernel walks their list in every workgroup
 constexpr uint32_t kDmFewTriangles = 300000u;       // up to here the record and key kernels spread their work over more waves (below)
 
 // slot of this lane's item in a list whose length sits in *count: one add per wave for all its lanes with `mine` set (an add per
@@ -287,10 +288,13 @@ __global__ __launch_bounds__(kThreads) void k_dm_emit(const DirRecord* __restric
     const uint32_t area = valid ? (i1 - i0 + 1u) * (j1 - j0 + 1u) : 0u;
     const bool toWhole = area > wholeFrom, toWaves = area > 32u && !toWhole;
     {
-        const uint32_t slot = wave_append(listCounts, toWaves);
-        if (toWaves) lists[slot] = i;
+        // (every workgroup of k_dm_emit_whole walks the whole list: it stays short -- what does not fit gets a wave like the others)
         const uint32_t back = wave_append(listCounts + 1, toWhole);
-        if (toWhole) lists[listWords - 1u - back] = i;
+        const bool whole = toWhole && back < kDmWholeMax;
+        if (whole) lists[listWords - 1u - back] = i;
+        const bool wave = toWaves || (toWhole && !whole);
+        const uint32_t slot = wave_append(listCounts, wave);
+        if (wave) lists[slot] = i;
     }
     if (!valid || area > 32u) return;
     const uint32_t tri = i / 6u, face = i % 6u;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void k_dm_emit_whole(const DirRecord* __r
                                                             const uint32_t* __restrict__ listCounts, const uint32_t* __restrict__ offsets,
                                                             uint32_t R, uint64_t* __restrict__ keys)
 {
-    const uint32_t n = listCounts[1];
+    const uint32_t n = listCounts[1] < kDmWholeMax ? listCounts[1] : kDmWholeMax;
     const DirKeyLayout lay = dm_key_layout(R);
     for (uint32_t h = 0; h < n; ++h) {
         const uint32_t i = lists[listWords - 1u - h], tri = i / 6u, face = i % 6u;

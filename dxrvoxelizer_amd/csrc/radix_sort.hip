@@ -1,9 +1,9 @@
 // radix_sort.hip -- stable LSD radix sort of 64-bit keys on gfx950 (the build's morton << 32 | index keys, the lists' texel | far radius |
 // triangle keys).
 //
-// A field of the key, bits [loBit, loBit + numBits), is sorted in p = ceil(numBits / 10 or 11) passes of equal digits of 8 - 11 bits
-// (30 bits of Morton code: three passes of 10; the lists' 37 bits on the 512 map: four of 10): the passes of a sort of a million
-// keys are bound by their launches, not by bytes, so fewer and wider digits win.  Each pass is
+// A field of the key, bits [loBit, loBit + numBits), is sorted in passes of equal digits of 8 - 11 bits, their width by the number
+// of keys (below): 30 bits of Morton code of a million triangles in three passes of 10, the lists' 37 bits of 6.4 M keys in five
+// of 8, of 150 M keys in four of 10.  Each pass is
 //   histogram (per tile, 2^bits bins)  ->  exclusive scan of every digit's row over the tiles  ->  stable scatter.
 // Three shapes (measured, tools/micro/sort_check.hip): up to 2 M keys tiles of 2048 keys (4 waves x 8 keys per lane) and the fewest
 // passes -- such a sort is bound by its launches and by the chain of dependent steps inside a workgroup, not by bytes; up to 16 M keys

@@ -959,6 +959,44 @@ def test_vertex_upload_overlaps_a_launch_in_flight(dxv, orc, bunny):
 # ---------------------------------------------------------------------------------------------
 # direction-space lists (option lists): the reference rule without a tree walk
 # ---------------------------------------------------------------------------------------------
+def test_lists_of_many_large_footprints_equal_host_lists(dxv, orc, hostcheck):
+    """The list build hands footprints out by size (a thread, a wave each, the whole GPU for the first 256 of more than 16,384 texels,
+    a wave each for the rest): 300 stacked triangles that each cover 143 x 143 texels of the 512 map's +z face -- more "whole"
+    footprints than that list holds -- a few of a whole face (at the grid's centre), and the corner triangles' one-texel ones; the
+    lists are the host's word for word, the grid the tree walk's and the oracle's."""
+    tris, nrm = [], []
+    for k in range(300):
+        d = 0.2 + 0.0026 * k
+        tris += [(-0.28 * d, -0.28 * d, d), (0.28 * d, -0.28 * d, d), (0.0, 0.28 * d, d)]
+        nrm += [(0.0, 0.0, -1.0)] * 3
+    for k in range(6):                                                 # through the centre: whole faces
+        d = 0.002 * (k + 1)
+        tris += [(-0.9, -0.9, -d), (0.9, -0.9, -d), (0.0, 0.9, -d)]
+        nrm += [(0.0, 0.0, 1.0)] * 3
+    for sgn in (-1.0, 1.0):                                            # the bound: [-1, 1]^3 whatever the rest is
+        tris += [(sgn, sgn, sgn), (sgn * 0.999, sgn, sgn), (sgn, sgn * 0.999, sgn)]
+        nrm += [(0.0, 0.0, 1.0)] * 3
+    vb = np.hstack([np.asarray(tris, np.float32), np.asarray(nrm, np.float32)])
+    ib = np.arange(len(vb), dtype=np.uint32)
+    s = orc.Scene(vb, ib)
+    v = dxv.Voxelizer(0)
+    v.set_option("lists", 0)
+    v.InitDynamic(vb, ib)
+    v.Voxelize(64)
+    want = v.Grid().copy()
+    assert np.array_equal(want, s.voxelize(64, algo=orc.ALGO_BVH))
+    v.set_option("listres", 512)
+    v.set_option("lists", 2)
+    v.Voxelize(64)
+    st = v.stats()
+    assert st["list_res"] == 512 and st["list_entries"] > 300 * 16384
+    assert np.array_equal(v.Grid(), want)
+    cells, entries = hostcheck(vb, ib, s.bound).lists(512)
+    assert np.array_equal(v.debug(DBG_LIST_CELLS), cells)
+    assert np.array_equal(v.debug(DBG_LIST_ENTRIES), entries)
+    v.close()
+
+
 @pytest.mark.parametrize("name", ["bunny", "dragon", "turingbowl"])
 def test_lists_equal_tree_walk_and_host_lists(dxv, orc, hostcheck, request, name):
     """Every grid through the lists equals the tree walk's (and the oracle's); the device-built lists
