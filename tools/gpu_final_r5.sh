@@ -28,6 +28,8 @@ python tools/refit_loop.py bunny16 512 30 >> $OUT/refit_loop.jsonl 2>&1
 python tools/waves_by_grid.py torus1m,bunny16,dragon9,bunny,dragon 128,256,512 > $OUT/waves_by_grid.jsonl 2>&1
 python tools/share_in_flight.py torus1m 512 8 4 > $OUT/share_in_flight.jsonl 2>&1
 python tools/share_in_flight.py bunny16 512 8 4 >> $OUT/share_in_flight.jsonl 2>&1
+python tools/share_in_flight.py torus1m 512 8 4 plan=1 > $OUT/share_in_flight_kept.jsonl 2>&1
+python tools/share_in_flight.py bunny16 512 8 4 plan=1 >> $OUT/share_in_flight_kept.jsonl 2>&1
 python tools/init_times.py torus1m 512 3 > $OUT/init_times.jsonl 2>&1
 python tools/init_times.py bunny 256 3 >> $OUT/init_times.jsonl 2>&1
 for m in bunny dragon dragon9 bunny16; do python tools/build_once.py $m 3 | tail -1; done > $OUT/build_other_meshes.jsonl 2>&1
