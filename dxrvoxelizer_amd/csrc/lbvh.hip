@@ -90,12 +90,7 @@ __device__ __forceinline__ void tri_gather(uint32_t i, const float* __restrict__
     tn.n0 = F4{n0[0], n0[1], n0[2], 0.0f};
     tn.n1 = F4{n1[0], n1[1], n1[2], 0.0f};
     tn.n2 = F4{n2[0], n2[1], n2[2], 0.0f};
-#if defined(DXV_EXP_NTB)
-    { typedef float F4v __attribute__((ext_vector_type(4))); F4v* d = reinterpret_cast<F4v*>(&triNrm[i]); const F4v a0 = {tn.n0.x, tn.n0.y, tn.n0.z, tn.n0.w}, a1 = {tn.n1.x, tn.n1.y, tn.n1.z, tn.n1.w}, a2 = {tn.n2.x, tn.n2.y, tn.n2.z, tn.n2.w};
-      __builtin_nontemporal_store(a0, d); __builtin_nontemporal_store(a1, d + 1); __builtin_nontemporal_store(a2, d + 2); }
-#else
     triNrm[i] = tn;
-#endif
     tp.v1.w = __builtin_bit_cast(float, normal_class(a, b, c, tn.n0, tn.n1, tn.n2) << kClassShift);   // spare word of the record
     triPos[i] = tp;
 }
@@ -506,29 +501,15 @@ __global__ __launch_bounds__(kThreads) void k_refit_ranges(const TriPos* __restr
     const Box6 b0 = range_box<DEPTH>(triPos, T, P, pyr, lo, gamma, depthLeaf, pyrD, deep0);
     const Box6 b1 = range_box<DEPTH>(triPos, T, P, pyr, gamma + 1u, hi, depthLeaf, pyrD, deep1);
     float* w = reinterpret_cast<float*>(&nodes[i]);      // words 0..5: child 0 box, 6..11: child 1 box; a refit's links and heights stay
-    uint32_t h0 = 0, h1 = 0;
-#if defined(DXV_EXP_NTB)
-    if (splits && DEPTH) {
-        const uint32_t below = depthNode[i] + 1u;
-        h0 = deep0 - below; h1 = deep1 - below;
-        typedef float F4v __attribute__((ext_vector_type(4)));
-        F4v* d = reinterpret_cast<F4v*>(&nodes[i]);
-        const F4v q0 = {b0.lo[0], b0.lo[1], b0.lo[2], b0.hi[0]}, q1 = {b0.hi[1], b0.hi[2], b1.lo[0], b1.lo[1]}, q2 = {b1.lo[2], b1.hi[0], b1.hi[1], b1.hi[2]};
-        const F4v q3 = {__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1), __builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1)};
-        __builtin_nontemporal_store(q0, d); __builtin_nontemporal_store(q1, d + 1); __builtin_nontemporal_store(q2, d + 2); __builtin_nontemporal_store(q3, d + 3);
-    } else {
-#endif
     w[0] = b0.lo[0]; w[1] = b0.lo[1]; w[2] = b0.lo[2]; w[3] = b0.hi[0]; w[4] = b0.hi[1]; w[5] = b0.hi[2];
     w[6] = b1.lo[0]; w[7] = b1.lo[1]; w[8] = b1.lo[2]; w[9] = b1.hi[0]; w[10] = b1.hi[1]; w[11] = b1.hi[2];
     if (splits) { nodes[i].c0 = c0; nodes[i].c1 = c1; }
+    uint32_t h0 = 0, h1 = 0;
     if (DEPTH) {                                         // a child sits one level below node i; a leaf child has height 0
         const uint32_t below = depthNode[i] + 1u;
         nodes[i].h0 = h0 = deep0 - below;
         nodes[i].h1 = h1 = deep1 - below;
     }
-#if defined(DXV_EXP_NTB)
-    }
-#endif
     if (i == 0u && rootInfo) {                           // rootInfo (k_root_info's words) from the root's own thread: a launch less
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -543,11 +524,7 @@ __global__ __launch_bounds__(kThreads) void k_refit_ranges(const TriPos* __restr
         n.lo0x = b0.lo[0]; n.lo0y = b0.lo[1]; n.lo0z = b0.lo[2]; n.hi0x = b0.hi[0]; n.hi0y = b0.hi[1]; n.hi0z = b0.hi[2];
         n.lo1x = b1.lo[0]; n.lo1y = b1.lo[1]; n.lo1z = b1.lo[2]; n.hi1x = b1.hi[0]; n.hi1y = b1.hi[1]; n.hi1z = b1.hi[2];
         n.c0 = c0; n.c1 = c1; n.h0 = n.h1 = 0;
-#if defined(DXV_EXP_NTB)
-        { const Node32 c32 = compress_node(n); typedef uint32_t U4v __attribute__((ext_vector_type(4))); U4v q[2]; __builtin_memcpy(q, &c32, 32); U4v* d = reinterpret_cast<U4v*>(&nodes32[i]); __builtin_nontemporal_store(q[0], d); __builtin_nontemporal_store(q[1], d + 1); }
-#else
         nodes32[i] = compress_node(n);
-#endif
     }
 }
 
