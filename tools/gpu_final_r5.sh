@@ -46,6 +46,7 @@ if [ -f $Q ]; then
 fi
 tools/micro/l1_roof > $OUT/l1_roof.jsonl 2>&1
 cd /tmp && export TMPDIR=/tmp
+export DXV_WARMUP=0      # (profiles: dxv_create's warm-up launches are not the kernels these averages are about)
 # the timed region alone, so that the kernel's average over this command is the average bench.py itself reports
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $OUT/prof_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_build -- python3 $GRAFT_REPO_ROOT/tools/build_once.py soup10m 3 > $OUT/prof_build.log 2>&1
@@ -71,7 +72,8 @@ for (disp, name), c in sorted(rows.items(), key=lambda kv: int(kv[0][0])):
 print(json.dumps(out, indent=1))
 PY
 find $OUT/prof_bench $OUT/prof_build $OUT/prof_build_torus1m $OUT/prof_refit_loop $OUT/pmc_l1_roof -name "*.csv" -size +4M -delete
-# counter passes (each in its own run, --kernel-trace only beside --pmc)
+unset DXV_WARMUP
+# counter passes (each in its own run, --kernel-trace only beside --pmc; tools/gpu_pmc_quick.sh switches the warm-up off itself)
 export PMC_LAUNCHES=5
 bash tools/gpu_pmc_quick.sh torus1m torus1m 512 > $OUT/pmc_torus1m.log 2>&1
 bash tools/gpu_pmc_quick.sh torus1m_kept torus1m 512 plan=1 > $OUT/pmc_torus1m_kept.log 2>&1

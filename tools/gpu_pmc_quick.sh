@@ -7,6 +7,8 @@ N=${1:-512}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcq/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# (no warm-up pass in dxv_create: its one small launch of the same kernel would be averaged into the per-launch figures)
+export DXV_WARMUP=0
 R=$GRAFT_REPO_ROOT/tools/run_once.py
 run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R $MESH $N ${PMC_LAUNCHES:-4} reference lists=2 $EXTRA > $OUT/$name.log 2>&1; }
 EXTRA="$*"
