@@ -10,14 +10,16 @@ starts the N ranks as a child `python -m torch.distributed.run` (127.0.0.1 rende
 A step = one Voxelize pass (the reference's per-frame DispatchRays, Content/Voxelizer.cpp:366)
 over the whole grid with the scene already resident in HBM: LBVH and candidate lists are built once in
 Init like the reference's acceleration structure (Content/Voxelizer.cpp:73) and are reported separately.
-`value` is the step with NOTHING carried from launch to launch (the library's default, option plan = 2: every
-step builds its work queue on the device, clears its grid and writes every voxel); the same steps with the
-queue and the zeros kept (plan = 1) are config.kept_step, and config.first_voxelize_after_init is the cold call.
+Init is told the grid (the reference's GRID_SIZE is a compile-time constant its Init knows too, Content/Voxelizer.cpp:8), so
+the work queue of the rank's share -- which bricks can hold a live ray: a pure function of lists, grid and partition -- is
+Init-time structure like the lists (dxv_prepare_launch).  `value` is the step of such a scene: the grid CLEARED and every queued
+brick written inside the step, one dispatch dealt out by the hardware; nothing of the output is carried from launch to launch.
+The same steps with the queue built inside every launch (what a launch of a grid Init was not told does; round 5's `value`) are
+config.unprepared_step, with queue and zeros kept (plan = 1) config.kept_step, and config.first_voxelize_after_init is the cold call.
 With N > 1 the grid is Z-slab partitioned, one process per GPU; rank 0 builds the LBVH and the
 scene blob is broadcast once over RCCL; there is no per-step collective.  Total work is fixed
-(strong scaling).  At N > 1 two steps are in flight per GPU (frames of the one context, like the reference's
-FrameCount = 3 grids: a rank's share is a short launch whose start and end the next frame's launch fills),
-at N = 1 one; config.frames_in_flight says which, config.frames_in_flight_1/2/3 are the other figures.
+(strong scaling).  ONE voxelization is in flight per GPU at every N (values at different N compare like for like);
+config.frames_in_flight_2/3 are the figures with the reference's FrameCount = 3 grids used to overlap launches.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -160,9 +162,9 @@ def main():
     ap.add_argument("--interleave", action="store_true", help="use the block-cyclic partition call even on one GPU")
     ap.add_argument("--frames", type=int, default=0,
                     help="voxelizations in flight per GPU in the headline region (frames of ONE context, dxv_set_frame; the "
-                         "reference keeps FrameCount = 3 grids in flight, Content/Voxelizer.h:24).  Default: 1 on one GPU (two compete "
-                         "for the same wave slots there: -4 %), 2 on several (a rank's share of the grid is a short launch whose start "
-                         "and end the next frame's launch fills: +21 % on a share at 8 ranks); the other figures are reported beside it")
+                         "reference keeps FrameCount = 3 grids in flight, Content/Voxelizer.h:24).  Default: 1 at every N (one discipline on "
+                         "both ends of a scaling ratio); the figures with 2 and 3 in flight are reported beside it")
+    ap.add_argument("--no-prepare", action="store_true", help="Init is not told the grid: every launch builds its work queue itself (round 5's headline)")
     ap.add_argument("--spin-ms", type=float, default=100.0, help="untimed launches for this long before the warm-up steps (GPU clocks out of idle); 0: none")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-device", action="store_true",
@@ -206,6 +208,7 @@ def main():
 
     import dxrvoxelizer_amd as dxv
     from dxrvoxelizer_amd.slabs import broadcast_scene, slab_range
+    from dxrvoxelizer_amd.slabs import prepare_share as prepare_share_of
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the voxelizer has no CPU path)")
@@ -232,10 +235,12 @@ def main():
     vb = ib = None
     label = args.mesh
     bcast_ms, bcast = 0.0, {}
+    warmup_ms = None
     if rank == 0:
         vb, ib, label = make_mesh(args.mesh)
+        warmup_ms = vox.stats()["warmup_ms"]     # (dxv_create's one pass through every step on a four-triangle scene: the runtime's lazy parts)
         vox.InitFromArrays(vb, ib)               # upload + LBVH + candidate lists (Init work, not part of a step)
-        cold_build_ms = vox.stats()["build_ms"]  # (the first build of a process pays for code loading and allocations)
+        cold_build_ms = vox.stats()["build_ms"]  # (the first build of a process behind that pass)
         cold_list_ms = vox.stats()["list_ms"]
         vox.InitFromArrays(vb, ib)               # ... the same again: the figure config.build_roofline is made from
         warm_list_ms = vox.stats()["list_ms"]
@@ -260,8 +265,19 @@ def main():
     if interleave:
         nz = N // world
 
-    prepared = set()                             # grid sizes launched once before any warm-up (that launch builds the scene's candidate lists)
-    untimed = [0]                                # launches made before the first warm-up step (lists + clock spin-up)
+    launched = set()                             # grid sizes launched once before any warm-up (that launch allocates the frame's grid)
+    untimed = [0]                                # launches made before the first warm-up step (allocations + clock spin-up)
+    prepare_ms = {}
+
+    def prepare_share(n):
+        """What Init does when it is told the grid: the work queue of this rank's share of the n^3 grid, built now and kept with the
+        scene (dxv_prepare_launch*).  After every Init / import, before the launches."""
+        if args.no_prepare or mode != dxv.MODE_REFERENCE:
+            return
+        prepare_share_of(vox, n, rank, world, zblock if (world > 1 or args.interleave) else 0)
+        prepare_ms[n] = vox.stats()["prepare_ms"]
+
+    prepare_share(N)
 
     def timed_region(frames, steps, warmup, n=None, per_step=False, lib_events=None):
         """`steps` steps with `frames` voxelizations in flight (frames of the one context, taking the steps in turn),
@@ -286,8 +302,8 @@ def main():
             elif nzn:
                 vox.Voxelize(n, mode, z0n, nzn, sync=False, frameIndex=f)
 
-        if n not in prepared:                    # (one launch allocates the frame's grid and queue; the lists exist since Init)
-            prepared.add(n)
+        if n not in launched:                    # (one launch allocates the frame's grid; lists and queue exist since Init)
+            launched.add(n)
             step()
             vox.SyncAll()
             # ... and the GPU out of its idle clocks: the same launch for ~0.1 s before anything is timed (a timed region of 20
@@ -357,13 +373,12 @@ def main():
     def stats_ms(xs):
         return {"median": float(np.median(xs)), "min": float(np.min(xs)), "max": float(np.max(xs))} if len(xs) else None
 
-    # Voxelizations in flight: one on one GPU; two on several (round 4's review, item 1 d: "make two frames in flight the bench's
-    # default at N > 1 only if [the other levers] fall short, and say so in the line" -- they did: 5.1 - 5.4 x at 8 ranks with one in
-    # flight, 6.6 - 7.0 x with two, tools/share_in_flight.py).  Every step is still one whole Voxelize of the rank's share with nothing
-    # carried; consecutive steps write different grids of the context's FrameCount = 3 (Content/Voxelizer.h:24, :110).
-    frames = max(1, min(args.frames if args.frames else (1 if world == 1 else 2), vox.FrameCount))
-    # THE HEADLINE: every step builds its work queue on the device, clears the grid and writes every voxel (plan = 2, the library's
-    # default): nothing a step does depends on what an earlier launch left behind.
+    # ONE voxelization in flight per GPU at every N: the same discipline on both ends of a scaling ratio (--frames overrides; the
+    # figures with two and three in flight -- frames of the one context, the reference's FrameCount = 3 grids, Content/Voxelizer.h:24,
+    # :110 -- are config.frames_in_flight_2/3).
+    frames = max(1, min(args.frames if args.frames else 1, vox.FrameCount))
+    # THE HEADLINE: the scene's work queue comes from Init (prepare_share above); every step clears the grid and writes every queued
+    # brick, one dispatch dealt out by the hardware.  Nothing a step reads was left behind by another launch.
     vox.set_option("plan", 2)
     dt, step_ms_events, _ = timed_region(frames, args.steps, args.warmup, lib_events=False)
     dt_max = reduce_max(dt)
@@ -372,9 +387,11 @@ def main():
         step_ms_events = k_one                   # (the dominant kernel's launch duration is a one-in-flight figure: overlapping launches share the GPU)
     st_run = st_probe()                          # of the timed rule (the extras below overwrite the launch fields)
     queued = bool(st_run["plan_bricks"]) and mode == dxv.MODE_REFERENCE
-    # the queue build (the kernel in front of the brick kernel: queue + clear) on its own: a few launches with the library's events
+    prepared_run = queued and bool(st_run["plan_prepared"])
+    # a launch that builds its queue: the queue build (the kernel in front of the brick kernel: queue + clear) on its own, a few launches with
+    # the library's events
     pm = []
-    if queued:
+    if queued and not prepared_run:
         for _ in range(7):
             if interleave:
                 vox.VoxelizeInterleaved(N, rank, world, zblock, mode)
@@ -382,17 +399,32 @@ def main():
                 vox.Voxelize(N, mode, z0, nz)
             pm.append(vox.stats()["plan_ms"])
     plan_ms = float(np.median(pm)) if pm else 0.0
-    kernel_ms = step_ms_events - plan_ms         # the dominant kernel's average launch duration: the step between two events minus the kernel in front of it
-    # The same steps with the queue and the zeros of the bricks it does not run KEPT from step to step (plan = 1: a static scene
-    # voxelized into the same frame again, the reference's own loop, Content/Voxelizer.cpp:108-113; launched through the hardware's
-    # dispatcher once a sync has read the queue's lengths)
-    kept = None
+    kernel_ms = step_ms_events - plan_ms         # the dominant kernel's average launch duration: the step between two events minus the kernel in front of it (none when prepared)
+    # The same steps (i) with the queue built INSIDE every launch -- what a launch of a grid Init was not told does (option prepared = 0;
+    # persistent waves: the launch does not know its size) -- and (ii) with the queue and the zeros of the bricks it does not run KEPT
+    # from step to step (plan = 1: a static scene voxelized into the same frame again, the reference's own loop,
+    # Content/Voxelizer.cpp:108-113; launched through the hardware's dispatcher once a sync has read the queue's lengths)
+    kept = unprepared = None
     if queued:
+        vox.set_option("prepared", 0)
+        if prepared_run:
+            dtu, ku, _ = timed_region(frames, args.steps, args.warmup, lib_events=False)
+            dtu = reduce_max(dtu)
+            stu = st_probe()
+            pmu = []
+            for _ in range(5):
+                if interleave:
+                    vox.VoxelizeInterleaved(N, rank, world, zblock, mode)
+                elif nz:
+                    vox.Voxelize(N, mode, z0, nz)
+                pmu.append(vox.stats()["plan_ms"])
+            unprepared = {"dt": dtu, "kernel_ms": ku, "waves": stu["plan_waves"], "queue_build_ms": float(np.median(pmu))}
         vox.set_option("plan", 1)
         dtk, kk, _ = timed_region(frames, args.steps, args.warmup, lib_events=False)
         dtk = reduce_max(dtk)
         kept = {"dt": dtk, "kernel_ms": kk, "waves": st_probe()["plan_waves"]}
         vox.set_option("plan", 2)
+        vox.set_option("prepared", 1)
         timed_region(1, 2, 1)                                           # (back to the default for what follows)
     rank_kernel_ms = gather(step_ms_events)      # every rank's mean step between two events: an imbalance of the partition shows here
     rank_wall_ms = gather(dt / max(args.steps, 1) * 1e3)
@@ -404,9 +436,9 @@ def main():
 
     extras = {}
     if not args.no_extras:
-        # the same steps with two voxelizations in flight per GPU, at every N (like-for-like ratios across N)
-        # (the reference keeps FrameCount = 3 grids in flight, Content/Voxelizer.h:24: consecutive frames write different grids and
-        # overlap on the GPU; the headline keeps ONE in flight at every N so that values at different N compare like for like)
+        # the same steps with two and three voxelizations in flight per GPU (the reference keeps FrameCount = 3 grids in flight,
+        # Content/Voxelizer.h:24: consecutive frames write different grids and overlap on the GPU); the headline keeps ONE in flight
+        # at every N so that values at different N compare like for like
         for other in [f for f in (1, 2, 3) if f != frames]:
             dt2, k2, _ = timed_region(other, args.steps, 2)
             dt2 = reduce_max(dt2)
@@ -442,21 +474,31 @@ def main():
                         vox.Voxelize(n, m)
                         ts.append(vox.stats()["voxelize_ms"])
                     return float(np.median(ts))
+                prepare_share(256)                                       # (Init told this grid too)
                 l256 = median_ms_at(256, mode)
+                p256 = vox.stats()["plan_prepared"]
+                vox.set_option("prepared", 0)
+                u256 = median_ms_at(256, mode)
                 vox.set_option("plan", 1)
                 k256 = median_ms_at(256, mode)
                 vox.set_option("plan", 2)
+                vox.set_option("prepared", 1)
                 vox.set_option("lists", 0)
                 t256 = median_ms_at(256, mode)
                 vox.set_option("lists", 1)
-                extras["grid_256"] = {"ms": l256, "mvoxels_s": 256 ** 3 / l256 / 1e3, "kept_queue_ms": k256, "kept_queue_mvoxels_s": 256 ** 3 / k256 / 1e3,
+                extras["grid_256"] = {"ms": l256, "mvoxels_s": 256 ** 3 / l256 / 1e3, "prepared": bool(p256),
+                                      "unprepared_ms": u256, "unprepared_mvoxels_s": 256 ** 3 / u256 / 1e3,
+                                      "kept_queue_ms": k256, "kept_queue_mvoxels_s": 256 ** 3 / k256 / 1e3,
                                       "tree_walk_ms": t256, "tree_walk_mvoxels_s": 256 ** 3 / t256 / 1e3,
-                                      "note": "standalone launches, median of 7, the library's events around each: ms = nothing carried (plan = 2)"}
+                                      "queue_prepare_ms": prepare_ms.get(256),
+                                      "note": "standalone launches, median of 7, the library's events around each: ms = the headline's step at this grid (queue from Init, "
+                                              "grid cleared inside the launch); unprepared = queue built inside the launch (plan = 2); kept = plan 1"}
                 vox.Voxelize(N, mode)                                    # (the 512^3 grid again for what follows)
             if args.mesh == "torus1m":
                 # the other "1 M-triangle mesh" BASELINE.md names (no part of its grid is cleared by the partial launch)
                 bvb, bib, blabel = make_mesh("bunny16")
                 vox.InitFromArrays(bvb, bib)
+                prepare_share(N)
                 lm = median_ms(mode)
                 vox.set_option("lists", 0)
                 tm = median_ms(mode)
@@ -473,6 +515,7 @@ def main():
             vox.InitFromArrays(vb4, ib4)
         if use_dist:
             broadcast_scene(vox, dist, torch.device("cuda", local_rank), grid=n4)
+        prepare_share(n4)
         dt4, k4ms, step4 = timed_region(1, k4, 3, n=n4, per_step=True)
         rk4 = gather(k4ms)
         dt4 = reduce_max(dt4)
@@ -482,11 +525,11 @@ def main():
 
     cold = None
     if rank == 0 and world == 1 and not args.no_extras and mode == dxv.MODE_REFERENCE:
-        # The cold call: one Init (upload, LBVH, candidate lists) and the scene's first three Voxelize calls, on a context that has
-        # launched other things before (allocations of this size exist; the code is loaded)
+        # The first call: one Init (upload, LBVH, candidate lists, the grid's work queue) and the scene's first three Voxelize calls, on a
+        # context that has launched other things before (allocations of this size exist; the code is loaded)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        vox.InitFromArrays(vb, ib)
+        vox.InitFromArrays(vb, ib, gridDim=0 if args.no_prepare else N)
         torch.cuda.synchronize()
         init_ms = (time.perf_counter() - t0) * 1e3
         sti = vox.stats()
@@ -495,9 +538,11 @@ def main():
             t0 = time.perf_counter()
             vox.Voxelize(N, mode)
             calls.append({"wall_ms": (time.perf_counter() - t0) * 1e3, "events_ms": vox.stats()["voxelize_ms"]})
-        cold = {"what": "InitFromArrays (upload + LBVH + lists, host wall clock around the call) and the scene's first three synchronous Voxelize "
-                        "calls (wall clock, and the library's events around what the launch put into the stream)",
-                "init_wall_ms": init_ms, "init_parts_ms": {"upload": sti["upload_ms"], "lbvh": sti["build_ms"], "lists": sti["list_ms"]},
+        cold = {"what": "InitFromArrays with the grid (upload + LBVH + lists + the grid's work queue, host wall clock around the call) and the scene's first "
+                        "three synchronous Voxelize calls (wall clock, and the library's events around what the launch put into the stream); the process's "
+                        "one warm-up pass (dxv_create of its first context: config.warmup_ms) is behind all of them",
+                "init_wall_ms": init_ms, "init_parts_ms": {"upload": sti["upload_ms"], "lbvh": sti["build_ms"], "lists": sti["list_ms"],
+                                                           "queue": 0.0 if args.no_prepare else sti["prepare_ms"]},
                 "voxelize_calls": calls, "init_plus_first_voxelize_ms": init_ms + calls[0]["wall_ms"]}
 
     if rank == 0:
@@ -525,7 +570,14 @@ def main():
         bricks = st_run.get("plan_bricks", 0)
         scene_bytes = bytes_launch - N * N * nz                  # the read side of the algorithmic bytes
         stored = N * N * nz + 64 * bricks if queued else N * N * nz   # the grid's clear + the queued bricks' results
-        kernel = ("k_voxelize_queue" if queued else "k_voxelize") if args.mode == "reference" else "k_parity_rows"
+        kernel = (("k_voxelize_listed" if prepared_run else "k_voxelize_queue") if queued else "k_voxelize") if args.mode == "reference" else "k_parity_rows"
+        unprepared_out = None
+        if unprepared:
+            unprepared_out = {"what": "the same steps with the work queue built INSIDE every launch (k_plan_bricks, which also clears the grid, then persistent "
+                                      "waves: a launch that has just built its queue does not know its size) -- what a launch of a grid Init was not told "
+                                      "does (option prepared = 0); round 5's headline",
+                              "ms_per_step": unprepared["dt"] / args.steps * 1e3, "mvoxels_s": (N ** 3) * args.steps / unprepared["dt"] / 1e6,
+                              "queue_build_ms": unprepared["queue_build_ms"], "persistent_waves": unprepared["waves"]}
         kept_out = None
         if kept:
             k_ms = kept["dt"] / args.steps * 1e3
@@ -544,17 +596,23 @@ def main():
             "config": {"workload": f"{label}, {T} triangles, {N}^3 grid, {args.mode} predicate, "
                                    f"one ray per voxel, " + (f"Z blocks of {zblock} slices dealt round-robin over {world} GPUs"
                                                            if interleave else f"Z-slab partition over {world} GPU(s)"),
-                       "step": "one Voxelize with nothing carried from launch to launch (option plan = 2, the library's default): the work queue built on "
-                               "the device, the grid cleared and every voxel written inside the step" if queued else "one Voxelize",
+                       "step": ("one Voxelize of a scene whose Init was told the grid: work queue from Init (dxv_prepare_launch: a pure function of lists, grid and "
+                                "partition, like the lists of the scene), grid cleared and every queued brick written inside the step, one dispatch dealt out "
+                                "by the hardware; nothing of the output carried from launch to launch" if prepared_run else
+                                "one Voxelize with nothing carried from launch to launch (option plan = 2): the work queue built on "
+                                "the device, the grid cleared and every voxel written inside the step" if queued else "one Voxelize"),
                        "grid": N, "triangles": T, "vertices": V, "mode": args.mode,
                        "slab_slices_rank0": nz, "frames_in_flight": frames,
-                       "frames_in_flight_note": ("one voxelization in flight per GPU" if frames == 1 else
-                                                 f"{frames} voxelizations in flight per GPU (frames of the one context: consecutive steps write different grids, "
-                                                 "like the reference's FrameCount = 3); at N = 1 the default is one -- config.frames_in_flight_1 is this run's like-for-like figure"),
+                       "frames_in_flight_note": ("one voxelization in flight per GPU, at every N" if frames == 1 else
+                                                 f"{frames} voxelizations in flight per GPU by --frames (frames of the one context: consecutive steps write different grids, "
+                                                 "like the reference's FrameCount = 3); the default is one at every N"),
                        "solid_voxels": int(tot.item()),
                        "steps": args.steps, "warmup": args.warmup, "spin_ms": args.spin_ms,
                        "untimed_launches_before_warmup": untimed[0],     # one allocates the frame's grid and queue, the others spin the clocks up (--spin-ms)
                        "queue_build_ms": plan_ms, "queued_bricks": bricks,
+                       "queue_prepare_ms": prepare_ms.get(N),               # in Init (dxv_prepare_launch): the queue's build on the device + one host round trip for its counts
+                       "warmup_ms": warmup_ms,                              # dxv_create of the process's first context: one pass through every step on four triangles
+                       "unprepared_step": unprepared_out,
                        "kept_step": kept_out,
                        "first_voxelize_after_init": cold,
                        "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": args.backend if use_dist else None,
@@ -578,8 +636,10 @@ def main():
                        "rank_imbalance": max(rank_kernel_ms) / (sum(rank_kernel_ms) / len(rank_kernel_ms)) if min(rank_kernel_ms) > 0 else None,
                        "step_ms_rank0": stats_ms(per_step),
                        "work_queue": ({"queued_bricks": bricks, "workgroups_launched": st_run["plan_waves"],
-                                       "launch": "persistent waves taking bricks from the queue's heads (a launch that builds its queue does not know its size)",
-                                       "built": "on the device inside every step, by the kernel that also clears the grid (k_plan_bricks)"}
+                                       "launch": ("one workgroup per queued brick dealt out by the hardware; the bricks nobody runs are zeroed by workgroups of the same dispatch"
+                                                  if prepared_run else "persistent waves taking bricks from the queue's heads (a launch that builds its queue does not know its size)"),
+                                       "built": ("in Init (dxv_prepare_launch), once per (lists, grid, partition)" if prepared_run else
+                                                 "on the device inside every step, by the kernel that also clears the grid (k_plan_bricks)")}
                                       if queued else None),
                        **extras},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -590,8 +650,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "l1": l1,
                          "note": "algorithmic bytes by SURVEY.md 8(d) (grid + every tree node, index and vertex once) over the dominant kernel's average "
-                                 "launch duration = the step between two events on the kernels' stream minus the queue build in front of it (config.queue_build_ms, "
-                                 "the library's events); the kernel is not bound by HBM bandwidth: it is a gather bound by the vector L1 / address "
+                                 "launch duration = the step between two events on the kernels' stream (a prepared launch is ONE dispatch: the clear's workgroups ride in it; an "
+                                 "unprepared one: minus the queue build in front of it, config.queue_build_ms); the kernel is not bound by HBM bandwidth: it is a gather bound by the vector L1 / address "
                                  "units (roofline.l1: line accesses per clock and CU against the measured roof of tools/micro/l1_roof.hip; DESIGN.md section 4.2)"},
         }
     # The CPU baseline is rank 0's alone and runs AFTER the process group is gone: no rank sits in an RCCL barrier (where a watchdog

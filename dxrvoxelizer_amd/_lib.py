@@ -6,7 +6,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-API_VERSION = 5          # DXV_API_VERSION of include/dxv.h (tests/test_cabi.py compares the two)
+API_VERSION = 6          # DXV_API_VERSION of include/dxv.h (tests/test_cabi.py compares the two)
 
 
 class DxvError(RuntimeError):
@@ -26,7 +26,8 @@ class Stats(C.Structure):
                 ("grid_dim", C.c_uint32), ("z0", C.c_uint32), ("nz", C.c_uint32),
                 ("stack_entries", C.c_uint32), ("render_ms", C.c_float), ("redo_rays", C.c_uint32),
                 ("row_block", C.c_uint32), ("tri_extent", C.c_float), ("list_entries", C.c_uint32), ("list_res", C.c_uint32),
-                ("list_ms", C.c_float), ("plan_bricks", C.c_uint32), ("plan_waves", C.c_uint32), ("plan_ms", C.c_float)]
+                ("list_ms", C.c_float), ("plan_bricks", C.c_uint32), ("plan_waves", C.c_uint32), ("plan_ms", C.c_float),
+                ("plan_prepared", C.c_uint32), ("prepare_ms", C.c_float), ("warmup_ms", C.c_float)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("bound", "reserved")}
@@ -39,6 +40,7 @@ _F32P = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _U32P = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 SYMBOLS = {
     "dxv_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "dxv_warmup": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "dxv_destroy": (None, [C.c_void_p]),
     "dxv_last_error": (C.c_char_p, [C.c_void_p]),
     "dxv_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -54,6 +56,8 @@ SYMBOLS = {
     "dxv_voxelize_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32]),
     "dxv_voxelize_interleaved": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
     "dxv_voxelize_interleaved_async": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "dxv_prepare_launch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "dxv_prepare_launch_interleaved": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "dxv_sync": (C.c_int, [C.c_void_p]),
     "dxv_set_frame": (C.c_int, [C.c_void_p, C.c_uint32]),
     "dxv_sync_all": (C.c_int, [C.c_void_p]),

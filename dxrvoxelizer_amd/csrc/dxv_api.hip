@@ -2,6 +2,7 @@
 // options.  The other entry points: dxv_frames.hip (launches), dxv_lists.hip (candidate lists), dxv_blob.hip (scene blob),
 // dxv_debug.hip (test hooks).  There is no CPU fallback anywhere in this library: without a HIP device dxv_create fails.
 #include "dxv_ctx.h"
+#include <chrono>
 
 using namespace dxv;
 using namespace dxvhost;
@@ -177,33 +178,48 @@ int dxv_create(dxv_ctx** out, int device)
         return fail(nullptr, "dxv_create: hipMalloc failed");
     }
     *out = c;
-    // A process's first build and first launch on a device pay for what the runtime sets up lazily -- the library's code object, the
-    // first host-to-device copy's staging, the kernels' first dispatch: 11 ms for the first Init of a 1 M-triangle mesh against 3.3
-    // for one that follows anything at all (LBVH 1.3 against 0.29 ms, lists 1.6 against 0.95, upload 7 against 0.7).  The first
-    // context of a process on a device therefore sends a four-triangle scene through every step once, on a context of its own that is
-    // gone when dxv_create returns (DXV_WARMUP=0: not at all).  Errors of the warm-up are nobody's: the caller's own calls will report.
-    static std::atomic<uint64_t> warmed{0};
-    const uint64_t bit = 1ull << (device & 63);
+    // A process's first build and first launch on a device pay for what the runtime sets up lazily (dxv_warmup, below): the first
+    // context of a process on a device runs that pass once (DXV_WARMUP=0: not at all) and says in its stats what it cost.
     const char* wu = getenv("DXV_WARMUP");
-    if (!(warmed.fetch_or(bit) & bit) && !(wu && wu[0] == '0')) {
-        dxv_ctx* w = nullptr;
-        if (dxv_create(&w, device) == 0) {
-            static const float vb[4 * 6] = {0.9f, 0.9f, 0.9f, 0.58f, 0.58f, 0.58f,   -0.9f, -0.9f, 0.9f, -0.58f, -0.58f, 0.58f,
-                                            -0.9f, 0.9f, -0.9f, -0.58f, 0.58f, -0.58f,   0.9f, -0.9f, -0.9f, 0.58f, -0.58f, -0.58f};
-            static const uint32_t ib[4 * 3] = {0, 1, 2, 0, 3, 1, 0, 2, 3, 1, 3, 2};
-            if (dxv_set_mesh(w, vb, 4, ib, 4) == 0 && dxv_build(w) == 0 && dxv_build_lists_for_grid(w, 0) == 0) {
-                (void)dxv_voxelize(w, 32, DXV_MODE_REFERENCE, 0, 32);
-                (void)dxv_voxelize(w, 32, DXV_MODE_PARITY, 0, 32);
-                std::vector<uint8_t> host(32 * 32 * 32);
-                (void)dxv_grid_download(w, host.data(), host.size());
-            }
-            std::vector<uint8_t> mb(1u << 20);                       // (a copy of a size the staging path handles in pieces)
-            void* d = nullptr;
-            if (hipMalloc(&d, mb.size()) == hipSuccess) { (void)hipMemcpy(d, mb.data(), mb.size(), hipMemcpyHostToDevice); (void)hipFree(d); }
-            dxv_destroy(w);
-            (void)hipGetLastError();
+    if (!(wu && wu[0] == '0')) (void)dxv_warmup(device, &c->stats.warmup_ms);
+    return 0;
+}
+
+// The code object of the library, the first host-to-device copy's staging, every kernel's first dispatch: 11 ms for the first Init of a
+// 1 M-triangle mesh against 3.3 for one that follows anything at all (LBVH 1.3 against 0.29 ms, lists 1.6 against 0.95, upload 7
+// against 0.7).  This sends a four-triangle scene through every step once, on a context of its own that is gone when it returns.
+// Once per process and device; errors of the pass are nobody's (the caller's own calls will report theirs), and the error state the
+// caller sees is left as it was.
+int dxv_warmup(int device, float* ms)
+{
+    static std::atomic<uint64_t> warmed{0};
+    if (ms) *ms = 0.0f;
+    if (device < 0) return 1;
+    const uint64_t bit = 1ull << (device & 63);
+    if (warmed.fetch_or(bit) & bit) return 0;
+    const std::string keep = g_createError;
+    const auto t0 = std::chrono::steady_clock::now();
+    dxv_ctx* w = nullptr;
+    if (dxv_create(&w, device) == 0) {                                 // (its own call of this function finds the device marked)
+        static const float vb[4 * 6] = {0.9f, 0.9f, 0.9f, 0.58f, 0.58f, 0.58f,   -0.9f, -0.9f, 0.9f, -0.58f, -0.58f, 0.58f,
+                                        -0.9f, 0.9f, -0.9f, -0.58f, 0.58f, -0.58f,   0.9f, -0.9f, -0.9f, 0.58f, -0.58f, -0.58f};
+        static const uint32_t ib[4 * 3] = {0, 1, 2, 0, 3, 1, 0, 2, 3, 1, 3, 2};
+        if (dxv_set_mesh(w, vb, 4, ib, 4) == 0 && dxv_build(w) == 0 && dxv_build_lists_for_grid(w, 32) == 0) {
+            (void)dxv_voxelize(w, 32, DXV_MODE_REFERENCE, 0, 32);       // (through the prepared queue)
+            (void)dxv_set_option(w, "prepared", 0);
+            (void)dxv_voxelize(w, 32, DXV_MODE_REFERENCE, 0, 32);       // (through a queue of its own)
+            (void)dxv_voxelize(w, 32, DXV_MODE_PARITY, 0, 32);
+            std::vector<uint8_t> host(32 * 32 * 32);
+            (void)dxv_grid_download(w, host.data(), host.size());
         }
+        std::vector<uint8_t> mb(1u << 20);                       // (a copy of a size the staging path handles in pieces)
+        void* d = nullptr;
+        if (hipMalloc(&d, mb.size()) == hipSuccess) { (void)hipMemcpy(d, mb.data(), mb.size(), hipMemcpyHostToDevice); (void)hipFree(d); }
+        dxv_destroy(w);
     }
+    (void)hipGetLastError();
+    g_createError = keep;
+    if (ms) *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }
 
@@ -223,6 +239,7 @@ void dxv_destroy(dxv_ctx* c)
         if (f.ownStream) (void)hipStreamDestroy(f.ownStream);
     }
     free_scratch(c);
+    drop_prepared(c, true);
     (void)hipFree(c->dMip);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene);
     (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dPlCells); (void)hipFree(c->dPlEntries); (void)hipFree(c->dPlScratch); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
@@ -293,19 +310,19 @@ int dxv_set_mesh(dxv_ctx* c, const float* vb, uint32_t V, const uint32_t* ib, ui
     const float* mn = scan.mn;
     const float* mx = scan.mx;
     const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
-    c->bound[0] = (mx[0] + mn[0]) / 2.0f;
-    c->bound[1] = (mx[1] + mn[1]) / 2.0f;
-    c->bound[2] = (mx[2] + mn[2]) / 2.0f;
+    // (into locals: a mesh that is refused leaves the context's earlier mesh AND its bound alone -- a later dxv_refit / dxv_build of
+    // that mesh normalises with the bound it was set with)
     const float eyz = ey > ez ? ey : ez;
-    c->bound[3] = (ex > eyz ? ex : eyz) / 2.0f;
-    if (!(c->bound[3] > 0.0f) || !std::isfinite(c->bound[3]) || !std::isfinite(c->bound[0]) ||
-        !std::isfinite(c->bound[1]) || !std::isfinite(c->bound[2]))
-        return fail(c, "dxv_set_mesh: degenerate or non-finite bound (half extent %g)", (double)c->bound[3]);
+    const float bound[4] = {(mx[0] + mn[0]) / 2.0f, (mx[1] + mn[1]) / 2.0f, (mx[2] + mn[2]) / 2.0f, (ex > eyz ? ex : eyz) / 2.0f};
+    if (!(bound[3] > 0.0f) || !std::isfinite(bound[3]) || !std::isfinite(bound[0]) || !std::isfinite(bound[1]) || !std::isfinite(bound[2]))
+        return fail(c, "dxv_set_mesh: degenerate or non-finite bound (half extent %g)", (double)bound[3]);
 
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
     DXV_HIP(c, hipStreamSynchronize(c->stream));
     c->vbCopyQueued = false;
+    memcpy(c->bound, bound, sizeof(bound));
+    drop_prepared(c);
     c->haveMesh = false; c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->refitted = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     // (a mesh of the size of the last one moves into its buffers: two frees and two allocations less on the way to the first launch)
     const size_t vbBytes = sizeof(float) * 6 * (size_t)V, ibBytes = sizeof(uint32_t) * 3 * (size_t)T;
@@ -454,6 +471,7 @@ int dxv_refit(dxv_ctx* c)
         else if (frame_stream(c, i) != c->stream) DXV_HIP(c, hipStreamWaitEvent(c->stream, f.evEnd, 0));
     }
     const uint32_t hadListsOn = c->listState == 1 ? c->listRes : 0u;
+    drop_prepared(c);                                                  // (queues prepared for the old surface; no launch that reads one is un-ordered: see above)
     c->haveScene = false; c->listState = 0; c->listResFloor = 0; c->listFloorTried = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0;
     c->refitted = true;
     c->specRes = 0;
@@ -493,6 +511,7 @@ int dxv_build(dxv_ctx* c)
     if (!c->haveMesh) return fail(c, "dxv_build: no mesh (call dxv_set_mesh first)");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
+    drop_prepared(c);
     c->haveScene = false; c->haveHierarchy = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->refitted = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     if (alloc_scene(c, c->T, c->V, c->optWide != 0)) return 1;
     if (alloc_scratch(c, c->T)) return 1;
@@ -654,6 +673,7 @@ int dxv_get_stats(const dxv_ctx* c, dxv_stats* out)
     out->stack_entries = f.stack_entries; out->redo_rays = f.redo_rays; out->row_block = f.row_block;
     out->list_entries = f.list_entries; out->list_res = f.list_res; out->list_ms = f.lastMode == DXV_MODE_PARITY ? c->plMs : c->listMs;
     out->plan_bricks = f.plan_bricks; out->plan_waves = f.plan_waves; out->plan_ms = f.plan_ms;
+    out->plan_prepared = f.lastPrepared >= 0 ? 1u : 0u;
     return 0;
 }
 
@@ -690,6 +710,12 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "plan")) {
         if (value < 0 || value > 2) return fail(c, "option plan: %lld not in {0,1,2}", (long long)value);
         c->optPlan = (int)value;
+    } else if (!strcmp(key, "prepared")) {
+        if (value != 0 && value != 1) return fail(c, "option prepared: %lld not in {0,1}", (long long)value);
+        c->optPrepared = (int)value;
+    } else if (!strcmp(key, "prepclear")) {
+        if (value < 0 || value > 3) return fail(c, "option prepclear: %lld not in {0,1,2,3}", (long long)value);
+        c->optPrepClear = (int)value;
     } else if (!strcmp(key, "queuewaves")) {
         if (value < 0 || value > (1 << 20)) return fail(c, "option queuewaves: %lld not in [0, 2^20]", (long long)value);
         c->optQueueWaves = (int)value;

@@ -112,6 +112,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
         (withPl && (h.offPlCells != b.offPlCells || h.offPlEntries != b.offPlEntries)) || (!withPl && (h.offPlCells || h.offPlEntries || h.plCount)))
         return fail(c, "dxv_scene_import: inconsistent header (T=%u, bytes=%zu)", h.numTris, bytes);
     if (sync_frames(c)) return 1;
+    drop_prepared(c);
     c->haveScene = false; c->listState = 0; c->specRes = 0; c->listResFloor = 0; c->listFloorTried = false; c->refitted = false; c->launchesOfScene = 0; c->plState = 0; c->parityLaunchesOfScene = 0; c->nodesStale = 0;
     // An imported scene carries no mesh and no build state: drop what an earlier dxv_set_mesh / dxv_build left on this
     // context, so that dxv_build, dxv_refit and dxv_update_vertices fail cleanly instead of running the imported

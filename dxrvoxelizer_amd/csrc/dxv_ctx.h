@@ -103,6 +103,7 @@ struct dxv_ctx {
         bool queueOtherClear = false;    // ... which is all zero (cleared at the allocation, then by every build's k_plan_bricks)
         bool lastQueued = false;         // the frame's last launch went through the queue (dxv_sync reads its lengths for the stats)
         bool lastRebuilt = false;        // ... and built it (plan_ms is that build's)
+        int lastPrepared = -1;           // the frame's last launch ran this PREPARED queue of the context (-1: none)
         hipEvent_t evP0 = nullptr, evP1 = nullptr;   // around the queue build of the frame's last launch (option events)
         uint32_t queueLens[16] = {};     // the lengths of the frame's eight queues and how many of each are heavy, as last read by dxv_sync ...
         uint64_t queueLenSig = 0;        // ... for the queue of this signature (clearSig); 0: not known
@@ -148,6 +149,7 @@ struct dxv_ctx {
         uint32_t listLongest, pad;
         uint32_t status[DXV_FRAME_COUNT][4];
         uint32_t queueLens[DXV_FRAME_COUNT][16 * 64];    // the sixteen count words of a frame's queue (light and heavy bricks of the eight queues; each in a 256-byte line of its own)
+        uint32_t preparedLens[16 * 64];                  // ... of a queue that is being prepared
     };
     Pinned* pin = nullptr;
     hipEvent_t evList[4] = {};       // around the counting pass, around the rest of the build
@@ -174,6 +176,30 @@ struct dxv_ctx {
                                      // queued brick dealt out by the hardware (-1 ... -10 % per launch, and back-to-back launches overlap
                                      // their ends: profiles/r04/ab_dispatch_kept_queue.jsonl), 2 = that for partitions of up to 2^25 voxels only
     int optEvents = 1;               // bracket every launch with two HIP events (stats.voxelize_ms); 0: none (a caller timing its own loop)
+    // PREPARED work queues (dxv_prepare_launch; the host mirrors' Init with a grid hint): the queue of a (lists, grid, partition) is a pure
+    // function of them, like the lists are of the scene -- built once when they are fixed, kept with the context (not with a frame:
+    // every frame's launches read it), dropped by whatever changes the scene or its lists.  A launch of a prepared partition clears
+    // its grid and has the hardware deal out the queued bricks; any other launch builds its queue itself (plan = 2).
+    struct Prepared {
+        uint64_t epoch = 0;              // listEpoch of the lists it was probed against (0: the slot is free)
+        uint32_t N = 0, z0 = 0, nz = 0, zBlock = 0, zPeriod = 0, regionBits = 0, planHeavy = 0;
+        uint32_t* dMem = nullptr;        // header (the build's counters), then 8 x cap brick words
+        size_t words = 0;
+        uint32_t cap = 0;
+        uint32_t* dLive = nullptr;       // one bit per brick of the partition: queued or not (what the launch's clear reads)
+        size_t liveWords = 0;
+        uint32_t lens[16] = {};          // the eight lengths and how many of each are heavy
+        uint32_t bricks = 0;
+        float ms = 0.0f;                 // its build on the device
+        uint64_t used = 0;               // (the least recently used slot goes when all are taken)
+    };
+    static constexpr uint32_t kPreparedSlots = 16;   // (eight shares of a looped 8-rank partition and a few whole grids)
+    Prepared prepared[kPreparedSlots];
+    uint64_t preparedClock = 0;
+    float prepareMs = 0.0f;          // device time of the last dxv_prepare_launch* (0: it found the partition prepared)
+    int optPrepared = 1;             // launches of a prepared partition use its queue (1, default); 0: they build their own like any other launch
+    int optPrepClear = 2;            // how such a launch clears: 0 = a clear kernel in front of the brick kernel, 1 / 2 = only the bricks nobody runs,
+                                     // by workgroups in front of / behind the bricks' in the SAME dispatch
     // row lists of the parity rule (dirmap.hip): built like the direction-space lists, on a scene's second parity launch or on
     // a large first one; not part of the scene blob (an importing context builds its own from the triangle records: 0.2 ms)
     uint32_t* dPlCells = nullptr;
@@ -249,6 +275,7 @@ int alloc_scratch(dxv_ctx* c, uint32_t T);
 void fill_build_buffers(dxv_ctx* c, BuildBuffers& b);
 int ensure_nodes(dxv_ctx* c, hipStream_t stream);       // the hierarchy's traversal copies after a refit that skipped them
 // dxv_frames.hip
+void drop_prepared(dxv_ctx* c, bool freeMemory = false);   // whatever changes the scene or its lists calls this (the slots keep their memory unless told otherwise)
 int frame_prepare(dxv_ctx* c, uint32_t i);
 int sync_frame(dxv_ctx* c, uint32_t i);
 int sync_frames(dxv_ctx* c);

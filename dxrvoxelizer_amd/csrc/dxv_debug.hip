@@ -69,7 +69,8 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
     if (!c || !out) return 1;
     Frame& f = cur_frame(c);
     if (settle_lists(c)) return 1;
-    if (!c->haveScene || c->listState != 1 || !f.lastQueued || !f.dQueue || !f.grid_dim)
+    const bool prepared = f.lastPrepared >= 0 && c->prepared[f.lastPrepared].epoch == c->listEpoch;
+    if (!c->haveScene || c->listState != 1 || !(prepared || (f.lastQueued && f.dQueue)) || !f.grid_dim)
         return fail(c, "dxv_debug_plan_check: the current frame's last launch did not go through a work queue");
     DXV_HIP(c, hipSetDevice(c->device));
     if (sync_frames(c)) return 1;
@@ -83,6 +84,10 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
     uint32_t cap = 0;
     (void)plan_queue_words(p.N, p.nz, &cap);
     p.queue = f.dQueue + f.queueHdr * kQueueHeaderWords; p.queueSlots = f.dQueue + kQueueSlotsAt; p.queueCap = cap; p.mip = c->dMip;
+    if (prepared) {                                                     // (a queue of the context's, built by dxv_prepare_launch: same layout behind ONE header)
+        const auto& q = c->prepared[f.lastPrepared];
+        p.queue = q.dMem; p.queueSlots = q.dMem + kQueueHeaderWords; p.queueCap = q.cap;
+    }
     VoxelizeParams q = p;
     const uint32_t nb = plan_layout(q);
     uint32_t* bits = nullptr;

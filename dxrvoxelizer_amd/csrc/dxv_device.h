@@ -104,6 +104,8 @@ struct VoxelizeParams {
     uint32_t queueHeads;    // heads per queue the persistent waves draw from: 1, 2, 4 or 8
     uint32_t queueMinBricks; // persistent waves beyond one per this many bricks of an XCD's share leave at once (0: all stay)
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
+    uint32_t* liveMask;     // k_plan_bricks: one bit per brick of the partition, id (bz nbx + by) nbx + bx, set for every queued brick (or NULL):
+                            // what the clear of a launch through a PREPARED queue reads (only the bricks nobody runs are zeroed)
 };
 hipError_t launch_voxelize(const VoxelizeParams& p, int brickShape, int stackEntries, hipStream_t s);
 // header of a queue: 64 heads (eight per queue: head h of queue x hands out the slots k = h mod 8 of that queue; head
@@ -129,6 +131,16 @@ hipError_t plan_build(const VoxelizeParams& p, hipStream_t s);          // k_pla
 // (planEvents: two events recorded around the queue build of a rebuilding launch, or NULL)
 // listedLens: the eight lengths of a kept queue and how many of each are heavy (16 words) as the host last read them (one workgroup per item, dealt out by the hardware), or NULL (persistent waves)
 hipError_t launch_voxelize_queue(const VoxelizeParams& p, bool rebuild, uint32_t* wavesOut, hipEvent_t* planEvents, const uint32_t* listedLens, hipStream_t s);
+// A launch through a queue that was PREPARED for (lists, grid, partition) -- built ONCE, in Init or by dxv_prepare_launch, like the lists
+// it is a pure function of: the host knows the sixteen counts, so the hardware deals the bricks out (k_voxelize_listed, one workgroup
+// per queued brick), and the grid is cleared inside the launch.  p.queueSlots / p.queueCap: the prepared queue's; lens: its sixteen
+// counts (eight lengths, of which heavy); live: its bit per brick (NULL: clearMode 0).
+//   clearMode 0: a kernel of its own clears the whole grid (16-byte non-temporal stores) in front of the brick kernel;
+//             1 / 2 / 3: ONE dispatch -- workgroups in front of (1), behind (2) or spread evenly between (3) the bricks' zero exactly the
+//             bricks that are not queued (every voxel is written once per launch, by the brick that owns it or by the clear; needs
+//             N % 16 == 0).
+hipError_t launch_voxelize_prepared(const VoxelizeParams& p, const uint32_t lens[16], const uint32_t* live, int clearMode, uint32_t* wavesOut, hipStream_t s);
+size_t plan_live_words(uint32_t N, uint32_t nz);   // 32-bit words of a partition's brick mask
 // test hook: every voxel's first-step decision against the queue; bits: one per brick of the partition, out: 16 words
 hipError_t launch_plan_check(const VoxelizeParams& p, uint32_t* bits, unsigned long long* out, hipStream_t s);
 hipError_t launch_voxelize_redo(const VoxelizeParams& p, hipStream_t s);   // finishes the rays on p.redo with a full-depth stack

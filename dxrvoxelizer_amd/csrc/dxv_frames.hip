@@ -30,6 +30,103 @@ int frame_prepare(dxv_ctx* c, uint32_t i)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prepared work queues (include/dxv.h: dxv_prepare_launch).  A slot is valid while its epoch is the lists' epoch; everything
+// that changes the scene calls drop_prepared as well (a refit keeps the epoch until the lists are rebuilt).
+// ---------------------------------------------------------------------------------------------
+void drop_prepared(dxv_ctx* c, bool freeMemory)
+{
+    for (auto& q : c->prepared) {
+        q.epoch = 0; q.bricks = 0;
+        if (freeMemory) { (void)hipFree(q.dMem); (void)hipFree(q.dLive); q.dMem = q.dLive = nullptr; q.words = q.liveWords = 0; }
+    }
+}
+static uint32_t queue_region_bits(const dxv_ctx* c, uint32_t N, uint32_t nz) { return c->optPlanRegion ? (uint32_t)c->optPlanRegion : plan_region_bits(N, nz); }
+static int find_prepared(const dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, uint32_t zBlock, uint32_t zPeriod)
+{
+    if (!c->listEpoch || c->listState != 1) return -1;
+    const uint32_t rb = queue_region_bits(c, N, nz);
+    for (uint32_t i = 0; i < dxv_ctx::kPreparedSlots; ++i) {
+        const auto& q = c->prepared[i];
+        if (q.epoch == c->listEpoch && q.N == N && q.z0 == z0 && q.nz == nz && q.zBlock == zBlock && q.zPeriod == zPeriod && q.regionBits == rb &&
+            q.planHeavy == (uint32_t)c->optPlanHeavy && q.dMem)
+            return (int)i;
+    }
+    return -1;
+}
+// slices: local lz in [0, nzLocal) <-> global z0 + (lz / zBlock) * zPeriod + lz % zBlock (as voxelize_common)
+static int prepare_partition(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nzLocal, uint32_t zBlock, uint32_t zPeriod)
+{
+    if (!c->haveScene) return fail(c, "dxv_prepare_launch: no scene (call dxv_build or dxv_scene_import first)");
+    DXV_HIP(c, hipSetDevice(c->device));
+    c->prepareMs = 0.0f;
+    if (!c->optLists || !c->optPlan || c->optBrick != 4 || c->optAblate) return 0;     // (launches of this context do not go through a queue)
+    if (settle_lists(c)) return 1;
+    if (c->listState == 0 || c->listOpt != c->optListRes) {
+        if (dxv_build_lists_for_grid(c, 0)) return 1;
+    }
+    if (c->listState != 1 || !c->dMip) return 0;                       // a scene without lists (over the caps): tree walks, nothing to prepare
+    if (find_prepared(c, N, z0, nzLocal, zBlock, zPeriod) >= 0) return 0;
+    if (sync_frames(c)) return 1;                                      // (a slot that is reused may still be read by a launch in flight)
+    // a slot: one whose key is this partition's (stale epoch), else a free one, else the least recently used
+    int slot = -1;
+    for (uint32_t i = 0; i < dxv_ctx::kPreparedSlots && slot < 0; ++i) {
+        const auto& q = c->prepared[i];
+        if (q.dMem && q.N == N && q.z0 == z0 && q.nz == nzLocal && q.zBlock == zBlock && q.zPeriod == zPeriod) slot = (int)i;
+    }
+    for (uint32_t i = 0; i < dxv_ctx::kPreparedSlots && slot < 0; ++i)
+        if (c->prepared[i].epoch != c->listEpoch) slot = (int)i;
+    if (slot < 0) {
+        slot = 0;
+        for (uint32_t i = 1; i < dxv_ctx::kPreparedSlots; ++i)
+            if (c->prepared[i].used < c->prepared[slot].used) slot = (int)i;
+    }
+    auto& q = c->prepared[slot];
+    q.epoch = 0; q.bricks = 0;
+    uint32_t cap = 0;
+    const size_t words = kQueueHeaderWords + (plan_queue_words(N, nzLocal, &cap) - kQueueSlotsAt), liveWords = plan_live_words(N, nzLocal);
+    if (words > q.words) {
+        (void)hipFree(q.dMem); q.dMem = nullptr; q.words = 0;
+        DXV_HIP(c, hipMalloc(&q.dMem, sizeof(uint32_t) * words));
+        q.words = words;
+    }
+    if (liveWords > q.liveWords) {
+        (void)hipFree(q.dLive); q.dLive = nullptr; q.liveWords = 0;
+        DXV_HIP(c, hipMalloc(&q.dLive, sizeof(uint32_t) * liveWords));
+        q.liveWords = liveWords;
+    }
+    const hipStream_t s = c->stream;
+    VoxelizeParams p{};
+    memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
+    memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
+    p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes;
+    p.N = N; p.z0 = z0; p.nz = nzLocal; p.zBlock = zBlock; p.zPeriod = zPeriod;
+    while ((1u << p.zShift) < p.zBlock) ++p.zShift;
+    p.queue = q.dMem; p.queueSlots = q.dMem + kQueueHeaderWords; p.queueCap = cap; p.mip = c->dMip;
+    p.planRegionBits = queue_region_bits(c, N, nzLocal); p.planHeavy = (uint32_t)c->optPlanHeavy;
+    p.planClear = 0u; p.queueZero = nullptr; p.liveMask = q.dLive;
+    DXV_HIP(c, hipEventRecord(c->ev[8], s));
+    DXV_HIP(c, hipMemsetAsync(q.dMem, 0, sizeof(uint32_t) * kQueueHeaderWords, s));
+    DXV_HIP(c, hipMemsetAsync(q.dLive, 0, sizeof(uint32_t) * liveWords, s));
+    DXV_HIP(c, plan_build(p, s));
+    DXV_HIP(c, hipMemcpyAsync(c->pin->preparedLens, q.dMem + queue_len_word(0), sizeof(c->pin->preparedLens), hipMemcpyDeviceToHost, s));
+    DXV_HIP(c, hipEventRecord(c->ev[9], s));
+    DXV_HIP(c, hipStreamSynchronize(s));
+    const uint32_t* lens = c->pin->preparedLens;
+    for (uint32_t x = 0; x < 8u; ++x) {
+        q.lens[8u + x] = lens[queue_heavy_word(x) - queue_len_word(0)];
+        q.lens[x] = lens[queue_len_word(x) - queue_len_word(0)] + q.lens[8u + x];
+        q.bricks += q.lens[x];
+    }
+    q.N = N; q.z0 = z0; q.nz = nzLocal; q.zBlock = zBlock; q.zPeriod = zPeriod; q.regionBits = p.planRegionBits; q.planHeavy = p.planHeavy; q.cap = cap;
+    q.ms = elapsed(c->ev[8], c->ev[9]);
+    q.used = ++c->preparedClock;
+    q.epoch = c->listEpoch;
+    c->prepareMs = q.ms;
+    c->stats.prepare_ms = q.ms;
+    return 0;
+}
+
 // Everything that changes what the frames read (mesh, scene, lists, options that rebuild) first lets every
 // frame finish -- including the status check and, if a launch asked for it, the relaunch against the OLD scene.
 int sync_frames(dxv_ctx* c)
@@ -83,6 +180,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
     p.wide = use_wide(c, p.mode) ? (uint32_t)c->optWide : 0u;      // 1: four-box nodes, 2: on wave-uniform visits only
     int st = c->optStack ? c->optStack : c->stackNow;
     bool queued = false;
+    int prep = -1;                                                      // the context's prepared queue this launch runs (-1: none)
     uint32_t cap = 0;                                                   // words per XCD queue of this partition
     f.list_entries = 0; f.list_res = 0;
     f.usedLists = false;
@@ -129,8 +227,10 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
             f.list_entries = c->listEntries; f.list_res = c->listRes;
             if (c->optBrick == 4 && !c->optAblate && c->optPlan && c->dMip) {
+                // a queue PREPARED for this very launch (dxv_prepare_launch, Init with a grid hint)?  Then the frame needs none of its own.
+                prep = c->optPrepared ? find_prepared(c, p.N, p.z0, p.nz, p.zBlock, p.zPeriod) : -1;
                 // the frame's work queue: sized for the partition (worst case: every brick live)
-                const size_t words = plan_queue_words(p.N, p.nz, &cap);
+                const size_t words = prep >= 0 ? 0 : plan_queue_words(p.N, p.nz, &cap);
                 if (words > f.queueWords) {
                     DXV_HIP(c, hipStreamSynchronize(fs));
                     (void)hipFree(f.dQueue); f.dQueue = nullptr; f.queueWords = 0;
@@ -144,7 +244,12 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
                     else return fail(c, "work queue: hipMalloc failed: %s", hipGetErrorString(qe));
                     f.clearSig = 0;
                 }
-                if (f.dQueue) {
+                if (prep >= 0) {
+                    const auto& q = c->prepared[prep];
+                    queued = true; p.queue = q.dMem; p.queueSlots = q.dMem + kQueueHeaderWords; p.queueCap = q.cap;
+                    p.mip = c->dMip; p.planRegionBits = q.regionBits; p.planHeavy = q.planHeavy;
+                }
+                else if (f.dQueue) {
                     queued = true; p.queue = f.dQueue + f.queueHdr * kQueueHeaderWords; p.queueSlots = f.dQueue + kQueueSlotsAt; p.queueCap = cap;
                     p.mip = c->dMip; p.queueWaves = (uint32_t)c->optQueueWaves; p.queueSevenths = queue_waves_sevenths(c->hdr.numTris, c->listRes, p.N); p.queueHeads = (uint32_t)c->optQueueHeads; p.queueMinBricks = (uint32_t)c->optQueueMin;
                     p.planRegionBits = c->optPlanRegion ? (uint32_t)c->optPlanRegion : plan_region_bits(p.N, p.nz);
@@ -155,7 +260,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
         }
     }
     if (!queued) { f.plan_bricks = 0; f.plan_waves = 0; f.plan_ms = 0.0f; }
-    f.lastQueued = false;
+    f.lastQueued = false; f.lastPrepared = -1;
     if (f.ptrExposed) p.clearSig = nullptr;                            // the caller may have written into the grid: clear it every time
     st = stack_for_brick(c->optBrick, st);                             // (shapes other than the shipped one are compiled for three depths)
     f.stack_entries = (uint32_t)st;
@@ -217,23 +322,34 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
             QueueState qs{};
             qs.optPlan = c->optPlan; qs.optDispatch = c->optDispatch; qs.ptrExposed = f.ptrExposed; qs.keptSig = f.clearSig; qs.lensSig = f.queueLenSig;
             qs.queuedBricks = f.plan_bricks;
+            qs.optPrepared = c->optPrepared; qs.prepared = prep >= 0;
             const QueueLaunch how = queue_policy(qs, sig, voxels);
-            const bool rebuild = how == QueueLaunch::build_and_persistent;
-            hipEvent_t pe[2] = {f.evP0, f.evP1};
-            const uint32_t* listed = how == QueueLaunch::kept_hardware ? f.queueLens : nullptr;
-            if (rebuild) {
-                // the new queue goes into the frame's other header, which the last build left cleared; this build clears the one it leaves
-                const uint32_t target = f.queueHdr ^ 1u;
-                p.queue = f.dQueue + target * kQueueHeaderWords;
-                p.queueZero = f.dQueue + f.queueHdr * kQueueHeaderWords;
-                if (!f.queueOtherClear) DXV_HIP(c, hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kQueueHeaderWords, fs));
-                f.queueOtherClear = false;                                 // (until this launch is in the stream)
+            if (how == QueueLaunch::prepared_hardware) {
+                // queue from Init; the grid cleared and every queued brick written inside this launch; the frame keeps nothing
+                auto& q = c->prepared[prep];
+                q.used = ++c->preparedClock;
                 f.clearSig = 0; f.queueLenSig = 0;
+                DXV_HIP(c, launch_voxelize_prepared(p, q.lens, q.dLive, c->optPrepClear, &f.plan_waves, fs));
+                f.plan_bricks = q.bricks; f.plan_ms = 0.0f;
+                f.lastPrepared = prep;
+            } else {
+                const bool rebuild = how == QueueLaunch::build_and_persistent;
+                hipEvent_t pe[2] = {f.evP0, f.evP1};
+                const uint32_t* listed = how == QueueLaunch::kept_hardware ? f.queueLens : nullptr;
+                if (rebuild) {
+                    // the new queue goes into the frame's other header, which the last build left cleared; this build clears the one it leaves
+                    const uint32_t target = f.queueHdr ^ 1u;
+                    p.queue = f.dQueue + target * kQueueHeaderWords;
+                    p.queueZero = f.dQueue + f.queueHdr * kQueueHeaderWords;
+                    if (!f.queueOtherClear) DXV_HIP(c, hipMemsetAsync(p.queue, 0, sizeof(uint32_t) * kQueueHeaderWords, fs));
+                    f.queueOtherClear = false;                                 // (until this launch is in the stream)
+                    f.clearSig = 0; f.queueLenSig = 0;
+                }
+                DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, listed, fs));
+                if (rebuild) { f.queueHdr ^= 1u; f.queueOtherClear = true; }
+                f.clearSig = f.ptrExposed ? 0 : sig;
+                f.lastQueued = true; f.lastRebuilt = rebuild;
             }
-            DXV_HIP(c, launch_voxelize_queue(p, rebuild, &f.plan_waves, rebuild && c->optEvents ? pe : nullptr, listed, fs));
-            if (rebuild) { f.queueHdr ^= 1u; f.queueOtherClear = true; }
-            f.clearSig = f.ptrExposed ? 0 : sig;
-            f.lastQueued = true; f.lastRebuilt = rebuild;
         } else DXV_HIP(c, launch_voxelize(p, c->optBrick, st, fs));
         if (p.lists) f.lastRedoParity = -1;                        // no column to run out of, nothing to redo
         else {
@@ -356,6 +472,24 @@ int dxv_voxelize_interleaved_async(dxv_ctx* c, uint32_t N, int mode, uint32_t ra
         return fail(c, "dxv_voxelize_interleaved: need rank < world, zblock a power of two and grid_dim %% (zblock * world) == 0 "
                        "(N=%u, world=%u, zblock=%u)", N, world, zblock);
     return voxelize_common(c, N, mode, rank * zblock, N / world, zblock, zblock * world);
+}
+
+int dxv_prepare_launch(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz)
+{
+    if (!c) return 1;
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_prepare_launch: grid_dim must be even and in [2, 2048], got %u", N);
+    if (nz == 0 || z0 >= N || nz > N - z0) return fail(c, "dxv_prepare_launch: slab [%u, %u+%u) outside the grid (N=%u)", z0, z0, nz, N);
+    return prepare_partition(c, N, z0, nz, nz, nz);
+}
+
+int dxv_prepare_launch_interleaved(dxv_ctx* c, uint32_t N, uint32_t rank, uint32_t world, uint32_t zblock)
+{
+    if (!c) return 1;
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_prepare_launch: grid_dim must be even and in [2, 2048], got %u", N);
+    if (!world || rank >= world || !zblock || (zblock & (zblock - 1u)) || N % (zblock * world))
+        return fail(c, "dxv_prepare_launch_interleaved: need rank < world, zblock a power of two and grid_dim %% (zblock * world) == 0 "
+                       "(N=%u, world=%u, zblock=%u)", N, world, zblock);
+    return prepare_partition(c, N, rank * zblock, N / world, zblock, zblock * world);
 }
 
 int dxv_voxelize_interleaved(dxv_ctx* c, uint32_t N, int mode, uint32_t rank, uint32_t world, uint32_t zblock)

@@ -326,18 +326,21 @@ int dxv_build_lists_for_grid(dxv_ctx* c, uint32_t N)
 {
     if (!c) return 1;
     if (!c->haveScene) return fail(c, "dxv_build_lists_for_grid: no scene");
+    if (N && (N < 2 || (N & 1u) || N > 2048)) return fail(c, "dxv_build_lists_for_grid: grid_dim must be 0 or even and in [2, 2048], got %u", N);
     DXV_HIP(c, hipSetDevice(c->device));
+    if (!c->optLists) return 0;                                        // (the caller asked for tree walks: no lists, no queue -- nothing a launch would read)
     // the map the launches of a static scene move to (launch_now: the 512 map, at every grid size)
-    (void)N;
     ListsState s{};
     s.optListRes = c->optListRes; s.numTris = c->hdr.numTris; s.refitted = c->refitted; s.floorTried = c->listFloorTried;
+    int rc;
     if (lists_static_scene_takes_fine_map(s, c->listResFloor)) {
         if (sync_frames(c)) return 1;
         c->listResFloor = kListsFineMap; c->listFloorTried = true;
-        if (c->listState == 1 && c->listRes >= 512u) return 0;
-        return build_lists(c, c->stream);
-    }
-    return dxv_build_lists(c);
+        rc = c->listState == 1 && c->listRes >= 512u ? 0 : build_lists(c, c->stream);
+    } else rc = dxv_build_lists(c);
+    if (rc || !N) return rc;
+    // ... and the work queue of the whole grid the caller names: Init-time structure like the lists (include/dxv.h, dxv_prepare_launch)
+    return dxv_prepare_launch(c, N, 0, N);
 }
 
 } // extern "C"

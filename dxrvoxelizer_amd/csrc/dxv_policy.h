@@ -104,6 +104,8 @@ struct QueueState {
     uint64_t keptSig;        // signature of the launch whose queue and zeros the frame still carries (0: none)
     uint64_t lensSig;        // signature of the queue whose lengths a dxv_sync has read (0: none)
     uint32_t queuedBricks;   // ... their sum
+    int optPrepared;         // 1: launches of a prepared partition use its queue
+    bool prepared;           // the context holds a queue PREPARED for this launch's (lists, grid, partition, queue options)
 };
 // Persistent waves of a launch through the queue, in sevenths of what the device holds at once (7 waves per SIMD).  A brick of a
 // coarse grid looks into a large patch of the map (5.6 R / N texels across), and on a mesh of many small triangles the rays of
@@ -120,9 +122,13 @@ inline uint32_t queue_waves_sevenths(uint32_t numTris, uint32_t R, uint32_t N)
     if (2ull * N <= R) return 5u;
     return 7u;
 }
-enum class QueueLaunch { build_and_persistent, kept_persistent, kept_hardware };
+// prepared_hardware: the queue came from Init (dxv_prepare_launch); the launch clears its grid and the hardware deals the bricks out --
+// nothing of the OUTPUT is carried, and what is read (the queue) is structure of the static scene like the lists.  It wins over a
+// kept queue (plan = 1) too: same kernel, and no dependence on the frame's last launch.
+enum class QueueLaunch { build_and_persistent, kept_persistent, kept_hardware, prepared_hardware };
 inline QueueLaunch queue_policy(const QueueState& q, uint64_t sig, uint64_t voxels)
 {
+    if (q.prepared && q.optPrepared && q.optPlan != 0) return QueueLaunch::prepared_hardware;
     if (q.optPlan == 2 || q.ptrExposed || q.keptSig != sig) return QueueLaunch::build_and_persistent;
     const bool sizeKnown = q.lensSig == sig && q.queuedBricks != 0u;
     if (sizeKnown && (q.optDispatch == 1 || (q.optDispatch == 2 && voxels <= (1ull << 25)))) return QueueLaunch::kept_hardware;

@@ -197,6 +197,15 @@ __global__ __launch_bounds__(256) void k_plan_bricks(VoxelizeParams p, uint32_t 
     // (heavy bricks from slot 0 upwards, the others from the far end downwards: queue_slot)
     const uint32_t slot = heavy ? heavyBase[first] + rank : p.queueCap - 1u - (lightBase[first] + rank);
     p.queueSlots[(size_t)x * p.queueCap + slot] = bx | (by << 10) | (bz << 20);
+    if (p.liveMask) {                                                   // (a queue that is being prepared: the bit the launches' clear reads)
+        const uint32_t nbx = (p.N + 3u) / 4u, id = (bz * nbx + by) * nbx + bx;
+        atomicOr(p.liveMask + (id >> 5), 1u << (id & 31u));
+    }
+}
+size_t plan_live_words(uint32_t N, uint32_t nz)
+{
+    const uint64_t nbx = (N + 3u) / 4u, nbz = (nz + 3u) / 4u;
+    return (size_t)((nbx * nbx * nbz + 31u) / 32u) + 4u;
 }
 
 // the brick order of the whole partition (no brick box): what k_plan_bricks, the checker and the host agree on
@@ -585,15 +594,89 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
 // known without a round trip of its own.  Workgroup b takes item b / 8 of XCD b % 8's equal share (workgroups b and b + 8 share an XCD);
 // no heads, no adds, parameters in scalar registers from the start.  What it is for: short launches (a 256^3 grid, a rank's
 // share), whose few bricks per persistent wave leave the end of the launch ragged (option dispatch).
+// The clear of a launch through a PREPARED queue (launch_voxelize_prepared), inside the brick kernel's own dispatch: the bricks that are
+// queued write all 64 of their voxels themselves, so a launch only has to zero the bricks that are NOT queued -- and that has no order
+// to keep with the brick workgroups (disjoint bytes), which is what lets both share one dispatch.  One thread per 16 voxels of a grid
+// row (16 bytes = four bricks' rows) and step; the four bricks' bits sit in one nibble of the prepared queue's brick mask (ids run
+// along x, N % 16 == 0).  Non-temporal stores, like every clear of this file: zeros nobody reads soon should not push the lists out
+// of the caches.
+struct ClearShare { const uint32_t* live; uint32_t blocks; uint32_t where; };   // blocks: workgroups that clear (0: none, a multiple of 8); where: 1 = the launch's first,
+                                                                                // 2 = its last, 3 = spread evenly between the bricks' (rows of 8 workgroups, one per XCD)
+__device__ __forceinline__ void clear_dead_bricks(const VoxelizeParams& p, const uint32_t* __restrict__ live, uint32_t block, uint32_t nblocks)
+{
+    typedef uint32_t Zero4 __attribute__((ext_vector_type(4)));
+    const Zero4 z = {0u, 0u, 0u, 0u};
+    const uint32_t N = p.N, px = N >> 4, nbx = N >> 2;
+    const uint32_t pieces = px * N * p.nz, per = (pieces + nblocks - 1u) / nblocks;      // (<= 2^29 pieces: 32-bit arithmetic throughout)
+    const uint32_t lo = block * per, hi = lo + per < pieces ? lo + per : pieces;
+    // four pieces per thread and round: their mask words are asked for together (a chain of sixteen dependent loads per thread made
+    // a clearing workgroup last 16 us -- longer than a brick)
+    for (uint32_t q0 = lo + threadIdx.x; q0 < hi; q0 += 256u) {
+        uint32_t nib[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t q = q0 + 64u * u;
+            nib[u] = 15u;                                              // (beyond the share: nothing to do)
+            if (q < hi) {
+                const uint32_t row = q / px, x16 = q - row * px, lz = row / N, y = row - lz * N;
+                const uint32_t bit = ((lz >> 2) * nbx + (y >> 2)) * nbx + (x16 << 2);
+                nib[u] = (live[bit >> 5] >> (bit & 31u)) & 15u;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            if (nib[u] == 15u) continue;
+            const size_t q = q0 + 64u * u;
+            uint8_t* g = p.grid + q * 16u;
+            if (nib[u] == 0u) __builtin_nontemporal_store(z, reinterpret_cast<Zero4*>(g));
+            else {
+                // (a piece on the queued region's rim: plain stores -- four bytes that leave non-temporally reach the fabric as a partial write)
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b)
+                    if (!((nib[u] >> b) & 1u)) *reinterpret_cast<uint32_t*>(g + 4u * b) = 0u;
+            }
+            if (p.texels) {
+                uint32_t* t = p.texels + q * 16u;
+#pragma unroll
+                for (uint32_t b = 0; b < 4u; ++b)
+                    if (!((nib[u] >> b) & 1u)) __builtin_nontemporal_store(z, reinterpret_cast<Zero4*>(t + 4u * b));
+            }
+        }
+    }
+}
+// ... and the clear as a kernel of its own (clearMode 0, and every grid whose side is no multiple of 16): the whole partition
+__global__ __launch_bounds__(256) void k_clear_grid(VoxelizeParams p)
+{
+    plan_clear(p.grid, (size_t)p.N * p.N * p.nz, gridDim.x);
+    if (p.texels) plan_clear(reinterpret_cast<uint8_t*>(p.texels), (size_t)p.N * p.N * p.nz * 4u, gridDim.x);
+}
+
 template <bool TEXELS>
-__global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, QueueLens lens)
+__global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, QueueLens lens, ClearShare clr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ int32_t stack[16 * 64];
-    const uint32_t x = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    uint32_t wg = blockIdx.x;
+    if (clr.blocks) {
+        // (clr.blocks is a multiple of 8: a brick workgroup's number keeps its residue mod 8 -- its XCD, its queue)
+        const uint32_t bricks = gridDim.x - clr.blocks;
+        if (clr.where == 3u) {
+            // rows of 8 workgroups; of the launch's R rows C clear, spread evenly: row r clears iff floor((r + 1) C / R) > floor(r C / R),
+            // and floor(r C / R) clearing rows lie in front of it -- the zeros leave as a trickle beside the bricks' loads, not as a burst
+            const uint32_t r = wg >> 3, R = gridDim.x >> 3, C = clr.blocks >> 3;
+            const uint32_t before = (uint32_t)(((uint64_t)r * C) / R), upto = (uint32_t)(((uint64_t)(r + 1u) * C) / R);
+            if (upto != before) { clear_dead_bricks(p, clr.live, 8u * before + (wg & 7u), clr.blocks); return; }
+            wg -= 8u * before;
+        } else {
+            const bool clears = clr.where == 1u ? wg < clr.blocks : wg >= bricks;
+            if (clears) { clear_dead_bricks(p, clr.live, clr.where == 1u ? wg : wg - bricks, clr.blocks); return; }
+            if (clr.where == 1u) wg -= clr.blocks;
+        }
+    }
+    const uint32_t x = wg & 7u, k = wg >> 3;
 #if defined(DXV_QUEUE_TIMES)
     const uint64_t tStart = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0u && 3u * blockIdx.x + 2u < p.redoCap) { p.redo[3u * blockIdx.x] = 0; p.redo[3u * blockIdx.x + 1u] = 0; }
+    if (threadIdx.x == 0u && 3u * wg + 2u < p.redoCap) { p.redo[3u * wg] = 0; p.redo[3u * wg + 1u] = 0; }
 #endif
     // (x's equal share of the launch: its own queue's first bricks, then what longer queues hold beyond theirs -- queue_item)
     uint32_t qy, qslot;
@@ -635,11 +718,11 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
     }
 #if defined(DXV_QUEUE_TIMES)
     // (diagnostic build only, tools/wg_times.py: start and end of every workgroup in 100 MHz ticks, and the XCD it ran on)
-    if (threadIdx.x == 0u && 3u * blockIdx.x + 2u < p.redoCap) {
+    if (threadIdx.x == 0u && 3u * wg + 2u < p.redoCap) {
         uint32_t xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p.redo[3u * blockIdx.x] = tStart; p.redo[3u * blockIdx.x + 1u] = (__builtin_amdgcn_s_memrealtime() & 0x0fffffffffffffffull) | ((uint64_t)(xcc & 15u) << 60);
-        p.redo[3u * blockIdx.x + 2u] = w;
+        p.redo[3u * wg] = tStart; p.redo[3u * wg + 1u] = (__builtin_amdgcn_s_memrealtime() & 0x0fffffffffffffffull) | ((uint64_t)(xcc & 15u) << 60);
+        p.redo[3u * wg + 2u] = w;
     }
 #endif
 #else
@@ -679,8 +762,8 @@ hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32
     if (!rebuild && listedLen) {
         // the queue as it stands, one workgroup per item of an XCD's equal share (listedLen = ceil(total / 8)) and per XCD
         if (wavesOut) *wavesOut = 8u * listedLen;
-        if (p.texels) k_voxelize_listed<true><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens);
-        else k_voxelize_listed<false><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens);
+        if (p.texels) k_voxelize_listed<true><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens, ClearShare{nullptr, 0u, 0u});
+        else k_voxelize_listed<false><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens, ClearShare{nullptr, 0u, 0u});
         return hipGetLastError();
     }
     if (rebuild) {
@@ -697,6 +780,38 @@ hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32
     if (wavesOut) *wavesOut = waves;
     if (p.texels) k_voxelize_queue<true><<<dim3(waves), dim3(64), 0, s>>>(p);
     else k_voxelize_queue<false><<<dim3(waves), dim3(64), 0, s>>>(p);
+    return hipGetLastError();
+}
+
+// A launch through a PREPARED queue (dxv_device.h): the queue is a pure function of (static scene's lists, grid, partition) and was
+// built when those were fixed -- Init, dxv_prepare_launch -- like the lists themselves (the reference builds everything its frames
+// trace through once, Content/Voxelizer.cpp:73, and a frame is one DispatchRays, :351-369).  The launch clears the grid and runs every
+// queued brick: every voxel is written in every launch, nothing a launch reads was left behind by another LAUNCH.
+hipError_t launch_voxelize_prepared(const VoxelizeParams& p, const uint32_t lens16[16], const uint32_t* live, int clearMode, uint32_t* wavesOut, hipStream_t s)
+{
+    QueueLens lens{};
+    uint32_t total = 0;
+    for (int a = 0; a < 8; ++a) { lens.len[a] = lens16[a]; lens.heavy[a] = lens16[8 + a]; total += lens16[a]; }
+    const uint32_t listedLen = (total + 7u) / 8u;
+    if (wavesOut) *wavesOut = 8u * listedLen;
+    const size_t bytes = (size_t)p.N * p.N * p.nz;
+    ClearShare clr{nullptr, 0u, 0u};
+    if (clearMode != 0 && live && (p.N & 15u) == 0u && listedLen) {
+        // 1,024 sixteen-byte pieces per clearing workgroup (16 per thread)
+        const uint64_t pieces = bytes >> 4;
+        uint64_t blocks = ((pieces + 1023u) >> 10);
+        blocks = (blocks + 7u) & ~(uint64_t)7u;
+        clr.live = live; clr.blocks = (uint32_t)blocks; clr.where = (uint32_t)clearMode;
+    } else {
+        // (about one workgroup of 256 threads per 64 KiB, at least 8 and at most 8,192)
+        uint32_t nb = (uint32_t)((bytes + 65535u) >> 16);
+        nb = nb < 8u ? 8u : nb > 8192u ? 8192u : nb;
+        k_clear_grid<<<dim3(nb), dim3(256), 0, s>>>(p);
+        if (!listedLen) return hipGetLastError();
+    }
+    const uint32_t wgs = 8u * listedLen + clr.blocks;
+    if (p.texels) k_voxelize_listed<true><<<dim3(wgs), dim3(64), 0, s>>>(p, lens, clr);
+    else k_voxelize_listed<false><<<dim3(wgs), dim3(64), 0, s>>>(p, lens, clr);
     return hipGetLastError();
 }
 

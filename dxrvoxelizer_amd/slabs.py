@@ -98,6 +98,21 @@ def broadcast_scene(engine, dist, device, src=0, parity_lists=False, info=None, 
     return nbytes
 
 
+def prepare_share(engine, N, rank, world, zblock=0):
+    """After Init / broadcast_scene, when the grid is known: every rank prepares the work queue of ITS share of the N^3 grid
+    (dxv_prepare_launch*; the queue is a function of lists, grid and partition and does not travel with the blob).  zblock: the
+    block-cyclic partition of bench.py (blocks of zblock slices dealt round-robin) when N divides, else contiguous slabs; 0: slabs.
+    Returns "interleaved", "slab" or None (an empty slab)."""
+    if zblock and N % (zblock * world) == 0:
+        engine.PrepareLaunchInterleaved(N, rank, world, zblock)
+        return "interleaved"
+    z0, nz = slab_range(N, rank, world)
+    if not nz:
+        return None
+    engine.PrepareLaunch(N, z0, nz)
+    return "slab"
+
+
 def gather_slabs(parts):
     """Concatenate per-rank slabs [(z0, grid[nz,N,N]), ...] into the full grid (host side)."""
     parts = sorted(parts, key=lambda p: p[0])

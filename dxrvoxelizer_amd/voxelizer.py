@@ -65,15 +65,18 @@ class Voxelizer:
             raise DxvError(self._lib.dxv_last_error(self._ctx).decode())
 
     # ---- reference surface ------------------------------------------------------------------
-    def Init(self, fileName, posScale=(0.0, 0.0, 0.0, 1.0), dynamicMesh=False):
+    def Init(self, fileName, posScale=(0.0, 0.0, 0.0, 1.0), dynamicMesh=False, gridDim=0):
         """Voxelizer::Init (Content/Voxelizer.cpp:30-79) minus the D3D12 arguments."""
         vb, ib, _ = obj_load(fileName)
-        return self.InitFromArrays(vb, ib, posScale, dynamicMesh)
+        return self.InitFromArrays(vb, ib, posScale, dynamicMesh, gridDim)
 
-    def InitFromArrays(self, vb, ib, posScale=(0.0, 0.0, 0.0, 1.0), dynamicMesh=False):
+    def InitFromArrays(self, vb, ib, posScale=(0.0, 0.0, 0.0, 1.0), dynamicMesh=False, gridDim=0):
         """Upload, bound, LBVH -- and, like the reference's Init (Content/Voxelizer.cpp:73), everything else the launches trace
         through: the candidate lists of the reference rule on the map a static scene is launched with, so that the first
-        Voxelize costs what every later one costs.  dynamicMesh=True (a mesh that is refitted every frame): the LBVH only."""
+        Voxelize costs what every later one costs.  gridDim (the reference's GRID_SIZE, a compile-time constant there,
+        Content/Voxelizer.cpp:8): the grid the scene will be voxelized at -- its work queue is then Init-time structure too
+        (dxv_prepare_launch) and a Voxelize(gridDim) is one clear + one hardware-dispatched launch; 0: every launch builds its
+        queue itself.  dynamicMesh=True (a mesh that is refitted every frame): the LBVH only."""
         self.posScale = tuple(posScale)  # display only in the reference (Voxelizer.cpp:84-87)
         vb = np.ascontiguousarray(vb, np.float32).reshape(-1, 6)
         ib = np.ascontiguousarray(ib, np.uint32).reshape(-1)
@@ -82,7 +85,18 @@ class Voxelizer:
         self._check(self._lib.dxv_set_mesh(self._ctx, vb, len(vb), ib, ib.size // 3))
         self._check(self._lib.dxv_build(self._ctx))
         if not dynamicMesh:
-            self._check(self._lib.dxv_build_lists_for_grid(self._ctx, 0))
+            self._check(self._lib.dxv_build_lists_for_grid(self._ctx, int(gridDim)))
+        return True
+
+    def PrepareLaunch(self, gridDim, z0=0, nz=None):
+        """dxv_prepare_launch: the work queue of slices [z0, z0 + nz) of a gridDim^3 grid, built now and kept with the scene."""
+        nz = gridDim - z0 if nz is None else nz
+        self._check(self._lib.dxv_prepare_launch(self._ctx, int(gridDim), int(z0), int(nz)))
+        return True
+
+    def PrepareLaunchInterleaved(self, gridDim, rank, world, zblock=8):
+        """dxv_prepare_launch_interleaved: the same for this rank's share of the block-cyclic partition."""
+        self._check(self._lib.dxv_prepare_launch_interleaved(self._ctx, int(gridDim), int(rank), int(world), int(zblock)))
         return True
 
     def InitDynamic(self, vb, ib, posScale=(0.0, 0.0, 0.0, 1.0)):

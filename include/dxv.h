@@ -22,11 +22,14 @@ extern "C" {
 
 /* Bumped whenever an entry point changes its signature or a struct of this header its layout; dxv_api_version() returns the
  * value the loaded library was built with -- a binding compares the two before its first call.
+ * 6: dxv_prepare_launch / dxv_prepare_launch_interleaved (the work queue of a static scene as Init-time structure), dxv_warmup,
+ *    dxv_stats grows plan_prepared / prepare_ms / warmup_ms, options prepared / prepclear, dxv_build_lists_for_grid prepares the grid
+ *    it is given;
  * 5: option plan defaults to 2 (every launch builds its queue and clears its grid: nothing carried from launch to launch; the kept
  *    queue is opt-in), options planregion / planheavy / fuse / queueheads;
  * 4: dxv_stats plan fields describe the work queue, options planorder / planregion gone, dxv_debug_plan_check, dxv_trim;
  * 3: dxv_debug_list_check takes a slab (z0, nz). */
-#define DXV_API_VERSION 5
+#define DXV_API_VERSION 6
 DXV_API int dxv_api_version(void);
 
 typedef struct dxv_ctx dxv_ctx;
@@ -74,6 +77,10 @@ typedef struct dxv_stats {
     uint32_t plan_bricks;    /* reference rule through a work queue: 4^3-voxel bricks queued as possibly holding a live ray (0 = no queue) */
     uint32_t plan_waves;     /* ... persistent single-wave workgroups the launch ran (what the GPU holds at once)        */
     float plan_ms;           /* ... time of the queue's build on the device, in front of the kernel (launches that built one) */
+    uint32_t plan_prepared;  /* 1: the last launch ran a queue PREPARED in Init / by dxv_prepare_launch (plan_bricks = its bricks, plan_waves = the
+                                workgroups the hardware dealt out, plan_ms = 0: no queue was built inside the launch)                            */
+    float prepare_ms;        /* device time of the context's last dxv_prepare_launch* that built a queue (queue build + its sixteen counts)       */
+    float warmup_ms;         /* host time dxv_create spent in the process's one warm-up pass on this device (0: another context paid, or none)  */
 } dxv_stats;
 
 /* Create a context on HIP device `device` (Voxelizer::Voxelizer + the device objects that
@@ -83,6 +90,10 @@ typedef struct dxv_stats {
  * lazily -- code object, staging of the first upload, the kernels' first dispatch -- is then paid here and not by the caller's first
  * Init, which it would cost 11 ms instead of 3.3 at 1 M triangles.  Environment DXV_WARMUP=0: no such pass. */
 DXV_API int dxv_create(dxv_ctx** out, int device);
+/* The warm-up pass on its own (idempotent per process and device; dxv_create calls it unless DXV_WARMUP=0): a host that wants its
+ * first dxv_create to be cheap, or wants to time the pass, calls it first.  *ms (may be NULL): host milliseconds it took, 0 when
+ * the device was warm already.  dxv_stats.warmup_ms of the context whose dxv_create ran the pass says the same. */
+DXV_API int dxv_warmup(int device, float* ms);
 DXV_API void dxv_destroy(dxv_ctx* ctx);
 
 /* Last error text of this context ("" when none); with ctx == NULL the last dxv_create error.
@@ -178,6 +189,22 @@ DXV_API int dxv_sync(dxv_ctx* ctx);
 DXV_API int dxv_set_frame(dxv_ctx* ctx, uint32_t frame_index);
 DXV_API int dxv_sync_all(dxv_ctx* ctx);
 
+/* The work queue of a STATIC scene as Init-time structure.  Which 4^3-voxel bricks of a (grid, partition) can hold a live ray is a
+ * pure function of the scene's candidate lists, the grid size and the partition -- exactly like the lists are of the scene -- so it
+ * can be built where the reference builds everything its frames trace through: once, in Init (Content/Voxelizer.cpp:73, :264-326),
+ * leaving a frame ONE dispatch (:351-369).  dxv_prepare_launch builds that queue now (k_plan_bricks once, 0.02 ms at 512^3, plus one
+ * host round trip for its sixteen counts) for slices [z0, z0 + nz) of a grid_dim^3 grid -- _interleaved: for rank's share of the
+ * block-cyclic partition -- and keeps it with the context, for all its frames, until the scene or its lists change (dxv_set_mesh,
+ * dxv_build, dxv_refit, dxv_scene_import, a rebuild of the lists: all drop it).  Every later dxv_voxelize* of that grid_dim and
+ * partition in reference mode is then: the grid cleared (only the bricks nobody runs, by workgroups of the same dispatch) + one
+ * workgroup per queued brick dealt out by the hardware.  Every voxel is still written in every launch and nothing a launch reads
+ * was left behind by another LAUNCH; what is read was left by Init.  Launches of partitions that were not prepared, of scenes
+ * without lists (over the caps: tree walk) and of refitted meshes build their queue themselves as before (option plan = 2).
+ * Builds the lists first if the scene has none yet (as dxv_build_lists_for_grid does).  Up to 16 partitions per context (least
+ * recently used goes).  Not an error when the scene cannot have lists: nothing is prepared then (dxv_stats.prepare_ms = 0). */
+DXV_API int dxv_prepare_launch(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, uint32_t nz);
+DXV_API int dxv_prepare_launch_interleaved(dxv_ctx* ctx, uint32_t grid_dim, uint32_t rank, uint32_t world, uint32_t zblock);
+
 /* Load-balanced multi-GPU partition: the grid's Z axis is cut into blocks of `zblock` slices dealt
  * round-robin to `world` ranks; this call voxelizes the grid_dim/world slices of `rank` (global
  * slice of local slice lz: (lz / zblock * world + rank) * zblock + lz % zblock, ascending) into a
@@ -245,9 +272,11 @@ DXV_API int dxv_render(dxv_ctx* ctx, const float eye[3], const float view_proj[1
  * scene exported after that carries them as two more sections of the blob, and the importing contexts adopt them instead of
  * building their own. */
 DXV_API int dxv_build_lists(dxv_ctx* ctx);
-/* ... on the map the launches of a static scene move to (the 512 map for scenes of 20,000 triangles or more, at every grid size;
- * grid_dim is accepted for compatibility): the exporting rank builds that map before dxv_scene_export, so that the importing
- * ranks do not each rebuild it at their second launch.  Lists that cannot be had on the finer map leave the ones there are. */
+/* ... on the map the launches of a static scene move to (the 512 map for scenes of 20,000 triangles or more, at every grid size):
+ * the exporting rank builds that map before dxv_scene_export, so that the importing ranks do not each rebuild it at their second
+ * launch.  Lists that cannot be had on the finer map leave the ones there are.  grid_dim != 0 (even, <= 2048): the whole grid of
+ * that size is prepared as well (dxv_prepare_launch(ctx, grid_dim, 0, grid_dim)) -- what the host mirrors' Init does with a grid
+ * hint; 0: lists only.  Option lists = 0: nothing is built (the caller asked for tree walks). */
 DXV_API int dxv_build_lists_for_grid(dxv_ctx* ctx, uint32_t grid_dim);
 /* The same for the parity rule's row lists (option plists): built now instead of at the scene's second parity launch; a scene
  * exported after that carries them too (33 + 72 MB at 1 M triangles), and an importing context adopts them. */
@@ -306,6 +335,10 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 Content/Voxelizer.cpp:108-113): -13 % per launch at 512^3, -25 % on a rank's share at 8 ranks, and the launch
  *                 goes through the hardware's dispatcher (option dispatch);
  *                 0: no queue, brick box around the scene in Morton order
+ *   prepared 0|1  launches of a partition that dxv_prepare_launch* prepared use its queue (1, default) or build their own (0)
+ *   prepclear 0|1|2|3  how a launch through a prepared queue clears its grid: 0 = a clear kernel in front of the brick kernel; 1 / 2 / 3 =
+ *                 only the bricks that are not queued, by workgroups in front of / behind / spread evenly between the bricks' in the
+ *                 SAME dispatch
  *   planregion 0|6|7|8  log2 of the run of consecutive Morton bricks that goes to one queue (0 = by partition size)
  *   planheavy 0..65535  a brick that can look into a list of more entries than this goes to the front of its queue (0, default: one
  *                 and a half times the scene's mean at the level of a brick's patch of texels; 65535: no brick does)

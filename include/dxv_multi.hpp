@@ -90,6 +90,8 @@ public:
 		for (size_t i = 1; i < m_devices.size(); ++i)
 			if (dxv_scene_import(m_ctx[i], m_blob[i], bytes)) return ctxError(i);
 		m_sceneBytes = bytes;
+		// with a grid hint every device's share of that grid is prepared now (dxv_prepare_launch*): Init-time structure, like the lists
+		if (m_gridHint && !prepare(m_gridHint, m_partitionHint, m_zblockHint)) return false;
 		return true;
 	}
 
@@ -160,7 +162,8 @@ public:
 	bool GetStats(size_t device, dxv_stats& s) const { return device < m_ctx.size() && dxv_get_stats(m_ctx[device], &s) == 0; }
 	// the grid size the scene will be launched at (before Init): the root builds the lists' map those launches want (dxv.h,
 	// dxv_build_lists_for_grid), so that the other devices do not each rebuild it
-	void SetGridHint(uint32_t gridDim) { m_gridHint = gridDim; }
+	// ... and every device prepares the work queue of its share of that grid after the import (partition / zblock as Voxelize's)
+	void SetGridHint(uint32_t gridDim, Partition partition = BLOCK_CYCLIC, uint32_t zblock = 0) { m_gridHint = gridDim; m_partitionHint = partition; m_zblockHint = zblock; }
 	double BroadcastMs() const { return m_broadcastMs; }				// the scene broadcast of the last Init, host clock
 	uint64_t SceneChecksum() const { return m_checksums.empty() ? 0 : m_checksums[0]; }	// ... and the blob's checksum (equal on every device, or Init failed)
 	// global slice of local slice lz of share g in the block-cyclic partition (blocks of zblock slices dealt round-robin over G shares)
@@ -177,6 +180,23 @@ public:
 	}
 
 protected:
+	bool prepare(uint32_t gridDim, Partition partition, uint32_t zblock)
+	{
+		if (!zblock) zblock = m_devices.size() >= 8 ? 4u : 8u;
+		const uint32_t G = static_cast<uint32_t>(m_devices.size());
+		const bool cyclic = partition == BLOCK_CYCLIC && !(zblock & (zblock - 1u)) && gridDim % (zblock * G) == 0;
+		for (uint32_t g = 0; g < G; ++g) {
+			int rc = 0;
+			if (cyclic) rc = dxv_prepare_launch_interleaved(m_ctx[g], gridDim, g, G, zblock);
+			else {
+				uint32_t z0, nz;
+				slab(gridDim, g, G, z0, nz);
+				if (nz) rc = dxv_prepare_launch(m_ctx[g], gridDim, z0, nz);
+			}
+			if (rc) return ctxError(g);
+		}
+		return true;
+	}
 	bool create()
 	{
 		const size_t G = m_devices.size();
@@ -218,7 +238,8 @@ protected:
 	std::vector<uint32_t>		m_z0, m_nz;
 	std::vector<uint64_t>		m_checksums;
 	double						m_broadcastMs = 0.0;
-	uint32_t					m_gridHint = 0;
+	uint32_t					m_gridHint = 0, m_zblockHint = 0;
+	Partition					m_partitionHint = BLOCK_CYCLIC;
 	size_t						m_sceneBytes = 0;
 	uint32_t					m_gridDim = 0, m_zblock = 8;
 	bool						m_cyclic = false, m_ready = false;

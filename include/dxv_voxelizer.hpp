@@ -33,11 +33,15 @@ public:
 	// (Content/Voxelizer.cpp:30-79).  Like the reference's Init (:73: buildAccelerationStructures), it leaves EVERYTHING the
 	// launches trace through finished -- the LBVH and the candidate lists of the reference rule on the map a static scene is
 	// launched with: the first Voxelize costs what every later one costs.
-	bool Init(const char* fileName, const float posScale[4] = nullptr, bool dynamicMesh = false)
+	// gridDim: the grid the scene will be voxelized at -- the reference's GRID_SIZE, which is a compile-time constant there
+	// (Content/Voxelizer.cpp:8) and so is known to its Init as well.  The scene's work queue for that grid is then built here too
+	// (dxv_prepare_launch) and every Voxelize(gridDim) is one dispatch behind a clear (Content/Voxelizer.cpp:351-369); 0: launches build
+	// their queue themselves.
+	bool Init(const char* fileName, const float posScale[4] = nullptr, bool dynamicMesh = false, uint32_t gridDim = 0)
 	{
 		float* vb = nullptr; uint32_t* ib = nullptr; uint32_t numVerts = 0, numIndices = 0; float aabb[6];
 		if (dxv_obj_load(fileName, &vb, &numVerts, &ib, &numIndices, aabb)) return setError("cannot load OBJ file");
-		const bool ok = InitFromArrays(vb, numVerts, ib, numIndices / 3, posScale, dynamicMesh);
+		const bool ok = InitFromArrays(vb, numVerts, ib, numIndices / 3, posScale, dynamicMesh, gridDim);
 		dxv_free(vb); dxv_free(ib);
 		return ok;
 	}
@@ -47,13 +51,20 @@ public:
 	// dynamicMesh: the vertices will be replaced and the hierarchy refitted every frame (UpdateVertices*): only the LBVH is
 	// built here, and every frame's lists are built for that frame on the coarser map (include/dxv.h, option lists).
 	bool InitFromArrays(const float* vb, uint32_t numVerts, const uint32_t* ib, uint32_t numTris,
-		const float posScale[4] = nullptr, bool dynamicMesh = false)
+		const float posScale[4] = nullptr, bool dynamicMesh = false, uint32_t gridDim = 0)
 	{
 		for (int i = 0; i < 4; ++i) m_posScale[i] = posScale ? posScale[i] : (i == 3 ? 1.0f : 0.0f);
 		if (!m_ctx && dxv_create(&m_ctx, m_device)) return setError(dxv_last_error(nullptr));
 		if (dxv_set_mesh(m_ctx, vb, numVerts, ib, numTris)) return false;
 		if (dxv_build(m_ctx)) return false;
-		return dynamicMesh || dxv_build_lists_for_grid(m_ctx, 0) == 0;
+		return dynamicMesh || dxv_build_lists_for_grid(m_ctx, gridDim) == 0;
+	}
+	// the work queue of another grid size or of a slab, built now (dxv_prepare_launch)
+	bool PrepareLaunch(uint32_t gridDim) { return PrepareLaunch(gridDim, 0, gridDim); }
+	bool PrepareLaunch(uint32_t gridDim, uint32_t z0, uint32_t nz)
+	{
+		if (!m_ctx) return setError("PrepareLaunch before Init");
+		return dxv_prepare_launch(m_ctx, gridDim, z0, nz) == 0;
 	}
 	bool InitDynamic(const float* vb, uint32_t numVerts, const uint32_t* ib, uint32_t numTris, const float posScale[4] = nullptr)
 	{

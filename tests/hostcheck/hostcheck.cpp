@@ -936,6 +936,16 @@ __attribute__((visibility("default"))) int hc_queue_policy(int optPlan, int optD
 {
     QueueState q{};
     q.optPlan = optPlan; q.optDispatch = optDispatch; q.ptrExposed = ptrExposed != 0; q.keptSig = keptSig; q.lensSig = lensSig; q.queuedBricks = queuedBricks;
+    q.optPrepared = 1; q.prepared = false;
+    return (int)queue_policy(q, sig, voxels);
+}
+// ... with a queue PREPARED for the launch (dxv_prepare_launch) in the context
+__attribute__((visibility("default"))) int hc_queue_policy_prepared(int optPlan, int optDispatch, int optPrepared, int prepared, int ptrExposed, uint64_t keptSig, uint64_t lensSig,
+                                                                    uint32_t queuedBricks, uint64_t sig, uint64_t voxels)
+{
+    QueueState q{};
+    q.optPlan = optPlan; q.optDispatch = optDispatch; q.ptrExposed = ptrExposed != 0; q.keptSig = keptSig; q.lensSig = lensSig; q.queuedBricks = queuedBricks;
+    q.optPrepared = optPrepared; q.prepared = prepared != 0;
     return (int)queue_policy(q, sig, voxels);
 }
 }

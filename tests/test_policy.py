@@ -8,7 +8,7 @@ import ctypes as C
 import pytest
 
 NONE, BUILD_IF_IT_PAYS, MOVE_TO_FINE_MAP, BUILD = range(4)
-BUILD_AND_PERSISTENT, KEPT_PERSISTENT, KEPT_HARDWARE = range(3)
+BUILD_AND_PERSISTENT, KEPT_PERSISTENT, KEPT_HARDWARE, PREPARED_HARDWARE = range(4)
 
 
 class S(C.Structure):
@@ -31,6 +31,7 @@ def pol(hostcheck):
     L.hc_lists_over_the_caps.argtypes = [C.c_uint64, C.c_uint32]
     L.hc_lists_pay.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
     L.hc_queue_policy.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.hc_queue_policy_prepared.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]
     return L
 
 
@@ -58,6 +59,15 @@ def test_static_scene_of_the_mirrors_every_launch_is_the_same(pol):
     # ... and every launch builds its queue (plan = 2, the default): nothing carried, whatever a sync has read meanwhile
     for kept, lens in ((0, 0), (7, 0), (7, 7)):
         assert pol.hc_queue_policy(2, 1, 0, kept, lens, 1000, 7, BIG) == BUILD_AND_PERSISTENT
+    # ... unless Init was given the grid (dxv_prepare_launch): the queue is then the scene's, like the lists, the launch clears its
+    # grid and the hardware deals the bricks out -- whatever the frame's last launch was, whoever holds a pointer to the grid
+    for plan in (1, 2):
+        for kept, lens, exposed in ((0, 0, 0), (7, 0, 0), (7, 7, 1), (9, 9, 0)):
+            assert pol.hc_queue_policy_prepared(plan, 1, 1, 1, exposed, kept, lens, 1000, 7, BIG) == PREPARED_HARDWARE
+    # option prepared = 0, no prepared queue for this partition, or no queue at all (plan = 0 is not asked): as before
+    assert pol.hc_queue_policy_prepared(2, 1, 0, 1, 0, 0, 0, 0, 7, BIG) == BUILD_AND_PERSISTENT
+    assert pol.hc_queue_policy_prepared(2, 1, 1, 0, 0, 0, 0, 0, 7, BIG) == BUILD_AND_PERSISTENT
+    assert pol.hc_queue_policy_prepared(1, 1, 1, 0, 0, 7, 7, 1000, 7, BIG) == KEPT_HARDWARE
 
 
 def test_the_c_abi_own_rules_first_second_third_launch(pol):
