@@ -842,8 +842,8 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
         else {
             // direction, 1 / d, -o / d (hlsl:52 and the slab constants): only now, after the scan of the short lists of a
             // surface mesh is over -- two waves in five never get here, and the scan runs with a dozen registers less
-            finish_ray_reference(r);
-            ray_shear(r);                                               // (here, not at the first triangle: the direction's registers are free through the tests)
+            finish_ray_reference(r, rho);                               // (|o| is the ray's start radius: the same expression, dm_ray_point)
+            ray_shear_finished(r);                                      // (here, not at the first triangle: the direction's registers are free through the tests)
             // Every lane takes its queued triangles in turn, but looks at an item's near radius once more first: what starts
             // beyond a hit found since it was queued is dropped unfetched, so a round is one triangle for every lane that
             // still has a live item (the most loaded lane of a wave decides how many rounds there are).

@@ -82,11 +82,30 @@ DXV_HD void ray_shear(Ray& r)
     r.Sy = sel3(r.dx, r.dy, r.dz, ky) / dkz;
     r.Sz = 1.0f / dkz;
 }
+// the same for a ray whose 1 / d is in place (finish_ray_reference): 1 / d[kz] is one of its three words -- the same operation on the
+// same operand, bit for bit -- so the third division is a select
+DXV_HD void ray_shear_finished(Ray& r)
+{
+    int kz = 0;
+    float m = abs_(r.dx);
+    if (abs_(r.dy) > m) { kz = 1; m = abs_(r.dy); }
+    if (abs_(r.dz) > m) { kz = 2; }
+    int kx = kz == 2 ? 0 : kz + 1;
+    int ky = kx == 2 ? 0 : kx + 1;
+    const float dkz = sel3(r.dx, r.dy, r.dz, kz);
+    if (dkz < 0.0f) { const int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = sel3(r.dx, r.dy, r.dz, kx) / dkz;
+    r.Sy = sel3(r.dx, r.dy, r.dz, ky) / dkz;
+    r.Sz = sel3(r.ivx, r.ivy, r.ivz, kz);
+}
 
 // Reference mode: direction = normalize(pos) (hlsl:52); canonical form p / sqrtf((xx+yy)+zz).
-DXV_HD void finish_ray_reference(Ray& r)
+// len: |o| = sqrtf((ox ox + oy oy) + oz oz) when the caller holds it already (the lists' first step computes it as the ray's start radius,
+// dm_ray_point: the same expression), else negative
+DXV_HD void finish_ray_reference(Ray& r, float lenKnown = -1.0f)
 {
-    const float len = __builtin_sqrtf((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz);
+    const float len = lenKnown >= 0.0f ? lenKnown : __builtin_sqrtf((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz);
     r.dx = r.ox / len; r.dy = r.oy / len; r.dz = r.oz / len;
     r.ivx = 1.0f / r.dx; r.ivy = 1.0f / r.dy; r.ivz = 1.0f / r.dz;
     r.nox = -(r.ox * r.ivx); r.noy = -(r.oy * r.ivy); r.noz = -(r.oz * r.ivz);

@@ -76,9 +76,13 @@ def test_two_real_ranks_on_one_gpu_through_the_launcher(grids_json):
     # the broadcast was timed and every rank's copy of the blob checked against the source's; the no-carried-state step is in the line
     b = out["config"]["scene_broadcast"]
     assert b["bytes"] > 0 and b["collective_ms"] > 0 and b["ranks_equal"] is True and int(b["checksum"], 16) != 0
-    # `value` is the step with nothing carried (queue built, grid cleared in the step); the kept-queue step stands beside it
+    # `value` is the step of a scene whose Init was told the grid: each rank prepared its share's queue after the import, the step
+    # clears the grid and the hardware deals the bricks out; the step that builds its queue itself and the kept-queue step stand beside it
     c = out["config"]
-    assert c["step"].startswith("one Voxelize with nothing carried") and c["queued_bricks"] > 0 and c["queue_build_ms"] > 0
-    assert c["work_queue"]["queued_bricks"] == c["queued_bricks"] and out["roofline"]["kernel"] == "k_voxelize_queue"
+    assert c["step"].startswith("one Voxelize of a scene whose Init was told the grid") and c["queued_bricks"] > 0
+    assert c["queue_build_ms"] == 0 and c["queue_prepare_ms"] > 0 and c["frames_in_flight"] == 1
+    assert c["work_queue"]["queued_bricks"] == c["queued_bricks"] and out["roofline"]["kernel"] == "k_voxelize_listed"
+    u = c["unprepared_step"]
+    assert u["ms_per_step"] > 0 and u["queue_build_ms"] > 0 and u["persistent_waves"] % 8 == 0
     k = c["kept_step"]
     assert k["ms_per_step"] > 0 and k["stored_bytes_per_launch"] == 64 * c["queued_bricks"]
