@@ -454,6 +454,23 @@ def main():
                 ts.append(vox.stats()["voxelize_ms"])
             return float(np.median(ts))
 
+        if mode == dxv.MODE_REFERENCE:
+            # The reference's own per-frame output: the R10G10B10A2_UNORM texel, float4(Normal, 1) where the ray is inside (hlsl:83-84,
+            # Content/Voxelizer.cpp:65), written beside the occupancy byte.  Every solid voxel then needs its hit's interpolated normal
+            # (the class bits cannot give it) and the step stores 4 more bytes per voxel -- the one variant of the path where HBM bytes
+            # begin to matter.  The same steps as the headline's, texel image on.
+            vox.EnableTexels(True)
+            kt = min(args.steps, 200)
+            dtt, ktm, _ = timed_region(1, kt, 3)
+            stt = st_probe()
+            vox.EnableTexels(False)
+            tb = algorithmic_bytes(N, nz, T, V) + 4 * N * N * nz
+            extras["texels"] = {"what": "the same steps with the reference's R10G10B10A2 texel image written beside the occupancy grid (dxv_enable_texels): "
+                                        "N^3 x 4 B more stored per step, the interpolated normal fetched for every solid voxel",
+                                "ms": dtt / kt * 1e3, "mvoxels_s": (N ** 3) * kt / dtt / 1e6, "steps": kt, "prepared": bool(stt["plan_prepared"]),
+                                "stored_bytes": 5 * N * N * nz, "algorithmic_bytes": tb, "achieved_gbps": tb / (ktm * 1e-3) / 1e9,
+                                "frac": tb / (ktm * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            timed_region(1, 2, 1)
         om = dxv.MODE_PARITY if mode == dxv.MODE_REFERENCE else dxv.MODE_REFERENCE
         other_ms = median_ms(om)                 # the second occupancy rule on the same scene, for the record
         extras["other_rule"] = {"mode": "parity" if args.mode == "reference" else "reference", "ms": other_ms,

@@ -614,7 +614,8 @@ DXV_HD uint8_t shade_reference(const SceneView& sc, Ray& r, Hit& best, float bes
         // most triangles answer the predicate for every ray that can hit them (normal_class): no normals, no barycentrics
         const uint32_t cls = (uint32_t)best.leaf >> kClassShift;
         best.leaf &= (int32_t)((1u << kClassShift) - 1u);
-        if (cls != 0u && !texel) return cls == kClassIn ? 1 : 0;
+        // (with the texel image on only the "inside" class needs its normal: an "outside" hit writes nothing, hlsl:83)
+        if (cls != 0u && (!texel || cls != kClassIn)) return cls == kClassIn ? 1 : 0;
         finish_hit(best, bestDet);
         finish_ray_reference(r);                                        // the direction again (not kept through the scan)
     }

@@ -611,7 +611,8 @@ __device__ __forceinline__ void clear_dead_bricks(const VoxelizeParams& p, const
     const uint32_t lo = block * per, hi = lo + per < pieces ? lo + per : pieces;
     // four pieces per thread and round: their mask words are asked for together (a chain of sixteen dependent loads per thread made
     // a clearing workgroup last 16 us -- longer than a brick)
-    for (uint32_t q0 = lo + threadIdx.x; q0 < hi; q0 += 256u) {
+    for (uint32_t base = lo; base < hi; base += 256u) {                 // (wave-uniform: the texel image's stores read other lanes' nibbles)
+        const uint32_t q0 = base + threadIdx.x;
         uint32_t nib[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; ++u) {
@@ -635,11 +636,20 @@ __device__ __forceinline__ void clear_dead_bricks(const VoxelizeParams& p, const
                 for (uint32_t b = 0; b < 4u; ++b)
                     if (!((nib[u] >> b) & 1u)) *reinterpret_cast<uint32_t*>(g + 4u * b) = 0u;
             }
-            if (p.texels) {
-                uint32_t* t = p.texels + q * 16u;
+        }
+        if (p.texels) {
+            // the same bricks of the texel image: a piece is 64 bytes there.  Lane l of round k writes the (64 k + l)-th 16 bytes of the
+            // wave's 4 KiB (consecutive lanes, consecutive bytes: a lane writing its own piece's four quarters would leave every store
+            // instruction a quarter of each line) -- brick l & 3 of piece 16 k + (l >> 2), whose nibble lane 16 k + (l >> 2) holds
+            const uint32_t lane = threadIdx.x;
 #pragma unroll
-                for (uint32_t b = 0; b < 4u; ++b)
-                    if (!((nib[u] >> b) & 1u)) __builtin_nontemporal_store(z, reinterpret_cast<Zero4*>(t + 4u * b));
+            for (uint32_t u = 0; u < 4u; ++u) {
+                uint32_t* t = p.texels + ((size_t)base + 64u * u) * 16u;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t n = (uint32_t)__shfl((int)nib[u], (int)(16u * k + (lane >> 2)));
+                    if (!((n >> (lane & 3u)) & 1u)) __builtin_nontemporal_store(z, reinterpret_cast<Zero4*>(t + (64u * k + lane) * 4u));
+                }
             }
         }
     }

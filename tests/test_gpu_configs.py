@@ -60,6 +60,9 @@ def make(name):
             _cache[name] = meshes.soup()
         elif name == "soup1m":
             _cache[name] = meshes.soup(1_000_000)
+        elif name in ("bunny", "dragon"):
+            d = gold(name)
+            _cache[name] = (d["vb"], d["ib"])
     return _cache[name]
 
 
@@ -125,6 +128,55 @@ def test_config_grid_equals_oracle_fixture(dxv, configs, key):
                 assert v.stats()["plan_bricks"] == 0
                 check_whole(v.Grid(), configs[key], f"{key} brick box")
                 v.set_option("plan", 2)
+    finally:
+        v.close()
+
+
+# N1 at the sizes the path is measured at: the reference's per-frame output IS the R10G10B10A2_UNORM texel (float4(Normal, 1) where the
+# ray is inside, hlsl:83-84; Content/Voxelizer.cpp:65) -- the whole uint32 image against the oracle's digest (SHA-256 + every slice's
+# wrapping sum), through the prepared launch, a launch that builds its queue, the kept queue, the brick box and the tree walk
+@pytest.mark.parametrize("key", ["torus1m/512/reference", "dragon9/512/reference", "bunny/256/reference"])
+def test_texel_image_at_config_scale_equals_oracle_fixture(dxv, configs, key):
+    name, N, _ = key.split("/")
+    N = int(N)
+    want = configs[key]
+    v = dxv.Voxelizer(0)
+    try:
+        init(v, configs, key)
+        v.EnableTexels(True)
+
+        def check(what):
+            t = v.Texels()
+            sums = [int(x) for x in t.reshape(N, -1).sum(1, dtype=np.uint64)]
+            bad = [z for z in range(N) if sums[z] != want["texel_slice_sums"][z]]
+            assert not bad, f"{key} texels, {what}: {len(bad)} slices differ, first z = {bad[0]}"
+            assert sha(t) == want["texels_sha256"], f"{key} texels, {what}"
+            # alpha is what the grid holds (the consumer reads nothing else, PSRayCast.hlsl:108): texel != 0 <=> occupancy 1
+            g = v.Grid()
+            assert np.array_equal(g != 0, (t >> 30) == 3) and np.array_equal(g == 0, t == 0)
+            check_whole(g, want, f"{key} grid beside its texels, {what}")
+
+        v.Voxelize(N)
+        assert v.stats()["list_entries"] > 0 and v.stats()["plan_prepared"] == 0
+        check("queue built inside the launch")
+        v.PrepareLaunch(N)
+        v.Voxelize(N)
+        assert v.stats()["plan_prepared"] == 1
+        check("prepared launch")
+        v.set_option("prepared", 0)
+        v.set_option("plan", 1)
+        for _ in range(3):
+            v.Voxelize(N)
+        check("kept queue, dealt out by the hardware")
+        v.set_option("plan", 0)
+        v.Voxelize(N)
+        check("brick box")
+        v.set_option("plan", 2)
+        v.set_option("prepared", 1)
+        v.set_option("lists", 0)
+        v.Voxelize(N)
+        assert v.stats()["list_entries"] == 0
+        check("tree walk")
     finally:
         v.close()
 
