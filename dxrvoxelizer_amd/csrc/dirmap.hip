@@ -721,6 +721,56 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The far-radius map WITHOUT lists: what the brick test of a tree walk reads (k_voxelize: a brick none of whose rays can reach a
+// triangle is zeroed and left).  A radial ray from p hits a triangle at p + t d = (|p| + t) d: a point of the triangle in the ray's
+// own direction, farther out than its start -- so a ray that starts beyond the farthest triangle point of its texel of direction
+// space is a miss, which is the very test the lists' max-mip answers (dm_box_may_be_live) with "farthest entry" for "farthest
+// point".  Per texel: the maximum, over the (triangle, face) footprints whose bounding rectangle reaches the texel, of the
+// footprint's far radius as a half rounded up -- dm_footprint / dm_record / dm_rect, the list build's own conservative functions, on
+// a coarse map (a superset of every texel's lists' far radius: no outline test, no per-texel radial cut).  One thread per triangle.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_dm_far(const TriPos* __restrict__ triPos, uint32_t T, uint32_t R, uint32_t* __restrict__ far32)
+{
+    const uint32_t tri = blockIdx.x * kThreads + threadIdx.x;
+    if (tri >= T) return;
+    const TriPos tp = triPos[tri];
+#pragma unroll 1
+    for (uint32_t face = 0; face < 6u; ++face) {
+        DirFootprint f;
+        if (!dm_footprint(tp, face, f)) continue;
+        const DirRecord e = dm_record(f);
+        uint32_t i0, i1, j0, j1;
+        if (!dm_rect(e, R, i0, i1, j0, j1)) continue;
+        const uint32_t r1 = e.rr >> 16;
+        for (uint32_t j = j0; j <= j1; ++j)
+            for (uint32_t i = i0; i <= i1; ++i) {
+                uint32_t* w = far32 + (face * R + j) * R + i;
+                if (*w < r1) atomicMax(w, r1);                           // (most texels have their maximum after a few triangles)
+            }
+    }
+}
+// ... as cells the mip build reads: one "entry" where any footprint reaches, its far radius
+__global__ __launch_bounds__(256) void k_dm_far_cells(const uint32_t* __restrict__ far32, uint32_t n, DirCell* __restrict__ cells)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    DirCell c{};
+    c.count = far32[k] ? 1u : 0u;
+    c.r1max = (uint16_t)far32[k];
+    cells[k] = c;
+}
+hipError_t dirmap_far(const TriPos* triPos, uint32_t T, uint32_t R, uint32_t* far32, DirCell* cells, uint16_t* mip, hipStream_t s)
+{
+    const uint32_t n = 6u * R * R;
+    hipError_t e = hipMemsetAsync(far32, 0, sizeof(uint32_t) * n, s);
+    if (e != hipSuccess) return e;
+    k_dm_far<<<(T + kThreads - 1u) / kThreads, kThreads, 0, s>>>(triPos, T, R, far32);
+    k_dm_far_cells<<<(n + 255u) / 256u, 256, 0, s>>>(far32, n, cells);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return dirmap_mip(cells, R, mip, s);
+}
+
 // mip: dm_mip_buffer_words(R) 16-bit words (far radii, then entry counts, then the count levels' "long list" words, then scratch)
 hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream_t s)
 {

@@ -240,6 +240,7 @@ void dxv_destroy(dxv_ctx* c)
     }
     free_scratch(c);
     drop_prepared(c, true);
+    (void)hipFree(c->dFar32); (void)hipFree(c->dFarCells); (void)hipFree(c->dFarMip);
     (void)hipFree(c->dMip);
     (void)hipFree(c->dVb); (void)hipFree(c->dIb); (void)hipFree(c->dScene);
     (void)hipFree(c->dImage); (void)hipFree(c->dEmpty); (void)hipFree(c->dListCells); (void)hipFree(c->dListEntries); (void)hipFree(c->dPlCells); (void)hipFree(c->dPlEntries); (void)hipFree(c->dPlScratch); (void)hipFree(c->dListScratchA); (void)hipFree(c->dListScratchB);
@@ -413,6 +414,7 @@ int finish_build(dxv_ctx* c, const char* who, bool headerToDevice = true)
         DXV_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->haveScene = true;
+    ++c->sceneEpoch;
     c->stackNow = stack_round_up((int)(c->hdr.treeHeight + 3 < (uint32_t)c->optStack0 ? c->hdr.treeHeight + 3 : (uint32_t)c->optStack0));
     c->stats.num_nodes = c->hdr.numNodes;
     c->stats.tree_height = c->hdr.treeHeight;
@@ -713,6 +715,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "prepared")) {
         if (value != 0 && value != 1) return fail(c, "option prepared: %lld not in {0,1}", (long long)value);
         c->optPrepared = (int)value;
+    } else if (!strcmp(key, "farmap")) {
+        if (value != 0 && value != 1) return fail(c, "option farmap: %lld not in {0,1}", (long long)value);
+        c->optFarMap = (int)value;
     } else if (!strcmp(key, "prepclear")) {
         if (value < 0 || value > 3) return fail(c, "option prepclear: %lld not in {0,1,2,3}", (long long)value);
         c->optPrepClear = (int)value;

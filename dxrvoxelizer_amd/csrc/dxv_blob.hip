@@ -191,6 +191,7 @@ int dxv_scene_import(dxv_ctx* c, const void* src, size_t bytes)
     c->T = h.numTris; c->V = h.numVerts;
     memcpy(c->bound, h.bound, sizeof(c->bound));
     c->haveScene = true;
+    ++c->sceneEpoch;
     if (withLists && (c->optListRes == 0 || (uint32_t)c->optListRes == listRes)) {   // (an explicit listres of another size: built here as asked)
         c->listEntries = listCount; c->listRes = listRes; c->listState = 1; c->listOpt = c->optListRes; c->listMs = 0.0f;
         ++c->listEpoch;

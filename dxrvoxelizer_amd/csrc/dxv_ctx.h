@@ -162,6 +162,15 @@ struct dxv_ctx {
     uint16_t* dMip = nullptr;
     size_t mipCap = 0;               // 16-bit words
     uint64_t listEpoch = 0;          // counts list builds / imports: a frame's queue belongs to the lists it was probed against
+    // far-radius map of a scene WITHOUT lists (dirmap_far): the brick test of its tree walks; made at the scene's first tree walk
+    uint64_t sceneEpoch = 0;         // counts builds / refits / imports
+    uint64_t farEpoch = 0;           // ... the one the far map was made for (0: none)
+    uint32_t* dFar32 = nullptr;
+    DirCell* dFarCells = nullptr;
+    uint16_t* dFarMip = nullptr;
+    uint32_t farR = 0, farCap = 0;   // the map it is on / was allocated for
+    float farMs = 0.0f;
+    int optFarMap = 1;               // 1: tree walks and brick-box launches of the reference rule skip the bricks none of whose rays can reach a triangle
     int optPlan = 2;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch (opt-in), 2 = on every launch (default: nothing carried)
     int optQueueWaves = 0;           // persistent waves of a queue launch; 0 = what the device holds at once
@@ -275,6 +284,7 @@ int alloc_scratch(dxv_ctx* c, uint32_t T);
 void fill_build_buffers(dxv_ctx* c, BuildBuffers& b);
 int ensure_nodes(dxv_ctx* c, hipStream_t stream);       // the hierarchy's traversal copies after a refit that skipped them
 // dxv_frames.hip
+int ensure_far_map(dxv_ctx* c, hipStream_t s);             // the far-radius map of a scene without lists (dirmap_far), current for the scene when this returns 0
 void drop_prepared(dxv_ctx* c, bool freeMemory = false);   // whatever changes the scene or its lists calls this (the slots keep their memory unless told otherwise)
 int frame_prepare(dxv_ctx* c, uint32_t i);
 int sync_frame(dxv_ctx* c, uint32_t i);

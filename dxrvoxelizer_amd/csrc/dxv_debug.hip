@@ -64,6 +64,39 @@ int dxv_debug_class_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, uint
     return 0;
 }
 
+int dxv_debug_far_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, int lists_mip, uint64_t out[12])
+{
+    if (!c || !out) return 1;
+    if (!c->haveScene) return fail(c, "dxv_debug_far_check: no scene");
+    if (N < 2 || (N & 1u) || N > 2048) return fail(c, "dxv_debug_far_check: grid_dim must be even and in [2, 2048], got %u", N);
+    if (nz == 0 || z0 >= N || nz > N - z0) return fail(c, "dxv_debug_far_check: slab [%u, %u+%u) outside the grid (N=%u)", z0, z0, nz, N);
+    if (c->hdr.treeHeight + 1 > 64) return fail(c, "dxv_debug_far_check: tree too deep for the checker's stack");
+    DXV_HIP(c, hipSetDevice(c->device));
+    if (sync_frames(c)) return 1;
+    if (ensure_nodes(c, c->stream)) return 1;
+    VoxelizeParams p{};
+    p.scene.nodes = scene_nodes32(c); p.scene.triPos = scene_tripos(c); p.scene.triNrm = scene_trinrm(c);
+    memcpy(p.scene.rootLo, c->hdr.rootLo, 12);
+    memcpy(p.scene.rootHi, c->hdr.rootHi, 12);
+    p.N = N; p.z0 = z0; p.nz = nz;
+    if (lists_mip) {
+        if (c->listState != 1 || !c->dMip) return fail(c, "dxv_debug_far_check: this scene has no lists");
+        p.mip = c->dMip; p.mipR = c->listRes;
+    } else {
+        if (ensure_far_map(c, c->stream)) return 1;
+        p.mip = c->dFarMip; p.mipR = c->farR;
+    }
+    unsigned long long* dOut = nullptr;
+    DXV_HIP(c, hipMalloc(&dOut, 12 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(dOut, 0, 12 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = launch_far_check(p, dOut, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(c, "dxv_debug_far_check failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
 {
     if (!c || !out) return 1;

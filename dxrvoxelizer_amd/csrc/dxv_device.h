@@ -57,6 +57,9 @@ hipError_t dirmap_fill(uint32_t T, uint32_t R, const DirRecord* rec, const uint3
 // max-mips of the texels' far radii and entry counts (dxv_dirmap.h: dm_mip_max), dm_mip_buffer_words(R) 16-bit words: what the launch's work queue is probed against
 hipError_t dirmap_mip(const DirCell* cells, uint32_t R, uint16_t* mip, hipStream_t s);
 
+// the far-radius map of a scene WITHOUT lists (a tree walk's brick test): far32 = 6 R R words of scratch, cells = 6 R R, mip = dm_mip_buffer_words(R)
+hipError_t dirmap_far(const TriPos* triPos, uint32_t T, uint32_t R, uint32_t* far32, DirCell* cells, uint16_t* mip, hipStream_t s);
+
 // consistency of a list section that arrived in a blob (dxv_scene_import): out[0] = cells whose range leaves the entries,
 // out[1] = entries whose triangle slot is >= T
 hipError_t dirmap_validate(const DirCell* cells, uint32_t R, const DirEntry* entries, uint32_t n, uint32_t T, uint32_t* out, hipStream_t s);
@@ -104,6 +107,8 @@ struct VoxelizeParams {
     uint32_t queueHeads;    // heads per queue the persistent waves draw from: 1, 2, 4 or 8
     uint32_t queueMinBricks; // persistent waves beyond one per this many bricks of an XCD's share leave at once (0: all stay)
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
+    uint32_t mipR;          // brick-box launches (k_voxelize, 4^3 bricks, reference rule): the map `mip` was made on -- every workgroup makes
+                            // the queue's brick test itself and a brick that cannot hold a live ray is zeroed and left; 0: no test
     uint32_t* liveMask;     // k_plan_bricks: one bit per brick of the partition, id (bz nbx + by) nbx + bx, set for every queued brick (or NULL):
                             // what the clear of a launch through a PREPARED queue reads (only the bricks nobody runs are zeroed)
 };
@@ -148,6 +153,7 @@ int stack_round_up(int want);
 int stack_for_brick(int brickShape, int want);   // the column depth compiled for this brick shape that is >= want
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s);   // parity mode: one walk per row run (1) or per 2 x 2 rows (2)
 hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);   // test hook: superset claim of the lists (slices [p.z0, p.z0 + p.nz))
+hipError_t launch_far_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);    // test hook: the brick test of the brick-box launches (p.mip, p.mipR; slices [p.z0, p.z0 + p.nz))
 hipError_t launch_class_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);  // test hook: per-triangle class of the normal test against the predicate
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);
 hipError_t launch_checksum(const void* buf, size_t bytes, unsigned long long* out, hipStream_t s);   // wrapping sum of the buffer's 64-bit words

@@ -127,6 +127,32 @@ static int prepare_partition(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nzLoc
     return 0;
 }
 
+// the far-radius map of the current scene (a scene without lists), on the frame's stream and finished before any other stream can use it
+int ensure_far_map(dxv_ctx* c, hipStream_t s)
+{
+    if (c->farEpoch == c->sceneEpoch && c->dFarMip) return 0;
+    // (coarse: a 4^3-voxel brick of a 512^3 grid is a texel of the 128 map wide where the map is finest; the test reads a max-mip level
+    // that holds the brick's patch in 2 x 2 cells anyway)
+    const uint32_t R = c->hdr.numTris < 20000u ? 64u : 128u;
+    if (R > c->farCap) {
+        (void)hipFree(c->dFar32); (void)hipFree(c->dFarCells); (void)hipFree(c->dFarMip);
+        c->dFar32 = nullptr; c->dFarCells = nullptr; c->dFarMip = nullptr; c->farCap = 0;
+        DXV_HIP(c, hipMalloc(&c->dFar32, sizeof(uint32_t) * 6u * R * R));
+        DXV_HIP(c, hipMalloc(&c->dFarCells, sizeof(DirCell) * 6u * R * R));
+        DXV_HIP(c, hipMalloc(&c->dFarMip, sizeof(uint16_t) * (size_t)dm_mip_buffer_words(R)));
+        c->farCap = R;
+    }
+    c->farEpoch = 0;
+    DXV_HIP(c, hipEventRecord(c->ev[8], s));
+    DXV_HIP(c, dirmap_far(scene_tripos(c), c->hdr.numTris, R, c->dFar32, c->dFarCells, c->dFarMip, s));
+    DXV_HIP(c, hipEventRecord(c->ev[9], s));
+    DXV_HIP(c, hipStreamSynchronize(s));
+    c->farMs = elapsed(c->ev[8], c->ev[9]);
+    c->farR = R;
+    c->farEpoch = c->sceneEpoch;
+    return 0;
+}
+
 // Everything that changes what the frames read (mesh, scene, lists, options that rebuild) first lets every
 // frame finish -- including the status check and, if a launch asked for it, the relaunch against the OLD scene.
 int sync_frames(dxv_ctx* c)
@@ -286,6 +312,14 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
         }
     }
     if (!p.lists && !p.scene.plCells && ensure_nodes(c, fs)) return 1;  // a tree walk after a refit: its copies of the hierarchy first
+    if (p.mode == DXV_MODE_REFERENCE && !queued && c->optFarMap && c->optBrick == 4 && !c->optAblate) {
+        // a launch over the brick box (tree walk, or the lists under plan = 0): every workgroup makes the queue's brick test itself --
+        // against the lists' max-mip when the scene has (settled) lists, else against the far-radius map of the triangles' own
+        // footprints, made once per scene at its first such launch (dirmap_far: 0.2 ms at 1 M triangles)
+        if (c->listState == 1 && c->dMip && !c->listCheckPending) { p.mip = c->dMip; p.mipR = c->listRes; }
+        else if (ensure_far_map(c, fs) == 0 && c->farEpoch == c->sceneEpoch) { p.mip = c->dFarMip; p.mipR = c->farR; }
+        else return 1;
+    }
     if ((p.mode == DXV_MODE_REFERENCE && p.lists) || (p.mode == DXV_MODE_PARITY && c->optRows && p.scene.plCells)) f.lastCanFail = false;
     if (c->optEvents) DXV_HIP(c, hipEventRecord(f.ev0, fs));
     if (p.mode == DXV_MODE_PARITY && c->optRows) {

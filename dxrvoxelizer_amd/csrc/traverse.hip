@@ -78,6 +78,18 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
     const uint32_t iz = p.zBlock == p.nz ? p.z0 + lz                                    // contiguous slab
                       : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));    // block-cyclic, zBlock = 2^zShift
     const size_t id = ((size_t)lz * N + iy) * N + ix;
+    if (MODE == 0 && B::x == 4 && B::y == 4 && B::z == 4 && p.mipR) {
+        // The work queue's brick test without a queue (tree walks, plan = 0): can ANY ray of this brick reach a triangle?  p.mip is the
+        // max-mip of the far radii of the scene's lists, or -- a scene without lists -- of the triangles' own footprints (dirmap_far).
+        // Wave-uniform; a dead brick costs its workgroup a hundred instructions and four loads instead of 64 walks out of the tree.
+        float x0, x1, y0, y1, z0, z1;
+        dm_brick_hull(N, p.nz, p.z0, p.zBlock, p.zShift, p.zPeriod, bx, by, bz, x0, x1, y0, y1, z0, z1);
+        if (!dm_box_may_be_live(x0, x1, y0, y1, z0, z1, p.scene.rootLo, p.scene.rootHi, p.mip, p.mipR)) {
+            if (TEXELS) p.texels[id] = 0u;
+            p.grid[id] = 0;
+            return;
+        }
+    }
 
     const StridedStack stk{stack + tid, B::threads};
     bool overflow = false;
@@ -947,6 +959,47 @@ hipError_t launch_class_check(const VoxelizeParams& p, unsigned long long* out, 
 {
     const uint32_t nb = (p.N + 3u) / 4u, nbz = (p.nz + 3u) / 4u;
     k_class_check<<<dim3(nb * nb * nbz), dim3(64), 0, s>>>(p, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Test hook (dxv_debug_far_check): the brick test of the launches over the brick box -- "no ray of a brick the test calls dead hits
+// anything" -- checked exhaustively: for every brick of slices [p.z0, p.z0 + p.nz) the test k_voxelize makes (dm_box_may_be_live
+// against p.mip), and for every voxel of a brick it calls dead the plain LBVH walk without any shortcut but the provable root
+// early-out.  out[0] bricks, out[1] bricks called dead, out[2] their rays walked, out[3] rays among them with a hit (must be 0),
+// out[4 + k]: voxel id of the first 8.  Not a product path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_far_check(VoxelizeParams p, unsigned long long* out)
+{
+    __shared__ int32_t stack[64 * 64];
+    const uint32_t N = p.N, nbx = (N + 3u) / 4u;
+    const uint32_t b = blockIdx.x, bx = b % nbx, by = (b / nbx) % nbx, bz = b / (nbx * nbx);
+    const uint32_t lane = threadIdx.x;
+    float x0, x1, y0, y1, z0, z1;
+    dm_brick_hull(N, p.nz, p.z0, p.nz, 0u, p.nz, bx, by, bz, x0, x1, y0, y1, z0, z1);
+    const bool live = dm_box_may_be_live(x0, x1, y0, y1, z0, z1, p.scene.rootLo, p.scene.rootHi, p.mip, p.mipR);
+    if (lane == 0u) { atomicAdd(out, 1ull); if (!live) atomicAdd(out + 1, 1ull); }
+    if (live) return;
+    const uint32_t ix = bx * 4u + (lane & 3u), iy = by * 4u + ((lane >> 2) & 3u), lz = bz * 4u + (lane >> 4), iz = p.z0 + lz;
+    if (ix >= N || iy >= N || lz >= p.nz) return;
+    const SceneView& sc = p.scene;
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) return;
+    finish_ray_reference(r);
+    atomicAdd(out + 2, 1ull);
+    const StridedStack stk{stack + lane, 64};
+    Hit best;
+    const bool done = trace_reference(r, sc.nodes, sc.triPos, stk, 64, best);
+    if (!done || best.k != 0xffffffffu) {
+        const unsigned long long slot = atomicAdd(out + 3, 1ull);
+        if (slot < 8ull) out[4 + slot] = ((unsigned long long)lz * N + iy) * N + ix;
+    }
+}
+hipError_t launch_far_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s)
+{
+    const uint32_t nb = (p.N + 3u) / 4u, nbz = (p.nz + 3u) / 4u;
+    k_far_check<<<dim3(nb * nb * nbz), dim3(64), 0, s>>>(p, out);
     return hipGetLastError();
 }
 

@@ -269,6 +269,15 @@ class Voxelizer:
         return {"live_voxels": int(out[0]), "live_bricks": int(out[1]), "queued_bricks": int(out[2]), "violations": int(out[3]),
                 "duplicates": int(out[4]), "first": [int(v) for v in out[5:5 + int(min(out[3], 11))]]}
 
+    def far_check(self, gridDim, z0=0, nz=None, lists_mip=False):
+        """dxv_debug_far_check: dict with bricks, dead_bricks (the brick test of the brick-box launches calls them dead), rays_walked
+        (their rays, walked through the LBVH), violations (rays among them that hit something: must be 0) and the first voxel ids."""
+        out = np.zeros(12, np.uint64)
+        nz = gridDim - z0 if nz is None else nz
+        self._check(self._lib.dxv_debug_far_check(self._ctx, int(gridDim), int(z0), int(nz), int(bool(lists_mip)), out.ctypes.data_as(C.c_void_p)))
+        return {"bricks": int(out[0]), "dead_bricks": int(out[1]), "rays_walked": int(out[2]), "violations": int(out[3]),
+                "first": [int(v) for v in out[4:4 + int(min(out[3], 8))]]}
+
     def trim(self):
         self._check(self._lib.dxv_trim(self._ctx))
 

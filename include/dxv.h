@@ -335,6 +335,10 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 Content/Voxelizer.cpp:108-113): -13 % per launch at 512^3, -25 % on a rank's share at 8 ranks, and the launch
  *                 goes through the hardware's dispatcher (option dispatch);
  *                 0: no queue, brick box around the scene in Morton order
+ *   farmap 0|1    launches over the brick box (tree walks -- lists = 0, dynamic first launches, scenes over the lists' caps -- and plan = 0):
+ *                 every workgroup makes the queue's brick test itself and a brick none of whose rays can reach a triangle is zeroed and
+ *                 left (1, default); the test reads the lists' max-mip or, for a scene without lists, a far-radius map of the triangles'
+ *                 own footprints made at the scene's first such launch (0.2 ms at 1 M triangles); 0: every brick is walked
  *   prepared 0|1  launches of a partition that dxv_prepare_launch* prepared use its queue (1, default) or build their own (0)
  *   prepclear 0|1|2|3  how a launch through a prepared queue clears its grid: 0 = a clear kernel in front of the brick kernel; 1 / 2 / 3 =
  *                 only the bricks that are not queued, by workgroups in front of / behind / spread evenly between the bricks' in the
@@ -370,6 +374,13 @@ DXV_API int dxv_debug_list_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, u
  * class the canonical predicate (hlsl:137-138) is evaluated and compared.  out[0] = hits on classified triangles, out[1] =
  * disagreements (must be 0), out[2] = all hits, out[3 + 2k], out[4 + 2k] = voxel id and triangle slot of the first 15. */
 DXV_API int dxv_debug_class_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, uint32_t nz, uint64_t out[34]);
+
+/* Test hook: the brick test of the launches over the brick box (tree walks, plan = 0; option farmap): for every 4^3-voxel brick of slices
+ * [z0, z0 + nz) the test the kernel makes, and for every voxel of a brick it calls dead a plain LBVH walk.  lists_mip = 0: against
+ * the far-radius map of the triangles' own footprints (what a scene without lists uses; made if need be), 1: against the max-mip of
+ * the scene's lists.  out[0] = bricks, out[1] = bricks called dead, out[2] = their rays walked, out[3] = rays among them that hit
+ * something (must be 0), out[4 + k] = voxel id of the first 8. */
+DXV_API int dxv_debug_far_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, uint32_t nz, int lists_mip, uint64_t out[12]);
 
 /* Test hook: the work queue's claim -- no live ray in a brick that is not queued -- checked exhaustively on the device for the
  * partition of the current frame's last launch (which must have gone through a queue): every voxel makes exactly the first-step

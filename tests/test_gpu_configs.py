@@ -289,6 +289,47 @@ def test_lists_and_classes_checked_exhaustively_at_config_scale(dxv, configs, na
         v.close()
 
 
+# The brick test of the launches over the brick box (tree walks: lists = 0, scenes over the lists' caps, dynamic first launches; and
+# plan = 0): a brick none of whose rays can reach a triangle is zeroed without a walk -- against a far-radius map made from the
+# triangles' own footprints (no lists needed) or the lists' max-mip.  Exhaustively: every ray of every brick the test calls dead is
+# walked through the LBVH and must hit nothing; and the grids with the test on and off are the fixture's.
+@pytest.mark.parametrize("key", ["torus1m/512/reference", "dragon9/512/reference", "bunny16/512/reference", "soup1m/256/reference", "bunny/256/reference"])
+def test_tree_walk_brick_test_never_drops_a_hit(dxv, configs, key):
+    name, N, _ = key.split("/")
+    N = int(N)
+    v = dxv.Voxelizer(0)
+    try:
+        vb, ib = make(name)
+        v.set_option("lists", 0)
+        v.InitFromArrays(vb, ib)                               # (lists = 0: Init builds the LBVH only)
+        chk = v.far_check(N)
+        assert chk["violations"] == 0 and chk["bricks"] == (N // 4) ** 3, chk
+        if name != "soup1m":
+            assert chk["dead_bricks"] > chk["bricks"] // 4 and chk["rays_walked"] > 0, chk        # (a surface mesh: most of the grid lies beyond it or outside its box)
+        ms = {}
+        for far in (1, 0, 1):
+            v.set_option("farmap", far)
+            v.Voxelize(N)
+            st = v.stats()
+            assert st["list_entries"] == 0 and st["plan_bricks"] == 0
+            ms[far] = st["voxelize_ms"]
+            check_whole(v.Grid(), configs[key], f"{key} tree walk, farmap={far}")
+        # the same test against the lists' max-mip (what a brick-box launch of a scene WITH lists reads: plan = 0, lists = 0 set later)
+        v.set_option("lists", 2)
+        v.Voxelize(N)
+        if v.stats()["list_entries"]:
+            chk = v.far_check(N, lists_mip=True)
+            assert chk["violations"] == 0 and chk["dead_bricks"] > 0, chk
+            v.set_option("plan", 0)
+            v.Voxelize(N)
+            check_whole(v.Grid(), configs[key], f"{key} lists over the brick box with the brick test")
+            v.set_option("lists", 0)
+            v.Voxelize(N)
+            check_whole(v.Grid(), configs[key], f"{key} tree walk with the lists' mip")
+    finally:
+        v.close()
+
+
 def test_headline_partition_of_bench_at_8_ranks(dxv, configs):
     """What `bench.py --gpus 8` runs: torus-1M at 512^3, Z blocks of 4 slices dealt round-robin over 8 ranks, every rank's
     share launched repeatedly (through its work queue; from the second launch on with the kept queue and memset).  One GPU plays the ranks in turn; the
