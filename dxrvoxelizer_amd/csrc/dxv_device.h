@@ -8,9 +8,11 @@
 namespace dxv {
 
 // radix_sort.hip
+// plan: the diagnostic override (option sortbits) as ONE caller snapshot of radix_sort_plan(), -1: read it now
 hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int numBits, uint64_t** result,
-                                hipStream_t s);
-int radix_sort_passes(uint32_t n, int numBits);     // how many times that sort swaps keys and tmp
+                                hipStream_t s, int plan = -1);
+int radix_sort_passes(uint32_t n, int numBits, int plan = -1);     // how many times that sort swaps keys and tmp
+int radix_sort_plan();                              // the process-wide override as it stands (a build asks once)
 uint32_t radix_sort_hist_words(uint32_t n);
 void radix_sort_set_plan(int v);                    // diagnostic (option sortbits)
 

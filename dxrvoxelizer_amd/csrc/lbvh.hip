@@ -328,13 +328,14 @@ hipError_t lbvh_build(const BuildBuffers& b, int refitMode, hipStream_t s, hipEv
     const uint32_t keyBlocks = blocks_for(T);
     // the Morton half of the keys, bits [32, 62), is sorted; the index half starts ascending and every pass is stable, so the whole
     // key ends up ordered.  The keys are written where the sort's passes (three of 10 bits) bring them back to b.keys.
-    const bool odd = T > 1 && (radix_sort_passes(T, 30) & 1);
+    const int sortPlan = radix_sort_plan();                              // (one snapshot of the diagnostic override for both questions below)
+    const bool odd = T > 1 && (radix_sort_passes(T, 30, sortPlan) & 1);
     uint64_t* unsorted = odd ? b.keysTmp : b.keys;
     k_tri_keys<<<keyBlocks, kThreads, 0, s>>>(b.vb, b.ib, T, bnd, unsorted, b.rootInfo, keyBlocks > 256u ? keyBlocks / 256u : 1u);
     (void)hipEventRecord(ev[1], s);
     if (T > 1) {
         uint64_t* sorted = nullptr;
-        if ((e = radix_sort_keys_bits(unsorted, odd ? b.keys : b.keysTmp, T, b.hist, 32, 30, &sorted, s)) != hipSuccess) return e;
+        if ((e = radix_sort_keys_bits(unsorted, odd ? b.keys : b.keysTmp, T, b.hist, 32, 30, &sorted, s, sortPlan)) != hipSuccess) return e;
         if (sorted != b.keys) return hipErrorUnknown;
     }
     (void)hipEventRecord(ev[2], s);

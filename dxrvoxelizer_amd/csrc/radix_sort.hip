@@ -16,6 +16,7 @@
 // counts), and every key is written.  (Until round 5: one item of all waves at a time, three barriers per ITEM -- 48 per tile.)
 // HBM traffic per pass: 8 B read (histogram) + 8 B read + 8 B write (scatter) per key.
 #include "dxv_device.h"
+#include <atomic>
 
 namespace dxv {
 
@@ -32,12 +33,16 @@ using SortLarge = SortShape<16, 16>;
 
 // diagnostic override of the plan (dxv_set_option "sortbits", process-wide; results do not depend on it): 0 = automatic,
 // 8..11 = digits of at most that many bits; +16 / +32 / +48: the medium / large / small shape where the scratch allows it
-static int g_sortPlan = 0;
-void radix_sort_set_plan(int v) { g_sortPlan = v; }
+// (atomic, and a build snapshots it ONCE -- radix_sort_plan -- for every question it asks about its sort: a set_option from another
+// thread or context between lbvh_build's radix_sort_passes and its radix_sort_keys_bits used to change the parity of the passes)
+static std::atomic<int> g_sortPlanWord{0};
+void radix_sort_set_plan(int v) { g_sortPlanWord.store(v, std::memory_order_relaxed); }
+int radix_sort_plan() { return g_sortPlanWord.load(std::memory_order_relaxed); }
 
 struct SortPlan { int shape, bits, passes; };          // shape: 0 small, 1 medium, 2 large
-static SortPlan sort_plan(uint32_t n, int numBits)
+static SortPlan sort_plan(uint32_t n, int numBits, int plan)
 {
+    const int g_sortPlan = plan < 0 ? radix_sort_plan() : plan;
     SortPlan pl;
     pl.shape = n <= kSortSmall ? 0 : n <= kSortMedium ? 1 : 2;
     if ((g_sortPlan & 48) == 16 && n <= kSortMedium) pl.shape = 1;
@@ -211,9 +216,9 @@ static void sort_pass(const uint64_t* src, uint64_t* dst, uint32_t n, int shift,
 // zeros or more of the same order there); tmp is a same-size ping-pong buffer, hist holds radix_sort_hist_words(n) words;
 // *result = keys or tmp, whichever holds the sorted keys.
 hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint32_t* hist, int loBit, int numBits, uint64_t** result,
-                                hipStream_t s)
+                                hipStream_t s, int plan)
 {
-    const SortPlan pl = sort_plan(n, numBits);
+    const SortPlan pl = sort_plan(n, numBits, plan);
     uint64_t* src = keys;
     uint64_t* dst = tmp;
     for (int pass = 0; pass < pl.passes; ++pass) {
@@ -228,7 +233,7 @@ hipError_t radix_sort_keys_bits(uint64_t* keys, uint64_t* tmp, uint32_t n, uint3
     return hipGetLastError();
 }
 
-int radix_sort_passes(uint32_t n, int numBits) { return sort_plan(n, numBits).passes; }
+int radix_sort_passes(uint32_t n, int numBits, int plan) { return sort_plan(n, numBits, plan).passes; }
 
 // words of the histogram scratch of a sort of n keys, whatever its plan: bins x tiles + bins of the shape with the most of them
 uint32_t radix_sort_hist_words(uint32_t n)

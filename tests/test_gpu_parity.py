@@ -70,6 +70,16 @@ def test_set_mesh_scan_in_threads_gives_the_sequential_bound_and_names_the_offen
                 v.InitDynamic(bad, ib)
     v.Voxelize(64)                                                             # the earlier mesh is still there
     assert np.array_equal(v.Grid(), want)
+    # ... and so is its BOUND after a mesh of zero extent was refused (the bound used to be overwritten before the check: a later
+    # refit of the earlier mesh then normalised with the refused mesh's): the refit of the same vertices gives the same grid
+    flat = vb.copy()
+    flat[:, :3] = flat[0, :3]
+    with pytest.raises(dxv.DxvError, match="degenerate or non-finite bound"):
+        v.InitDynamic(flat, ib)
+    assert np.array_equal(np.asarray(v.stats()["bound"], np.float32).view(np.uint32), s.bound.view(np.uint32))
+    v.UpdateVertices(vb)
+    v.Voxelize(64)
+    assert np.array_equal(v.Grid(), want)
     small = meshes.torus(40, 20)                                               # a much smaller mesh: new buffers, not the old ones
     v.InitDynamic(*small)
     v.Voxelize(64)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic (library built with -DDXV_QUEUE_TIMES): the time line of a launch through a KEPT queue dealt out by the hardware
-(k_voxelize_listed): when does every workgroup start and end, how many are in flight over time, where does the launch spend its
+"""Diagnostic (library built with -DDXV_QUEUE_TIMES): the time line of a launch through a PREPARED (or, plan=1,prepared=0, a kept) queue dealt
+out by the hardware (k_voxelize_listed): when does every workgroup start and end, how many are in flight over time, where does the launch spend its
 beginning and its end?   usage: DXV_LIBRARY=.../libdxv_qtimes.so wg_times.py [mesh] [grid] [world] [zblock] [key=value,...]"""
 import ctypes as C
 import json
@@ -22,9 +22,10 @@ v.set_option("lists", 2)
 for kv in filter(None, (sys.argv[5] if len(sys.argv) > 5 else "").split(",")):
     v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 vb, ib, _ = make_mesh(mesh)
-v.InitFromArrays(vb, ib)
-v.build_lists(grid=N)
+v.InitFromArrays(vb, ib, gridDim=N)
 for rank in ((0, world // 2) if world > 1 else (0,)):
+    if world > 1:
+        v.PrepareLaunchInterleaved(N, rank, world, zb)                  # (the launch through the prepared queue: round 6's headline path)
     for _ in range(4):
         v.VoxelizeInterleaved(N, rank, world, zb, 0) if world > 1 else v.Voxelize(N, 0)
     st = v.stats()
