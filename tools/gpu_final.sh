@@ -1,71 +1,90 @@
 #!/bin/bash
-# Round evidence run: tests, smoke, configs 2-5, bench line, rocprof kernel stats of the bench command,
-# PMC passes, CPU baseline table, build timings.  Everything lands in gpurun_out/final/.
+# THE evidence run of a round (one script; tools/collect_evidence.py copies the judged summaries into profiles/<round>/final/):
+# suite + smoke, the bench line (default flags, the driver's flags, two ranks on one GPU over gloo, one rank through torch.distributed.run
+# over RCCL), the launch disciplines side by side with the looped 8-rank shares, standalone launch times of every configuration's mesh,
+# configurations and exhaustive checks, build / refit / Init timings, the reference's OBJ loader beside the product's, host-boundary
+# costs, a soak, workgroup time lines (diagnostic library built HERE), rocprofv3 kernel stats of the bench command and of the builds,
+# PMC passes (each in its own run, --kernel-trace only beside --pmc).  Everything lands in gpurun_out/final/.
+# usage (on the GPU box): bash tools/gpu_final.sh [quick]      quick: no soak, no soup-10M PMC, fewer repetitions
 cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/final
+QUICK=${1:-}
 rm -rf $OUT; mkdir -p $OUT
 (time python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider) > $OUT/pytest_gpu.log 2>&1
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
-python tools/configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 10 --warmup 2 --interleave --no-cpu-baseline --no-extras > $OUT/bench_torchrun_world1.log 2>&1
-python tools/build_bench.py bunny torus1m soup10m > $OUT/build.jsonl 2>&1
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench_driver_flags.err
+python bench.py --gpus 2 --backend gloo --same-device --steps 100 > $OUT/bench_2rank_same_gpu_gloo.json 2> $OUT/bench_2rank_same_gpu_gloo.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 bench.py --gpus 1 --steps 50 --warmup 3 --interleave --no-cpu-baseline --no-extras > $OUT/bench_torchrun_world1.log 2>&1
+for m in torus1m bunny16 dragon9; do python tools/prepared_ab.py $m 512 8 4 1,2,3 >> $OUT/launch_disciplines.jsonl 2>> $OUT/launch_disciplines.err; done
+python tools/prepared_ab.py torus1m 256 8 4 1,2 >> $OUT/launch_disciplines.jsonl 2>> $OUT/launch_disciplines.err
+python tools/prepared_ab.py dragon9 1024 8 4 1,2 >> $OUT/launch_disciplines.jsonl 2>> $OUT/launch_disciplines.err
+python tools/quick_times.py --meshes torus1m,bunny16,dragon9,bunny,dragon,soup10m > $OUT/quick_times.jsonl 2>&1
+python tools/quick_times.py --meshes torus1m,bunny,dragon --grid 256 > $OUT/quick_times_256.jsonl 2>&1
+python tools/quick_times.py --meshes dragon9,bunny --grid 1024 --reps 3 > $OUT/quick_times_1024.jsonl 2>&1
+python tools/configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
+python tools/list_check_configs.py > $OUT/list_check_configs.jsonl 2>&1
+python tools/build_once.py soup10m 4 > $OUT/build_soup10m.jsonl 2>&1
+python tools/build_once.py torus1m 6 > $OUT/build_torus1m.jsonl 2>&1
+for m in bunny dragon dragon9 bunny16; do python tools/build_once.py $m 3 | tail -1; done > $OUT/build_other_meshes.jsonl 2>&1
+python tools/build_bench.py bunny torus1m soup10m > $OUT/build_bench.jsonl 2>&1
+python tools/refit_loop.py torus1m 512 60 > $OUT/refit_loop.jsonl 2>&1
+python tools/refit_loop.py bunny16 512 30 >> $OUT/refit_loop.jsonl 2>&1
+python tools/init_times.py torus1m 512 3 > $OUT/init_times.jsonl 2>&1
+python tools/init_times.py bunny 256 3 >> $OUT/init_times.jsonl 2>&1
+python tools/obj_ingest_vs_reference.py 5 > $OUT/obj_ingest_vs_reference.jsonl 2> $OUT/obj_ingest_vs_reference.err
+python tools/ab_option.py farmap 0,1 --meshes torus1m,bunny16,dragon9,bunny --grid 512 --set lists=0 > $OUT/ab_tree_walk_brick_test.jsonl 2>&1
+tools/micro/sort_check time 0 8 10 > $OUT/sort_times.jsonl 2>&1
 python tools/cpu_baseline.py > $OUT/cpu_baseline.jsonl 2>&1
-python - > $OUT/render.jsonl 2>&1 <<'PY'
-import sys, json, numpy as np
-sys.path.insert(0, '.')
-import dxrvoxelizer_amd as dxv
-from dxrvoxelizer_amd import camera
-from bench import make_mesh
-v = dxv.Voxelizer(0)
-for mesh, N in (("bunny", 64), ("dragon", 512), ("torus1m", 512)):
-    vb, ib, _ = make_mesh(mesh)
-    v.InitFromArrays(vb, ib); v.Voxelize(N)
-    eye, vp = camera.default_view_proj(1280, 720)
-    ts = []
-    for _ in range(6):
-        img = v.Render(eye, vp, 1280, 720)
-        ts.append(v.stats()["render_ms"])
-    camera.write_png(f"gpurun_out/final/render_{mesh}_{N}.png", img)
-    print(json.dumps({"mesh": mesh, "N": N, "render_ms_1280x720": float(np.median(ts[1:])), "opaque_px": int((img[..., 3] == 255).sum())}))
-PY
 python tools/pcie_bench.py 512 > $OUT/pcie.jsonl 2>&1
-python tools/ab_option.py wide 0,2 --set lists=0 --meshes torus1m,bunny,dragon,dragon9,bunny16 --grid 512 > $OUT/ab_wide.jsonl 2>&1
-python tools/ab_option.py wide 0,2 --set lists=0 --meshes torus1m,bunny,dragon --grid 256 >> $OUT/ab_wide.jsonl 2>&1
-python tools/ab_option.py stack0 12,16,20,24 --set lists=0 --rounds 2 > $OUT/ab_stack0.jsonl 2>&1
-python tools/ab_lists.py > $OUT/ab_lists.jsonl 2>&1
-python tools/ab_lists.py --grid 256 --meshes torus1m,bunny,dragon >> $OUT/ab_lists.jsonl 2>&1
-python tools/ab_lists.py --grid 1024 --meshes dragon9,bunny --reps 3 >> $OUT/ab_lists.jsonl 2>&1
-python tools/ab_lists.py --grid 64 --meshes bunny,dragon >> $OUT/ab_lists.jsonl 2>&1
-python tools/ab_lists.py --meshes soup10m --reps 3 >> $OUT/ab_lists.jsonl 2>&1
-python tools/rowblock_table.py > $OUT/rowblock.jsonl 2>&1
-python tools/small_grid_latency.py > $OUT/small_grid_latency.jsonl 2>&1
-python tools/texel_time.py > $OUT/texel_time.jsonl 2>&1
-python tools/frame_loop.py > $OUT/frame_loop.jsonl 2>&1
-python tools/refit_loop.py torus1m 512 40 > $OUT/refit_loop.jsonl 2>&1
-python tools/refit_loop.py bunny16 512 20 >> $OUT/refit_loop.jsonl 2>&1
-python tools/refit_loop.py dragon9 512 20 >> $OUT/refit_loop.jsonl 2>&1
-python tools/ablate.py --meshes torus1m,bunny16 > $OUT/ablate.jsonl 2>&1
-python tools/quick_times.py --meshes torus1m,bunny16,dragon9,bunny,dragon,soup10m --tree > $OUT/quick_times.jsonl 2>&1
-python bench.py --gpus 2 --backend gloo --same-device --no-cpu-baseline > $OUT/bench_2rank_same_gpu_gloo.json 2> $OUT/bench_2rank_same_gpu_gloo.err
-python tools/sweep.py --meshes torus1m,bunny,dragon --grids 256,512 --bricks 4 --stacks 0 --modes reference,parity --reps 5 > $OUT/sweep.jsonl 2>&1
+[ -z "$QUICK" ] && python tools/gpu_soak.py 420 60606 > $OUT/soak_60606.jsonl 2>&1
+# workgroup time lines: the diagnostic build of the library is made here (it does not travel: .gpurunignore)
+python -c "from dxrvoxelizer_amd import build; build.build(defines=['DXV_QUEUE_TIMES'], name='qtimes')" > $OUT/build_qtimes.log 2>&1
+Q=$GRAFT_REPO_ROOT/dxrvoxelizer_amd/libdxv_qtimes.so
+if [ -f $Q ]; then
+  for m in torus1m bunny16 dragon9; do DXV_LIBRARY=$Q python tools/wg_times.py $m 512 8 4 >> $OUT/wg_times.jsonl 2>> $OUT/wg_times.err; done
+  DXV_LIBRARY=$Q python tools/wg_times.py torus1m 512 1 4 >> $OUT/wg_times.jsonl 2>> $OUT/wg_times.err
+fi
+tools/micro/l1_roof > $OUT/l1_roof.jsonl 2>&1
 cd /tmp && export TMPDIR=/tmp
-# the timed region alone (no second occupancy rule, tree walk, second mesh or two-in-flight region behind it), so that the
-# kernel's average over this command is the average bench.py itself reports
+export DXV_WARMUP=0      # (profiles: dxv_create's warm-up launches are not the kernels these averages are about)
+# the timed regions alone, so that the kernel's average over this command is the average bench.py itself reports
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $OUT/prof_bench.log 2>&1
-# the refit-per-frame loop: kernels of refit + list build + voxelize, per frame
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_build -- python3 $GRAFT_REPO_ROOT/tools/build_once.py soup10m 3 > $OUT/prof_build.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_build_torus1m -- python3 $GRAFT_REPO_ROOT/tools/build_once.py torus1m 6 > $OUT/prof_build_torus1m.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_refit_loop -- python3 $GRAFT_REPO_ROOT/tools/refit_loop.py torus1m 512 20 > $OUT/prof_refit_loop.log 2>&1
-R=$GRAFT_REPO_ROOT/tools/run_once.py
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq1 -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_sq1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc_sq2 -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_sq2.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_tcc -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_tcc.log 2>&1
-rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcp -- python3 $R torus1m 512 3 reference lists=2 > $OUT/pmc_tcp.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_parity -- python3 $R torus1m 512 3 parity > $OUT/pmc_fetch_parity.log 2>&1
-# the deep scene's kernel (BASELINE config 5): counters of the same launch on the 10 M-triangle soup
-bash $GRAFT_REPO_ROOT/tools/gpu_pmc_quick.sh soup10m soup10m 512 > $OUT/pmc_soup10m.log 2>&1
-cp $GRAFT_REPO_ROOT/gpurun_out/pmcq/soup10m/summary.json $OUT/pmc_soup10m_summary.json 2>/dev/null
-python $GRAFT_REPO_ROOT/tools/quick_times.py --meshes soup10m,torus1m,dragon9 --frames 3 --reps 5 > $OUT/frames3.jsonl 2>&1
-python $GRAFT_REPO_ROOT/tools/list_check_configs.py --quick > $OUT/list_check_quick.jsonl 2>&1
+rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_l1_roof -- $GRAFT_REPO_ROOT/tools/micro/l1_roof > $OUT/pmc_l1_roof.log 2>&1
+cd $GRAFT_REPO_ROOT
+for d in prof_bench prof_build prof_build_torus1m prof_refit_loop; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${d}_kernel_stats.csv; done
+python3 tools/trace_gaps.py $OUT/prof_refit_loop 3 > $OUT/refit_loop_trace_gaps.jsonl 2>&1
+python3 - > $OUT/pmc_l1_roof_summary.json <<'PY'
+import csv, glob, json, os, collections
+out = collections.OrderedDict()
+d = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "final", "pmc_l1_roof")
+rows = collections.defaultdict(dict)
+for cc in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(cc)):
+        if "k_gather" in r["Kernel_Name"]:
+            rows[(r["Dispatch_Id"], r["Kernel_Name"])][r["Counter_Name"]] = float(r["Counter_Value"])
+for (disp, name), c in sorted(rows.items(), key=lambda kv: int(kv[0][0])):
+    clk = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if clk:
+        out.setdefault(name, []).append({"line_accesses_per_clk_per_cu": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / 256 / clk, "ta_busy": c.get("TA_TA_BUSY_sum", 0) / 256 / clk, "clocks": clk})
+print(json.dumps(out, indent=1))
+PY
+find $OUT/prof_bench $OUT/prof_build $OUT/prof_build_torus1m $OUT/prof_refit_loop $OUT/pmc_l1_roof -name "*.csv" -size +4M -delete
+unset DXV_WARMUP
+# counter passes (tools/gpu_pmc_quick.sh switches the warm-up off itself): the headline's launch (prepared), the launch that builds its
+# queue, a rank's share at 2 / 4 / 8 ranks, the other 1 M-triangle mesh, the texel image, the tree walk, the soup
+export PMC_LAUNCHES=5
+bash tools/gpu_pmc_quick.sh torus1m torus1m 512 > $OUT/pmc_torus1m.log 2>&1
+bash tools/gpu_pmc_quick.sh torus1m_unprepared torus1m 512 prepare=0 > $OUT/pmc_torus1m_unprepared.log 2>&1
+bash tools/gpu_pmc_quick.sh rank8 torus1m 512 world=8 rank=0 zblock=4 > $OUT/pmc_rank8.log 2>&1
+bash tools/gpu_pmc_quick.sh rank4 torus1m 512 world=4 rank=0 > $OUT/pmc_rank4.log 2>&1
+bash tools/gpu_pmc_quick.sh rank2 torus1m 512 world=2 rank=0 > $OUT/pmc_rank2.log 2>&1
+bash tools/gpu_pmc_quick.sh bunny16 bunny16 512 > $OUT/pmc_bunny16.log 2>&1
+export PMC_LAUNCHES=3
+bash tools/gpu_pmc_quick.sh treewalk torus1m 512 lists=0 > $OUT/pmc_treewalk.log 2>&1
+[ -z "$QUICK" ] && bash tools/gpu_pmc_quick.sh soup10m soup10m 512 > $OUT/pmc_soup10m.log 2>&1
+for t in torus1m torus1m_unprepared rank8 rank4 rank2 bunny16 treewalk soup10m; do cp gpurun_out/pmcq/$t/summary.json $OUT/pmc_${t}_summary.json 2>/dev/null; done
 exit 0

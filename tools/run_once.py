@@ -14,7 +14,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 mode = dxv.MODE_PARITY if len(sys.argv) > 4 and sys.argv[4] == "parity" else dxv.MODE_REFERENCE
 v = dxv.Voxelizer(0)
-part = {"world": 1, "rank": 0, "zblock": 8}          # world=8 rank=0: one rank's share of the block-cyclic partition (bench.py --gpus 8)
+part = {"world": 1, "rank": 0, "zblock": 8, "prepare": 1}          # world=8 rank=0: one rank's share of the block-cyclic partition (bench.py --gpus 8);
+                                                                    # prepare=0: Init is not told the grid (every launch builds its queue)
 for kv in sys.argv[5:]:
     k, val = kv.split("=")
     if k in part:
@@ -23,6 +24,11 @@ for kv in sys.argv[5:]:
         v.set_option(k, int(val))
 vb, ib, _ = make_mesh(mesh)
 v.InitFromArrays(vb, ib)
+if part["prepare"] and mode == dxv.MODE_REFERENCE:
+    if part["world"] > 1:
+        v.PrepareLaunchInterleaved(N, part["rank"], part["world"], part["zblock"])
+    else:
+        v.PrepareLaunch(N)
 for _ in range(K):
     if part["world"] > 1:
         v.VoxelizeInterleaved(N, part["rank"], part["world"], part["zblock"], mode)
