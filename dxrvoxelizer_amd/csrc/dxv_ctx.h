@@ -170,6 +170,7 @@ struct dxv_ctx {
     uint16_t* dFarMip = nullptr;
     uint32_t farR = 0, farCap = 0;   // the map it is on / was allocated for
     float farMs = 0.0f;
+    int optCoop = 1;                 // 1: the lists kernel scans a lone lane's long list with its whole wave (dxv_dirmap.h: trace_reference_dm_from)
     int optFarMap = 1;               // 1: tree walks and brick-box launches of the reference rule skip the bricks none of whose rays can reach a triangle
     int optPlan = 2;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box
                                      // in Morton order), 1 = built when lists, partition or buffers differ from the frame's last launch (opt-in), 2 = on every launch (default: nothing carried)

@@ -89,6 +89,7 @@ struct DirMapView {
     const DirCell* cells;      // 6 * R * R, cell = (face * R + j) * R + i; NULL: no map
     const DirEntry* entries;
     uint32_t R;                // texels per face side, a power of two
+    uint32_t coop = 0u;        // device: 1 = a lone lane's long list is scanned by its whole wave (trace_reference_dm_from)
 };
 
 constexpr float kDmDelta = 3.0517578125e-5f;        // 2^-15: dilation of the triangles
@@ -748,6 +749,7 @@ DXV_HD uint64_t dm_key(const DirKeyLayout& k, uint32_t cell, uint16_t r1, uint32
 DXV_HD uint32_t dm_key_cell(const DirKeyLayout& k, uint64_t key) { return (uint32_t)(key >> (64u - k.cellBits)); }
 DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32_t)(key & ((1ull << k.triBits) - 1ull)); }
 
+constexpr uint32_t kDmCoopLanes = 2u, kDmCoopMin = 24u;     // the cooperative scan of a lone lane's long list (trace_reference_dm_from)
 // closest hit of the reference rule through the lists
 // Two steps like the postponed-leaf walks: scanning entries is short and cheap, the triangle step is
 // long, so the triangles an entry scan selects are queued in the thread's LDS column (cap entries)
@@ -794,10 +796,61 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
     float bound = (rho + best.t) * 1.001f + 1e-4f;                      // how far out an entry may start and still matter: behind the closest hit so far
     uint32_t rc = dm_radial_word(near, bound);                          // radial cut: r1 >= near, r0 not beyond `bound`
     for (;;) {
+        bool coop = false;                                                  // this round was a cooperative one (wave-uniform; the host: never)
+#if defined(__HIP_DEVICE_COMPILE__)
+        // A LONG list scanned by a LONE lane: a brick is as long as its longest list (a ray that finds no hit reads its texel's list to
+        // the end: hundreds of entries in a deep fold of a real mesh, four per round, while the wave's other lanes have long
+        // finished: 40 - 80 us against a median brick of 10, and a short launch cannot end before its longest brick).  When at most
+        // kDmCoopLanes lanes are still scanning and the first of them has kDmCoopMin entries or more ahead, the WHOLE wave scans that
+        // lane's list, one entry per lane and round (one coalesced kilobyte), with that ray's words broadcast through scalar
+        // registers; what passes goes into the ray's own queue, as if it had scanned alone.  Same entries, same integer test, same
+        // stop rule -- entries are only LOOKED AT in another order, and the closest hit does not depend on the order of tests.
+        {
+            const uint64_t sm = __builtin_amdgcn_ballot_w64(i < end);
+            if (dm.coop && sm != 0ull && __builtin_popcountll(sm) <= (int)kDmCoopLanes) {
+                const int L = __builtin_ctzll(sm);
+                const uint32_t iL = (uint32_t)__builtin_amdgcn_readlane((int)i, L), endL = (uint32_t)__builtin_amdgcn_readlane((int)end, L);
+                if (endL - iL >= kDmCoopMin) {
+                    const DirRayLocal locL{(uint32_t)__builtin_amdgcn_readlane((int)loc.q, L), (uint32_t)__builtin_amdgcn_readlane((int)loc.p, L)};
+                    const uint32_t rcL = (uint32_t)__builtin_amdgcn_readlane((int)rc, L);
+                    const float stepL = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, step), L));
+                    const float boundL = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bound), L));
+                    // (lanes of this wave that take part: a brick at the grid's end has left some behind)
+                    const uint64_t act = __builtin_amdgcn_ballot_w64(true);
+                    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                    const uint32_t rank = (uint32_t)__builtin_popcountll(act & ((1ull << lane) - 1ull)), width = (uint32_t)__builtin_popcountll(act);
+                    const uint32_t at = iL + rank;
+                    const bool have = at < endL;
+                    const DirEntry e = dm.entries[have ? at : endL - 1u];
+                    const uint64_t stop = __builtin_amdgcn_ballot_w64(have && dm_stop_radius(e, stepL) > boundL);
+                    // the first entry (in list order) at which a lone scan would have stopped: nothing from there on matters
+                    uint32_t stopRank = 64u;
+                    if (stop) stopRank = (uint32_t)__builtin_popcountll(act & ((1ull << __builtin_ctzll(stop)) - 1ull));
+                    uint64_t pm = __builtin_amdgcn_ballot_w64(have && rank < stopRank && dm_local_pass(e, locL, rcL));
+                    int qnL = __builtin_amdgcn_readlane(qn, L);
+                    const uint32_t triE = dm_entry_tri(e);
+                    uint32_t next = stop ? endL : (iL + width < endL ? iL + width : endL);
+                    while (pm) {
+                        const int src = __builtin_ctzll(pm);
+                        if (2 * (qnL + 1) > cap) {                           // the ray's queue is full: go on behind the last entry taken
+                            next = iL + (uint32_t)__builtin_popcountll(act & ((1ull << src) - 1ull));
+                            break;
+                        }
+                        pm &= pm - 1ull;
+                        const int32_t t = __builtin_amdgcn_readlane((int)triE, src), rr = __builtin_amdgcn_readlane((int)e.rr, src);
+                        if ((int)lane == L) { stk.put(2 * qn, t); stk.put(2 * qn + 1, rr); ++qn; }
+                        ++qnL;
+                    }
+                    if ((int)lane == L) i = next;
+                    coop = true;                                            // (the ray's queue may now hold up to `cap` words: no lane scans on its own in this round)
+                }
+            }
+        }
+#endif
         // four entries per round, all four loads in flight before the first is looked at (two per round:
         // +13 % on the 1 M-triangle scene, one: +40 %).  One address, four offsets: entries behind the end of the list are
         // loaded and not looked at (the next texel's, or the three spare ones behind the last list).
-        if (i < end) {
+        if (!coop && i < end) {
             const uint32_t last = end - 1u;
             // (the third and fourth load are skipped when no lane of the wave has that many entries left:
             // -5 % on the 1 M-triangle scene; voting on the second one as well: +7 %)
@@ -885,7 +938,7 @@ DXV_HD void trace_reference_dm(Ray& r, const DirMapView& dm, const TriPos* tris,
 template <class Stack, int ABL>
 DXV_HD void trace_reference_lists(Ray& r, const SceneView& sc, const Stack& stk, int cap, Hit& best, float& bestDet)
 {
-    const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
+    const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR, sc.dmCoop};
     trace_reference_dm<Stack, ABL>(r, dm, sc.triPos, stk, cap, best, bestDet);
 }
 

@@ -596,6 +596,7 @@ struct SceneView {
     const void* dmCells;    // direction-space lists (dxv_dirmap.h, WALK 4): DirCell[6 R R], DirEntry[], R
     const void* dmEntries;
     uint32_t dmR;
+    uint32_t dmCoop;        // 1: a lone lane's long list is scanned by its whole wave (trace_reference_dm_from; option coop)
     const uint32_t* plCells;    // row lists of the parity rule (dirmap.hip): (begin, count) per texel of the plR x plR grid over (y, z); NULL: none
     const uint32_t* plEntries;  // triangle slots
     uint32_t plR;

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
             SceneView sc;                                               // (what the lists' path reads of it)
             sc.nodes = nullptr; sc.wide = nullptr; sc.plCells = nullptr; sc.plEntries = nullptr; sc.plR = 0;
             sc.triPos = pp->scene.triPos; sc.triNrm = pp->scene.triNrm;
-            sc.dmCells = pp->scene.dmCells; sc.dmEntries = pp->scene.dmEntries; sc.dmR = pp->scene.dmR;
+            sc.dmCells = pp->scene.dmCells; sc.dmEntries = pp->scene.dmEntries; sc.dmR = pp->scene.dmR; sc.dmCoop = pp->scene.dmCoop;
 #pragma unroll
             for (int a = 0; a < 3; ++a) { sc.rootLo[a] = pp->scene.rootLo[a]; sc.rootHi[a] = pp->scene.rootHi[a]; }
             const uint32_t N = pp->N, nz = pp->nz;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
             // raygenMain for the 64 voxels of the brick (voxel_reference<4>, dxv_trace.h, with its first step made by all lanes)
             Ray r;
             ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
-            const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
+            const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR, sc.dmCoop};
             DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
             wAhead = 0xffffffffu;
             if (ahead) {
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
     const uint32_t iz = p.zBlock == nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
     Ray r;
     ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
-    const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR};
+    const DirMapView dm{static_cast<const DirCell*>(sc.dmCells), static_cast<const DirEntry*>(sc.dmEntries), sc.dmR, sc.dmCoop};
     DirRayStart start = dm_ray_start(r.ox, r.oy, r.oz, dm);
     if (origin_leaves_root(r.ox, r.oy, r.oz, sc.rootLo, sc.rootHi)) start.live = false;
     Hit best;

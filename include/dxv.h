@@ -155,7 +155,7 @@ DXV_API int dxv_update_vertices(dxv_ctx* ctx, const float* vb, uint32_t num_vert
  *    only the host can act on (a texel with more than 65,535 entries: tree walk) is read when the frame is next
  *    synchronised -- dxv_sync, any dxv_grid_* call, the next dxv_refit -- and a frame launched with lists that fail it is
  *    launched again through the tree there.
- * 1 M triangles at 512^3 from a device buffer: 650 - 660 frames/s (four round trips per frame: 576). */
+ * (frames per second of this loop at 1 M triangles: README.md's table, from the round's evidence run) */
 DXV_API int dxv_update_vertices_device(dxv_ctx* ctx, const void* device_vb, uint32_t num_verts);
 DXV_API int dxv_refit(dxv_ctx* ctx);
 
@@ -335,6 +335,9 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *                 Content/Voxelizer.cpp:108-113): -13 % per launch at 512^3, -25 % on a rank's share at 8 ranks, and the launch
  *                 goes through the hardware's dispatcher (option dispatch);
  *                 0: no queue, brick box around the scene in Morton order
+ *   coop   0|1    the lists kernel: when at most two lanes of a wave are still scanning and the first has 24 entries or more ahead, the whole
+ *                 wave scans that ray's list, one entry per lane and round (1, default) -- a brick is as long as its longest list, and a
+ *                 short launch (a rank's share) cannot end before its longest brick; 0: every lane scans alone
  *   farmap 0|1    launches over the brick box (tree walks -- lists = 0, dynamic first launches, scenes over the lists' caps -- and plan = 0):
  *                 every workgroup makes the queue's brick test itself and a brick none of whose rays can reach a triangle is zeroed and
  *                 left (1, default); the test reads the lists' max-mip or, for a scene without lists, a far-radius map of the triangles'

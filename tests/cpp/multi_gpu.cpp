@@ -29,11 +29,17 @@ int main(int argc, char** argv)
 	for (int d = 0; d < want; ++d) devices.push_back(d);
 
 	MultiVoxelizer vox(devices);
+	vox.SetGridHint(N, MultiVoxelizer::BLOCK_CYCLIC, 8);			// Init knows the grid (the reference's GRID_SIZE): every device prepares its share's work queue after the import
 	if (!vox.InitFromArrays(vb.data(), hdr[0], ib.data(), hdr[1])) { fprintf(stderr, "Init failed: %s\n", vox.LastError()); return 1; }
 	std::vector<uint8_t> cyclic, slabs;
 	uint64_t solidCyclic = 0, solidSlabs = 0;
 	if (!vox.Voxelize(N, MultiVoxelizer::REFERENCE, MultiVoxelizer::BLOCK_CYCLIC, 8) || !vox.Download(cyclic) || !vox.CountSolid(solidCyclic)) {
 		fprintf(stderr, "block-cyclic: %s\n", vox.LastError()); return 1;
+	}
+	for (size_t d = 0; d < vox.DeviceCount(); ++d) {				// the prepared partition's launch is the one dispatch; the slabs below were not prepared
+		dxv_stats st;
+		if (!vox.GetStats(d, st)) return 1;
+		if (st.list_entries && N % (8u * static_cast<uint32_t>(vox.DeviceCount())) == 0 && !st.plan_prepared) { fprintf(stderr, "device %zu: the block-cyclic launch did not use the prepared queue\n", d); return 1; }
 	}
 	if (!vox.Voxelize(N, MultiVoxelizer::REFERENCE, MultiVoxelizer::SLABS) || !vox.Download(slabs) || !vox.CountSolid(solidSlabs)) {
 		fprintf(stderr, "slabs: %s\n", vox.LastError()); return 1;

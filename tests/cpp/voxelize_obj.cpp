@@ -11,9 +11,14 @@ int main(int argc, char** argv)
 	if (argc < 4) { fprintf(stderr, "usage: %s mesh.obj gridDim out.bin [parity]\n", argv[0]); return 2; }
 	const float posScale[4] = { 0.0f, 0.0f, 0.0f, 1.0f };	// DXRVoxelizer.cpp:37 default
 	Voxelizer voxelizer;
-	if (!voxelizer.Init(argv[1], posScale)) { fprintf(stderr, "Init failed: %s\n", voxelizer.LastError()); return 1; }
+	const uint32_t gridDim = static_cast<uint32_t>(atoi(argv[2]));		// the reference's GRID_SIZE: a constant its Init knows (Content/Voxelizer.cpp:8)
+	if (!voxelizer.Init(argv[1], posScale, false, gridDim)) { fprintf(stderr, "Init failed: %s\n", voxelizer.LastError()); return 1; }
 	const auto mode = argc > 4 ? Voxelizer::PARITY : Voxelizer::REFERENCE;
-	if (!voxelizer.Voxelize(static_cast<uint32_t>(atoi(argv[2])), mode)) { fprintf(stderr, "Voxelize failed: %s\n", voxelizer.LastError()); return 1; }
+	if (!voxelizer.Voxelize(gridDim, mode)) { fprintf(stderr, "Voxelize failed: %s\n", voxelizer.LastError()); return 1; }
+	// Init was told the grid: a launch of the reference rule through the lists is the prepared one (queue from Init, one dispatch)
+	dxv_stats st;
+	if (!voxelizer.GetStats(st)) return 1;
+	if (mode == Voxelizer::REFERENCE && st.list_entries && !st.plan_prepared) { fprintf(stderr, "the launch did not use the queue Init prepared\n"); return 1; }
 	std::vector<uint8_t> grid;
 	uint64_t solid = 0;
 	if (!voxelizer.Download(grid) || !voxelizer.CountSolid(solid)) { fprintf(stderr, "%s\n", voxelizer.LastError()); return 1; }

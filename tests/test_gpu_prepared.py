@@ -68,6 +68,11 @@ def test_prepared_launch_equals_oracle_fixture_whatever_the_grid_held(dxv, confi
             check_whole(v.Grid(), configs[key], f"{key} prepared, prepclear={clear}")
         chk = v.plan_check()
         assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == st["plan_bricks"], chk
+        # the whole wave scanning a lone lane's long list (option coop, default on) looks at the same entries in another order: same grid without
+        v.set_option("coop", 0)
+        v.Voxelize(N)
+        check_whole(v.Grid(), configs[key], f"{key} prepared, every lane scanning alone")
+        v.set_option("coop", 1)
         # preparing again finds the partition prepared; option prepared = 0 goes back to a queue per launch
         v.PrepareLaunch(N)
         v.set_option("prepared", 0)

@@ -29,11 +29,39 @@ def test_slab_ranges_cover_the_grid():
     assert sorted(allz) == list(range(512)) and list(interleaved_slices(512, 3, 8, 8)[:9]) == [24, 25, 26, 27, 28, 29, 30, 31, 88]
 
 
+def test_prepare_share_names_the_rank_s_own_partition():
+    """slabs.prepare_share: every rank prepares the work queue of ITS share after the import -- the block-cyclic share when the grid
+    divides into blocks of zblock slices for every rank, else its contiguous slab, nothing for an empty slab."""
+    from dxrvoxelizer_amd.slabs import prepare_share
+
+    class Recorder:
+        def __init__(self):
+            self.calls = []
+
+        def PrepareLaunch(self, N, z0, nz):
+            self.calls.append(("slab", N, z0, nz))
+
+        def PrepareLaunchInterleaved(self, N, rank, world, zblock):
+            self.calls.append(("interleaved", N, rank, world, zblock))
+
+    for N, W, zb, want in ((512, 8, 4, "interleaved"), (512, 8, 0, "slab"), (100, 8, 4, "slab"), (512, 1, 0, "slab")):
+        for r in range(W):
+            e = Recorder()
+            assert prepare_share(e, N, r, W, zb) == want
+            assert e.calls == ([("interleaved", N, r, W, zb)] if want == "interleaved" else [("slab", N) + slab_range(N, r, W)])
+    e = Recorder()
+    assert prepare_share(e, 4, 7, 8) is None and e.calls == []          # (more ranks than slices: rank 7 owns nothing)
+
+
 class HostEngine:
     """scene blob = [V, T, vb, ib] in host memory; voxelize through the oracle."""
 
     def __init__(self):
         self.blob = None
+        self.prepared = None
+
+    def PrepareLaunch(self, N, z0, nz):
+        self.prepared = (N, z0, nz)
 
     def set_mesh(self, vb, ib):
         hdr = np.array([len(vb), len(ib) // 3], np.uint64)
@@ -75,6 +103,8 @@ def _worker(rank, world, port, outdir):
     assert len(set(info["checksums"])) == 1 and info["checksum"] == info["checksums"][0] != 0
     assert info["checksum"] == int(eng.blob[: nbytes - nbytes % 8].view(np.uint64).sum(dtype=np.uint64))
     z0, nz = slab_range(32, rank, world)
+    from dxrvoxelizer_amd.slabs import prepare_share
+    assert prepare_share(eng, 32, rank, world) == "slab" and eng.prepared == (32, z0, nz)   # (after the import, before the launches)
     g = eng.voxelize(32, z0, nz)
     np.save(os.path.join(outdir, f"slab{rank}.npy"), g)
     np.save(os.path.join(outdir, f"meta{rank}.npy"), np.array([z0, nz, nbytes]))

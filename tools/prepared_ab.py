@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Launch disciplines side by side, in one process on one GPU, timed like bench.py's region (K back-to-back steps by wall clock,
 best of 3): the full grid and every rank's share of the block-cyclic partition at `world` ranks, for
-    prepared / clear 0, 1, 2   queue from Init (dxv_prepare_launch), grid cleared inside the launch: by a kernel of its own (0), by
-                               workgroups in front of (1) / behind (2) the bricks' in the same dispatch
+    prepared                   queue from Init (dxv_prepare_launch), the unqueued bricks zeroed by workgroups behind the bricks' in the same dispatch
+                               (the default); ..._every_lane_scans_alone: option coop = 0; ..._clear_in_front / _clear_kernel: prepclear = 1 / 0
     unprepared                 queue built inside every launch (plan = 2, persistent waves)
     kept                       queue and zeros kept (plan = 1, hardware dispatch once a sync has read the lengths)
 with 1, 2 and 3 voxelizations in flight.  Slowest share against the full grid's step of the SAME discipline with ONE in flight is
@@ -32,8 +32,9 @@ for r in range(world):
 v.set_option("events", 0)
 K = 300
 
-DISC = {"prepared_clear3": {"prepared": 1, "prepclear": 3, "plan": 2}, "prepared_clear2": {"prepared": 1, "prepclear": 2, "plan": 2}, "prepared_clear1": {"prepared": 1, "prepclear": 1, "plan": 2},
-        "prepared_clear0": {"prepared": 1, "prepclear": 0, "plan": 2}, "unprepared": {"prepared": 0, "plan": 2}, "kept": {"prepared": 0, "plan": 1}}
+DISC = {"prepared": {"prepared": 1, "prepclear": 2, "plan": 2, "coop": 1}, "prepared_every_lane_scans_alone": {"prepared": 1, "prepclear": 2, "plan": 2, "coop": 0},
+        "prepared_clear_in_front": {"prepared": 1, "prepclear": 1, "plan": 2, "coop": 1}, "prepared_clear_kernel": {"prepared": 1, "prepclear": 0, "plan": 2},
+        "unprepared": {"prepared": 0, "plan": 2}, "kept": {"prepared": 0, "plan": 1}}
 
 
 def loop(frames, launch):
