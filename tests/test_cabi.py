@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol(dxvlib):
     assert sorted(_lib.SYMBOLS) == names          # the Python binding covers the whole header
 
 
+def test_every_option_the_library_takes_is_documented_in_the_header():
+    """dxv_set_option's keys (csrc/dxv_api.hip) against the list in include/dxv.h: a knob nobody can read about is a bug of the boundary."""
+    src = open(os.path.join(ROOT, "dxrvoxelizer_amd", "csrc", "dxv_api.hip")).read()
+    keys = set(re.findall(r'strcmp\(key, "([a-z0-9]+)"\)', src))
+    assert {"plan", "prepared", "prepclear", "lists", "coop", "farmap"} <= keys
+    header = open(os.path.join(ROOT, "include", "dxv.h")).read()
+    doc = header[header.index("Tuning knobs"):header.index("DXV_API int dxv_set_option")]
+    documented = set(re.findall(r"^ \*\s+([a-z0-9]+)\s", doc, re.M)) | set(re.findall(r"\b([a-z0-9]+) 0\|", doc))
+    missing = sorted(k for k in keys - {"ablate"} if k not in documented and not re.search(r"\b" + k + r"\b", doc))
+    assert not missing, f"options without a line in include/dxv.h: {missing}"
+
+
 def test_no_oracle_in_product():
     """The product never routes through the oracle: no source of the package mentions it and the
     library does not link it."""

@@ -75,19 +75,26 @@ def main():
                     "plists": int(rng.integers(0, 3)), "plistres": int(rng.choice([0, 0, 16, 128, 1024])),
                     "plan": int(rng.integers(0, 3)), "queuewaves": int(rng.choice([0, 0, 8, 64, 1000])),
                     "dispatch": int(rng.choice([1, 1, 0, 2])), "planregion": int(rng.choice([0, 0, 6, 7, 8])),
-                    "planheavy": int(rng.choice([0, 0, 0, 3, 65535])), "fuse": int(rng.choice([1, 1, 0])), "queueheads": int(rng.choice([8, 8, 8, 1, 2, 4]))}
+                    "planheavy": int(rng.choice([0, 0, 0, 3, 65535])), "fuse": int(rng.choice([1, 1, 0])), "queueheads": int(rng.choice([8, 8, 8, 1, 2, 4])),
+                    "prepared": int(rng.choice([1, 1, 1, 0])), "prepclear": int(rng.integers(0, 4)), "coop": int(rng.choice([1, 1, 0])),
+                    "farmap": int(rng.choice([1, 1, 0]))}
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))
+            prep = bool(rng.integers(0, 2))                   # the partition's work queue prepared before the launches (Init-time structure) or not
             v.SetFrame(int(rng.integers(0, 3)))               # any of the context's frames in flight
             again = int(rng.choice([1, 1, 2, 3]))             # the same launch again: kept memsets and work queues from the second launch on
             try:
                 if part == 0:
+                    if prep:
+                        v.PrepareLaunch(N)
                     for _ in range(again):
                         v.Voxelize(N, mode)
                     got, ref = v.Grid(), want
                 elif part == 1:
                     z0 = int(rng.integers(0, N)); nz = int(rng.integers(1, N - z0 + 1))
+                    if prep:
+                        v.PrepareLaunch(N, z0, nz)
                     for _ in range(again):
                         v.Voxelize(N, mode, z0, nz)
                     got, ref = v.Grid(), want[z0:z0 + nz]
@@ -96,6 +103,8 @@ def main():
                     if N % (world * zb):
                         continue
                     rank = int(rng.integers(0, world))
+                    if prep:
+                        v.PrepareLaunchInterleaved(N, rank, world, zb)
                     for _ in range(again):
                         v.VoxelizeInterleaved(N, rank, world, zb, mode)
                     zs = np.concatenate([np.arange(b, b + zb) for b in range(rank * zb, N, world * zb)])
@@ -117,6 +126,14 @@ def main():
                     print(json.dumps({"FAIL": label, "plan_check": chk, "T": T, "N": N, "part": part, "opts": opts, "seed": seed}))
                     sys.exit(1)
                 queued += chk["queued_bricks"]
+            if mode == 0 and T * N ** 3 < 2e9 and rng.integers(0, 4) == 0:
+                # the brick test of the launches over the brick box: no ray of a brick it calls dead hits anything (the triangles' own far-radius
+                # map, and the lists' mip when the scene has lists)
+                for lists_mip in ((False, True) if v.stats()["list_entries"] > 0 else (False,)):
+                    fc = v.far_check(N, lists_mip=lists_mip)
+                    if fc["violations"]:
+                        print(json.dumps({"FAIL": label, "far_check": fc, "lists_mip": lists_mip, "T": T, "N": N, "opts": opts, "seed": seed}))
+                        sys.exit(1)
             if mode == 0 and v.stats()["list_entries"] > 0 and T * N ** 3 < 2e9:
                 # the lists in use, exhaustively: every triangle the canonical step accepts for a ray is selectable from its list
                 accepted, violations, first = v.list_check(N)
