@@ -165,6 +165,8 @@ struct dxv_ctx {
     // far-radius map of a scene WITHOUT lists (dirmap_far): the brick test of its tree walks; made at the scene's first tree walk
     uint64_t sceneEpoch = 0;         // counts builds / refits / imports
     uint64_t farEpoch = 0;           // ... the one the far map was made for (0: none)
+    uint64_t boxLaunchEpoch = 0;     // the scene epoch boxLaunchesOfScene counts for
+    uint32_t boxLaunchesOfScene = 0; // reference-rule launches over the brick box (tree walks, plan = 0) since the scene last changed
     uint32_t* dFar32 = nullptr;
     DirCell* dFarCells = nullptr;
     uint16_t* dFarMip = nullptr;

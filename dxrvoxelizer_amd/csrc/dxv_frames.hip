@@ -316,9 +316,15 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
         // a launch over the brick box (tree walk, or the lists under plan = 0): every workgroup makes the queue's brick test itself --
         // against the lists' max-mip when the scene has (settled) lists, else against the far-radius map of the triangles' own
         // footprints, made once per scene at its first such launch (dirmap_far: 0.2 ms at 1 M triangles)
+        // (dxv_policy.h, far_map_build_now: at the scene's second such launch -- a mesh refitted every frame goes without)
+        if (c->boxLaunchEpoch != c->sceneEpoch) { c->boxLaunchEpoch = c->sceneEpoch; c->boxLaunchesOfScene = 0; }
+        const bool haveFar = c->farEpoch == c->sceneEpoch && c->dFarMip;
         if (c->listState == 1 && c->dMip && !c->listCheckPending) { p.mip = c->dMip; p.mipR = c->listRes; }
-        else if (ensure_far_map(c, fs) == 0 && c->farEpoch == c->sceneEpoch) { p.mip = c->dFarMip; p.mipR = c->farR; }
-        else return 1;
+        else if (haveFar || far_map_build_now(haveFar, c->boxLaunchesOfScene)) {
+            if (ensure_far_map(c, fs)) return 1;
+            p.mip = c->dFarMip; p.mipR = c->farR;
+        }
+        if (!relaunch) ++c->boxLaunchesOfScene;
     }
     if ((p.mode == DXV_MODE_REFERENCE && p.lists) || (p.mode == DXV_MODE_PARITY && c->optRows && p.scene.plCells)) f.lastCanFail = false;
     if (c->optEvents) DXV_HIP(c, hipEventRecord(f.ev0, fs));

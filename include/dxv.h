@@ -341,7 +341,8 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   farmap 0|1    launches over the brick box (tree walks -- lists = 0, dynamic first launches, scenes over the lists' caps -- and plan = 0):
  *                 every workgroup makes the queue's brick test itself and a brick none of whose rays can reach a triangle is zeroed and
  *                 left (1, default); the test reads the lists' max-mip or, for a scene without lists, a far-radius map of the triangles'
- *                 own footprints made at the scene's first such launch (0.2 ms at 1 M triangles); 0: every brick is walked
+ *                 own footprints made at the scene's SECOND such launch (0.13 ms at 1 M triangles: a mesh refitted every frame never pays
+ *                 it); 0: every brick is walked
  *   prepared 0|1  launches of a partition that dxv_prepare_launch* prepared use its queue (1, default) or build their own (0)
  *   prepclear 0|1|2|3  how a launch through a prepared queue clears its grid: 0 = a clear kernel in front of the brick kernel; 1 / 2 / 3 =
  *                 only the bricks that are not queued, by workgroups in front of / behind / spread evenly between the bricks' in the

@@ -939,6 +939,7 @@ __attribute__((visibility("default"))) int hc_queue_policy(int optPlan, int optD
     q.optPrepared = 1; q.prepared = false;
     return (int)queue_policy(q, sig, voxels);
 }
+__attribute__((visibility("default"))) int hc_far_map_build_now(int haveForScene, uint32_t boxLaunchesOfScene) { return far_map_build_now(haveForScene != 0, boxLaunchesOfScene) ? 1 : 0; }
 // ... with a queue PREPARED for the launch (dxv_prepare_launch) in the context
 __attribute__((visibility("default"))) int hc_queue_policy_prepared(int optPlan, int optDispatch, int optPrepared, int prepared, int ptrExposed, uint64_t keptSig, uint64_t lensSig,
                                                                     uint32_t queuedBricks, uint64_t sig, uint64_t voxels)

@@ -307,7 +307,7 @@ def test_tree_walk_brick_test_never_drops_a_hit(dxv, configs, key):
         if name != "soup1m":
             assert chk["dead_bricks"] > chk["bricks"] // 4 and chk["rays_walked"] > 0, chk        # (a surface mesh: most of the grid lies beyond it or outside its box)
         ms = {}
-        for far in (1, 0, 1):
+        for far in (1, 1, 0, 1):                               # (a scene's first launch over the brick box makes no map: dxv_policy.h, far_map_build_now)
             v.set_option("farmap", far)
             v.Voxelize(N)
             st = v.stats()

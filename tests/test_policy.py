@@ -169,3 +169,12 @@ def test_work_queue_kept_only_on_request_and_dealt_out_only_when_its_size_is_kno
     assert pol.hc_queue_policy(1, 2, 0, sig, sig, 60_000, sig, 1 << 25) == KEPT_HARDWARE
     # the lengths of ANOTHER queue (a sync before the partition changed) do not count
     assert pol.hc_queue_policy(1, 1, 0, sig, sig + 2, 455_584, sig, BIG) == KEPT_PERSISTENT
+
+
+def test_far_map_of_a_scene_without_lists_is_made_at_its_second_launch(pol):
+    """The tree walks' brick test reads a far-radius map made from the triangles (dirmap_far, 0.13 ms at 1 M triangles): not for a scene's
+    first launch over the brick box -- a mesh refitted every frame would pay it every frame for 1 - 5 % of one launch -- but from the second on."""
+    assert pol.hc_far_map_build_now(0, 0) == 0            # first launch of the scene: no map, every brick is walked
+    assert pol.hc_far_map_build_now(0, 1) == 1            # launched again unchanged: made now
+    assert pol.hc_far_map_build_now(0, 7) == 1
+    assert pol.hc_far_map_build_now(1, 1) == 0            # there already
