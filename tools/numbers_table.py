@@ -92,11 +92,15 @@ def main():
         cb = b.get("cpu_baseline")
         if cb:
             rows.append(("`cpu_baseline` (the oracle's BVH tracer, kind \"port\")", f"{cb['value']:.1f} M voxels/s on {cb['cores']} threads", "bench.json"))
+        src = "bench.json, profiles/traffic.json"
+        if not r.get("traffic") and j("bench_after_counters.json"):      # (the counters of these sources did not exist yet when bench.json was taken: the same command afterwards)
+            r = j("bench_after_counters.json")["roofline"]
+            src = "bench_after_counters.json, profiles/traffic.json"
         if r.get("traffic"):
             l1 = r.get("l1") or {}
             rows.append(("`roofline.traffic` (PMC: FETCH_SIZE × 2 + WRITE_SIZE per launch) and the L1 view (`roofline.l1`)",
                          f"{r['traffic'] / 1e9:.2f} GB = {r['traffic'] / r['algorithmic_bytes_per_launch']:.1f} × the algorithmic bytes; address units {100 * l1.get('ta_busy', 0):.0f} % busy, "
-                         f"{l1.get('per_brick', 0):.0f} L1 requests per brick, loads at {100 * l1.get('frac_of_load_rate', 0):.0f} % of the full-wave gather roof", "bench.json, profiles/traffic.json"))
+                         f"{l1.get('per_brick', 0):.0f} L1 requests per brick, loads at {100 * l1.get('frac_of_load_rate', 0):.0f} % of the full-wave gather roof", src))
     s = j("pmc_torus1m_summary.json")
     if s and s.get("k_voxelize_listed"):
         k = s["k_voxelize_listed"]
