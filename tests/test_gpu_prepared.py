@@ -283,3 +283,33 @@ def test_more_partitions_than_slots(dxv, orc, bunny):
         assert v.stats()["plan_prepared"] == 1
     finally:
         v.close()
+
+
+def test_prepare_launch_refuses_what_voxelize_refuses_and_warmup_is_explicit(dxv, dxvlib, bunny):
+    """Argument checks of dxv_prepare_launch* mirror dxv_voxelize*'s (same words in the message); dxv_warmup is idempotent per process and
+    device and says what it cost (0 ms once the device is warm -- the first context of this process paid, and reported it in its stats)."""
+    import ctypes as C
+    vb, ib, _ = bunny
+    v = dxv.Voxelizer(0)
+    try:
+        with pytest.raises(dxv.DxvError, match="no scene"):
+            v.PrepareLaunch(64)
+        v.InitFromArrays(vb, ib)
+        for bad in (63, 0, 4096):
+            with pytest.raises(dxv.DxvError, match="grid_dim must be even"):
+                v.PrepareLaunch(bad)
+        with pytest.raises(dxv.DxvError, match="outside the grid"):
+            v.PrepareLaunch(64, 60, 8)
+        with pytest.raises(dxv.DxvError, match="zblock a power of two"):
+            v.PrepareLaunchInterleaved(64, 0, 4, 3)
+        with pytest.raises(dxv.DxvError, match="rank < world"):
+            v.PrepareLaunchInterleaved(64, 4, 4, 4)
+        v.PrepareLaunch(64)                                     # ... and the context is still good
+        v.Voxelize(64)
+        assert v.stats()["plan_prepared"] == 1
+        ms = C.c_float(-1.0)
+        assert dxvlib.dxv_warmup(0, C.byref(ms)) == 0 and ms.value == 0.0       # (warm since this process's first dxv_create)
+        assert dxvlib.dxv_warmup(0, None) == 0 and dxvlib.dxv_warmup(-1, None) != 0
+        assert v.stats()["warmup_ms"] >= 0.0
+    finally:
+        v.close()
