@@ -5,6 +5,10 @@
 using namespace dxv;
 using namespace dxvhost;
 
+#if defined(DXV_PHASE_TIMES)
+namespace dxv { hipError_t phase_times_read(unsigned long long out[16], bool reset); }     // traverse.hip, diagnostic build only
+#endif
+
 extern "C" {
 
 int dxv_debug_list_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, uint64_t out[34])
@@ -138,6 +142,16 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
 int dxv_debug_download(dxv_ctx* c, int what, void* host, size_t bytes)
 {
     if (!c || !host) return 1;
+#if defined(DXV_PHASE_TIMES)
+    if (what == 101 || what == 102) {                                   // the lists kernel's phase sums (102: and reset); diagnostic build only
+        if (bytes != 16 * sizeof(unsigned long long)) return fail(c, "dxv_debug_download: phase times are 128 bytes");
+        DXV_HIP(c, hipSetDevice(c->device));
+        if (sync_frames(c)) return 1;
+        DXV_HIP(c, hipDeviceSynchronize());
+        DXV_HIP(c, phase_times_read(static_cast<unsigned long long*>(host), what == 102));
+        return 0;
+    }
+#endif
     const void* src = nullptr;
     size_t want = 0;
     const size_t T = c->T;

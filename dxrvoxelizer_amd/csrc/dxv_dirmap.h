@@ -750,6 +750,26 @@ DXV_HD uint32_t dm_key_cell(const DirKeyLayout& k, uint64_t key) { return (uint3
 DXV_HD uint32_t dm_key_tri(const DirKeyLayout& k, uint64_t key) { return (uint32_t)(key & ((1ull << k.triBits) - 1ull)); }
 
 constexpr uint32_t kDmCoopLanes = 2u, kDmCoopMin = 24u;     // the cooperative scan of a lone lane's long list (trace_reference_dm_from)
+// Diagnostic build (-DDXV_PHASE_TIMES, tools/phase_times.py): where a brick's TIME goes -- 100 MHz ticks between stamps of the wave's own
+// instruction stream, summed over all bricks per phase: [0] ray set-up and the texel's cell, [1] start search, [2] scan rounds,
+// [3] direction / shear at a flush, [4] triangle rounds, [5] predicate and stores; [6] bricks, [7] scan rounds counted, [8] triangle
+// rounds counted, [9] flushes.  A stall on a load is charged to the phase that first uses the value.
+#if defined(DXV_PHASE_TIMES) && defined(__HIPCC__)
+constexpr uint32_t kPhaseSlots = 1u << 16;                   // (a workgroup adds to the slot of its number: no two waves in flight share a word for long)
+static __device__ unsigned long long g_dxvPhase[kPhaseSlots * 16u];
+#endif
+#if defined(DXV_PHASE_TIMES) && defined(__HIP_DEVICE_COMPILE__)
+#define DXV_PHASE_BEGIN() unsigned long long tPhase_ = __builtin_amdgcn_s_memrealtime(), ph_[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}
+#define DXV_PHASE(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); ph_[k] += now_ - tPhase_; tPhase_ = now_; } while (0)
+#define DXV_COUNT(k) do { ph_[k] += 1ull; } while (0)
+#define DXV_PHASE_END() do { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) { unsigned long long* slot_ = g_dxvPhase + (size_t)(blockIdx.x & (kPhaseSlots - 1u)) * 16u; \
+    for (int k_ = 1; k_ < 10; ++k_) if (ph_[k_]) atomicAdd(slot_ + k_, ph_[k_]); } } while (0)
+#else
+#define DXV_PHASE_BEGIN() do { } while (0)
+#define DXV_PHASE(k) do { } while (0)
+#define DXV_COUNT(k) do { } while (0)
+#define DXV_PHASE_END() do { } while (0)
+#endif
 // closest hit of the reference rule through the lists
 // Two steps like the postponed-leaf walks: scanning entries is short and cheap, the triangle step is
 // long, so the triangles an entry scan selects are queued in the thread's LDS column (cap entries)
@@ -766,6 +786,7 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
 {
     best.t = kTMax; best.b1 = 0.0f; best.b2 = 0.0f; best.k = 0xffffffffu; best.leaf = -1;
     if (ABL & 8) return;
+    DXV_PHASE_BEGIN();
     const DirCell cell = start.cell;
     const uint32_t cx = start.cx, cy = start.cy;
     const float rho = start.rho, near = start.near;
@@ -789,6 +810,7 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
         const uint32_t mid = i + ((hi - i) >> 1);
         if (dm_entry_r1(dm.entries[mid]) < near) i = mid + 1u; else hi = mid;
     }
+    DXV_PHASE(1);
     int qn = 0;
     bestDet = 1.0f;                                                     // divisor of the closest hit's barycentrics (the caller's finish_hit)
     const float step = dm_stop_step(half_bits_to_float(cell.thick));
@@ -890,13 +912,16 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
             }
         }
         const bool scanning = wave_any(i < end);
+        DXV_PHASE(2); DXV_COUNT(7);
         if (scanning && !wave_any(2 * (qn + 4) > cap)) continue;
+        DXV_COUNT(9);
         if (ABL & 2) { if (qn > 100) best.k = 0u; }
         else {
             // direction, 1 / d, -o / d (hlsl:52 and the slab constants): only now, after the scan of the short lists of a
             // surface mesh is over -- two waves in five never get here, and the scan runs with a dozen registers less
             finish_ray_reference(r, rho);                               // (|o| is the ray's start radius: the same expression, dm_ray_point)
             ray_shear_finished(r);                                      // (here, not at the first triangle: the direction's registers are free through the tests)
+            DXV_PHASE(3);
             // Every lane takes its queued triangles in turn, but looks at an item's near radius once more first: what starts
             // beyond a hit found since it was queued is dropped unfetched, so a round is one triangle for every lane that
             // still has a live item (the most loaded lane of a wave decides how many rounds there are).
@@ -910,11 +935,14 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
                     rc = dm_radial_word(near, bound);
                     ++k;
                 }
+                DXV_COUNT(8);
             }
+            DXV_PHASE(4);
         }
         qn = 0;
         if (!scanning) break;
     }
+    DXV_PHASE_END();
 }
 
 // Row lists of the parity rule (dirmap.hip): the texels of the R x R grid over the (y, z) plane that a triangle's padded box --

@@ -15,6 +15,8 @@
 #include "dxv_device.h"
 #include "dxv_trace.h"
 #include "dxv_dirmap.h"
+#include <algorithm>
+#include <vector>
 
 namespace dxv {
 
@@ -696,6 +698,9 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
         }
     }
     const uint32_t x = wg & 7u, k = wg >> 3;
+#if defined(DXV_PHASE_TIMES)
+    const unsigned long long tPhase0_ = __builtin_amdgcn_s_memrealtime();
+#endif
 #if defined(DXV_QUEUE_TIMES)
     const uint64_t tStart = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0u && 3u * wg + 2u < p.redoCap) { p.redo[3u * wg] = 0; p.redo[3u * wg + 1u] = 0; }
@@ -703,7 +708,13 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
     // (x's equal share of the launch: its own queue's first bricks, then what longer queues hold beyond theirs -- queue_item)
     uint32_t qy, qslot;
     if (!queue_item(lens, p.queueCap, x, k, qy, qslot)) return;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.queueSlots[(size_t)qy * p.queueCap + qslot]);
+    // the brick's word through the SCALAR cache (one word per wave; the queue was written long before this launch): as a vector load it was
+    // a round trip through the busy vector-memory pipe (~1 us of a 10 us brick) in front of everything else the workgroup does
+    uint32_t w;
+    {
+        const uint32_t* slot = p.queueSlots + (uint32_t)__builtin_amdgcn_readfirstlane((int)(qy * p.queueCap + qslot));     // (8 cap <= 2^27 bricks)
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(slot) : "memory");
+    }
     const SceneView& sc = p.scene;
     const uint32_t N = p.N, nz = p.nz;
     const uint32_t bx = w & 1023u, by = (w >> 10) & 1023u, bz = w >> 20;
@@ -720,7 +731,13 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
     Hit best;
     float bestDet = 1.0f;
     const StridedStack stk{stack + tid, 64};
+#if defined(DXV_PHASE_TIMES)
+    { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0u) { unsigned long long* slot_ = g_dxvPhase + (size_t)(blockIdx.x & (kPhaseSlots - 1u)) * 16u; atomicAdd(slot_, now_ - tPhase0_); atomicAdd(slot_ + 6, 1ull); } }
+#endif
     trace_reference_dm_from<StridedStack, 0>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
+#if defined(DXV_PHASE_TIMES)
+    const unsigned long long tPhase5_ = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t texel = 0;
     const uint8_t occ = shade_reference<4, 0>(sc, r, best, bestDet, TEXELS ? &texel : nullptr);
     if (TEXELS || (N & 3u) != 0u) {
@@ -738,6 +755,9 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
             *reinterpret_cast<uint32_t*>(p.grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;
         }
     }
+#if defined(DXV_PHASE_TIMES)
+    { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0u) atomicAdd(g_dxvPhase + (size_t)(blockIdx.x & (kPhaseSlots - 1u)) * 16u + 5, now_ - tPhase5_); }
+#endif
 #if defined(DXV_QUEUE_TIMES)
     // (diagnostic build only, tools/wg_times.py: start and end of every workgroup in 100 MHz ticks, and the XCD it ran on)
     if (threadIdx.x == 0u && 3u * wg + 2u < p.redoCap) {
@@ -804,6 +824,22 @@ hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32
     else k_voxelize_queue<false><<<dim3(waves), dim3(64), 0, s>>>(p);
     return hipGetLastError();
 }
+
+#if defined(DXV_PHASE_TIMES)
+// diagnostic build: the phase sums of the lists kernel (dxv_dirmap.h, DXV_PHASE) since the last reset
+hipError_t phase_times_read(unsigned long long out[16], bool reset)
+{
+    std::vector<unsigned long long> all((size_t)kPhaseSlots * 16u);
+    hipError_t e = hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_dxvPhase), all.size() * sizeof(unsigned long long));
+    for (int k = 0; k < 16; ++k) out[k] = 0;
+    for (size_t i = 0; i < all.size(); ++i) out[i & 15u] += all[i];
+    if (e == hipSuccess && reset) {
+        std::fill(all.begin(), all.end(), 0ull);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_dxvPhase), all.data(), all.size() * sizeof(unsigned long long));
+    }
+    return e;
+}
+#endif
 
 // A launch through a PREPARED queue (dxv_device.h): the queue is a pure function of (static scene's lists, grid, partition) and was
 // built when those were fixed -- Init, dxv_prepare_launch -- like the lists themselves (the reference builds everything its frames
