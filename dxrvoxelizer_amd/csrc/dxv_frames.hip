@@ -315,8 +315,8 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
     if (p.mode == DXV_MODE_REFERENCE && !queued && c->optFarMap && c->optBrick == 4 && !c->optAblate) {
         // a launch over the brick box (tree walk, or the lists under plan = 0): every workgroup makes the queue's brick test itself --
         // against the lists' max-mip when the scene has (settled) lists, else against the far-radius map of the triangles' own
-        // footprints, made once per scene at its first such launch (dirmap_far: 0.2 ms at 1 M triangles)
-        // (dxv_policy.h, far_map_build_now: at the scene's second such launch -- a mesh refitted every frame goes without)
+        // footprints (dirmap_far: 0.13 ms at 1 M triangles), made at the scene's SECOND such launch -- a mesh refitted every frame
+        // goes without (dxv_policy.h, far_map_build_now)
         if (c->boxLaunchEpoch != c->sceneEpoch) { c->boxLaunchEpoch = c->sceneEpoch; c->boxLaunchesOfScene = 0; }
         const bool haveFar = c->farEpoch == c->sceneEpoch && c->dFarMip;
         if (c->listState == 1 && c->dMip && !c->listCheckPending) { p.mip = c->dMip; p.mipR = c->listRes; }
