@@ -265,6 +265,13 @@ int dxv_trim(dxv_ctx* c)
     c->dListScratchA = c->dListScratchB = nullptr; c->listScratchACap = c->listScratchBCap = 0;
     c->specRes = 0;
     if (!c->haveHierarchy) free_scratch(c);                             // (a built scene keeps keys and links: dxv_refit reads them)
+    // prepared queues of lists that are gone (their slots keep their memory for the next dxv_prepare_launch of the partition: 8 MB at
+    // 512^3, half a gigabyte at 2048^3); the ones in use stay
+    for (auto& q : c->prepared)
+        if (q.epoch != c->listEpoch || c->listState != 1) {
+            (void)hipFree(q.dMem); (void)hipFree(q.dLive);
+            q.dMem = q.dLive = nullptr; q.words = q.liveWords = 0; q.epoch = 0; q.bricks = 0;
+        }
     return 0;
 }
 

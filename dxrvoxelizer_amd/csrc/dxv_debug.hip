@@ -106,7 +106,12 @@ int dxv_debug_plan_check(dxv_ctx* c, uint64_t out[16])
     if (!c || !out) return 1;
     Frame& f = cur_frame(c);
     if (settle_lists(c)) return 1;
-    const bool prepared = f.lastPrepared >= 0 && c->prepared[f.lastPrepared].epoch == c->listEpoch;
+    // (the frame's last launch ran a queue of the context's: still the one for that partition?  A slot may have been reused since)
+    bool prepared = f.lastPrepared >= 0 && c->prepared[f.lastPrepared].epoch == c->listEpoch;
+    if (prepared) {
+        const auto& q = c->prepared[f.lastPrepared];
+        prepared = q.N == f.grid_dim && q.z0 == f.z0 && q.nz == f.nz && q.zBlock == f.lastZBlock && q.zPeriod == f.lastZPeriod && q.dMem;
+    }
     if (!c->haveScene || c->listState != 1 || !(prepared || (f.lastQueued && f.dQueue)) || !f.grid_dim)
         return fail(c, "dxv_debug_plan_check: the current frame's last launch did not go through a work queue");
     DXV_HIP(c, hipSetDevice(c->device));

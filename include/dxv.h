@@ -394,7 +394,8 @@ DXV_API int dxv_debug_far_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, ui
 DXV_API int dxv_debug_plan_check(dxv_ctx* ctx, uint64_t out[16]);
 
 /* Give back what the context keeps only to make the next build faster: the list build's scratch (up to 16 GiB per buffer
- * after a 10 M-triangle scene), the LBVH build's scratch when no refit can follow (imported scenes).  Nothing a launch reads. */
+ * after a 10 M-triangle scene), the LBVH build's scratch when no refit can follow (imported scenes), the memory of prepared queues
+ * whose lists are gone.  Nothing a launch reads. */
 DXV_API int dxv_trim(dxv_ctx* ctx);
 
 /* Test hook: copy an internal device array to the host (enum above). */
