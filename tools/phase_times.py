@@ -21,6 +21,8 @@ v = dxv.Voxelizer(0)
 for kv in filter(None, (sys.argv[4] if len(sys.argv) > 4 else "").split(",")):
     v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 vb, ib, _ = make_mesh(mesh)
+if os.environ.get("PHASE_TEXELS"):
+    v.EnableTexels(True)                                   # (the reference's texel image beside the grid: the normal of every inside hit)
 v.InitFromArrays(vb, ib, gridDim=N)
 v.Voxelize(N)
 raw = np.zeros(16, np.uint64)
@@ -34,7 +36,7 @@ names = ["setup_and_cell", "start_search", "scan_rounds", "direction_and_shear",
 bricks = int(raw[6]) or 1
 us = {n: float(raw[i]) / 100.0 / bricks for i, n in enumerate(names)}
 tot = sum(us.values())
-print(json.dumps({"mesh": mesh, "N": N, "launches": K, "kernel_ms_instrumented": round(float(np.median(ms)), 4), "bricks_per_launch": bricks // K,
+print(json.dumps({"mesh": mesh, "N": N, "texels": bool(os.environ.get("PHASE_TEXELS")), "launches": K, "kernel_ms_instrumented": round(float(np.median(ms)), 4), "bricks_per_launch": bricks // K,
                   "us_per_brick": {k: round(x, 2) for k, x in us.items()}, "us_per_brick_total": round(tot, 2),
                   "share": {k: round(x / tot, 3) for k, x in us.items()},
                   "scan_rounds_per_brick": round(float(raw[7]) / bricks, 2), "triangle_rounds_per_brick": round(float(raw[8]) / bricks, 2), "flushes_per_brick": round(float(raw[9]) / bricks, 2)}))
