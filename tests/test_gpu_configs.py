@@ -340,15 +340,25 @@ def test_headline_partition_of_bench_at_8_ranks(dxv, configs):
     v = dxv.Voxelizer(0)
     try:
         init(v, configs, key)
-        for plan in (2, 1):                                    # the headline's steps (nothing carried) and config.kept_step's
+        # the headline's steps (every rank's share prepared after Init, as bench.py does: queue from Init, grid cleared inside the launch),
+        # config.unprepared_step's (queue built inside the launch) and config.kept_step's
+        for what, plan, prepare in (("prepared", 2, True), ("unprepared", 2, False), ("kept", 1, False)):
             v.set_option("plan", plan)
+            v.set_option("prepared", 1 if prepare else 0)
             parts = []
             for r in range(W):
+                if prepare:
+                    v.PrepareLaunchInterleaved(N, r, W, blk)
                 for _ in range(3):
                     v.VoxelizeInterleaved(N, r, W, blk)
-                assert v.stats()["plan_bricks"] > 0
+                st = v.stats()
+                assert st["plan_bricks"] > 0 and st["plan_prepared"] == (1 if prepare else 0)
+                if prepare and r in (0, 5):
+                    chk = v.plan_check()
+                    assert chk["violations"] == 0 and chk["duplicates"] == 0 and chk["queued_bricks"] == st["plan_bricks"], (r, chk)
                 parts.append((r, v.Grid().copy()))
-            check_whole(scatter_interleaved(parts, N, W, blk), configs[key], f"8 ranks x blocks of 4 slices, plan = {plan}")
+            check_whole(scatter_interleaved(parts, N, W, blk), configs[key], f"8 ranks x blocks of 4 slices, {what}")
+        v.set_option("prepared", 1)
     finally:
         v.close()
 
