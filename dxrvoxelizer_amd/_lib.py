@@ -84,6 +84,7 @@ SYMBOLS = {
     "dxv_debug_list_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "dxv_debug_class_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "dxv_debug_plan_check": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dxv_debug_division_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "dxv_debug_far_check": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "dxv_trim": (C.c_int, [C.c_void_p]),
     "dxv_api_version": (C.c_int, []),

@@ -68,6 +68,22 @@ int dxv_debug_class_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, uint
     return 0;
 }
 
+int dxv_debug_division_check(dxv_ctx* c, uint32_t n_first, uint32_t n_last, uint64_t out[8])
+{
+    if (!c || !out) return 1;
+    if (n_first < 2 || (n_first & 1u) || n_last > 2048 || n_last < n_first) return fail(c, "dxv_debug_division_check: need even 2 <= n_first <= n_last <= 2048");
+    DXV_HIP(c, hipSetDevice(c->device));
+    unsigned long long* dOut = nullptr;
+    DXV_HIP(c, hipMalloc(&dOut, 10 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(dOut, 0, 10 * sizeof(unsigned long long), c->stream);
+    for (uint32_t N = n_first; N <= n_last && e == hipSuccess; N += 2u) e = launch_division_check(N, dOut, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(c, "dxv_debug_division_check failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int dxv_debug_far_check(dxv_ctx* c, uint32_t N, uint32_t z0, uint32_t nz, int lists_mip, uint64_t out[12])
 {
     if (!c || !out) return 1;

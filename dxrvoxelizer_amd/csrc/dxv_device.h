@@ -155,6 +155,7 @@ int stack_round_up(int want);
 int stack_for_brick(int brickShape, int want);   // the column depth compiled for this brick shape that is >= want
 hipError_t launch_parity_rows(const VoxelizeParams& p, int rowBlock, hipStream_t s);   // parity mode: one walk per row run (1) or per 2 x 2 rows (2)
 hipError_t launch_list_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);   // test hook: superset claim of the lists (slices [p.z0, p.z0 + p.nz))
+hipError_t launch_division_check(uint32_t N, unsigned long long* out, hipStream_t s);             // test hook: the ray set-up's divisions against `/` for every voxel of an N^3 grid (out: 10 words, zeroed by the caller)
 hipError_t launch_far_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);    // test hook: the brick test of the brick-box launches (p.mip, p.mipR; slices [p.z0, p.z0 + p.nz))
 hipError_t launch_class_check(const VoxelizeParams& p, unsigned long long* out, hipStream_t s);  // test hook: per-triangle class of the normal test against the predicate
 hipError_t launch_count(const uint8_t* grid, size_t n, unsigned long long* out, hipStream_t s);

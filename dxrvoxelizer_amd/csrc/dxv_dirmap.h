@@ -177,9 +177,13 @@ DXV_HD float dm_entry_r0(const DirEntry& e) { return half_bits_to_float(0x7fffu 
 DXV_HD void dm_ray_point(float ox, float oy, float oz, uint32_t& face, float& u, float& v, float& rho)
 {
     const float ax = __builtin_fabsf(ox), ay = __builtin_fabsf(oy), az = __builtin_fabsf(oz);
-    if (ax >= ay && ax >= az) { face = ox < 0.0f ? 1u : 0u; u = oy / ax; v = oz / ax; }
-    else if (ay >= az) { face = oy < 0.0f ? 3u : 2u; u = oz / ay; v = ox / ay; }
-    else { face = oz < 0.0f ? 5u : 4u; u = ox / az; v = oy / az; }
+    // (the two quotients share their denominator: div_by, dxv_math.h -- the same bits as `/` for these operands, checked exhaustively)
+    float a, nb, nc;
+    if (ax >= ay && ax >= az) { face = ox < 0.0f ? 1u : 0u; a = ax; nb = oy; nc = oz; }
+    else if (ay >= az) { face = oy < 0.0f ? 3u : 2u; a = ay; nb = oz; nc = ox; }
+    else { face = oz < 0.0f ? 5u : 4u; a = az; nb = ox; nc = oy; }
+    const RcpRefined byA = rcp_refined(a);
+    u = div_by(nb, byA); v = div_by(nc, byA);
     rho = __builtin_sqrtf((ox * ox + oy * oy) + oz * oz);
 }
 

@@ -24,6 +24,41 @@ DXV_HD float abs_(float a) { return __builtin_fabsf(a); }
 DXV_HD float sel3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
 
 // ------------------------------------------------------------------------------------------
+// a / b, correctly rounded, for operands the RAY SET-UP divides: voxel-centre coordinates, their length, direction components
+// (|a|, |b| in [2^-13, 2^12], |a / b| in [2^-13, 2^12]).  The compiler's quotient is the IEEE sequence  div_scale x 2, rcp, two
+// Newton steps on the reciprocal, the product, two residual corrections, div_fmas, div_fixup  -- eleven instructions, of which
+// div_scale and div_fixup only act on operands near the ends of the exponent range or on specials, and div_fmas is a plain fma when
+// nothing was scaled.  In that range the quotient is therefore the eight instructions below, bit for bit, and the first three depend on the
+// DENOMINATOR alone: the three components of o / |o|, the two texel coordinates, the two shear constants share them.  The host (oracle-side
+// checks, tests/hostcheck) divides with `/`: equality of the two on EVERY voxel origin of every even grid up to 2048^3 is checked on the
+// device (dxv_debug_division_check, tests/test_gpu_parity.py).  Divisions whose operands depend on the mesh (t, barycentrics, the normal)
+// stay `/`.
+// ------------------------------------------------------------------------------------------
+struct RcpRefined { float b, r; };                            // a denominator and its reciprocal after two Newton steps
+DXV_HD RcpRefined rcp_refined(float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DXV_IEEE_SETUP_DIVISIONS)
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r0, 1.0f);
+    return RcpRefined{b, __builtin_fmaf(e0, r0, r0)};
+#else
+    return RcpRefined{b, 0.0f};
+#endif
+}
+DXV_HD float div_by(float a, const RcpRefined& d)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DXV_IEEE_SETUP_DIVISIONS)
+    const float q0 = a * d.r;
+    const float e1 = __builtin_fmaf(-d.b, q0, a);
+    const float q1 = __builtin_fmaf(e1, d.r, q0);
+    const float e2 = __builtin_fmaf(-d.b, q1, a);
+    return __builtin_fmaf(e2, d.r, q1);
+#else
+    return a / d.b;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // Ray generation: Content/Shaders/DXRVoxelizer.hlsl:44-53 (generateRay), :64-67 (un-flatten).
 // ------------------------------------------------------------------------------------------
 struct Ray {
@@ -46,9 +81,10 @@ DXV_HD void ray_origin(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, float&
         oz = ((float)iz + 0.5f) * rn * 2.0f - 1.0f;
         return;
     }
-    ox = ((float)ix + 0.5f) / fn * 2.0f - 1.0f;          // hlsl:46
-    oy = -(((float)iy + 0.5f) / fn * 2.0f - 1.0f);       // hlsl:49
-    oz = ((float)iz + 0.5f) / fn * 2.0f - 1.0f;
+    const RcpRefined byN = rcp_refined(fn);
+    ox = div_by((float)ix + 0.5f, byN) * 2.0f - 1.0f;          // hlsl:46
+    oy = -(div_by((float)iy + 0.5f, byN) * 2.0f - 1.0f);       // hlsl:49
+    oz = div_by((float)iz + 0.5f, byN) * 2.0f - 1.0f;
 }
 
 // A radial ray whose origin lies beyond the scene's root box on the side it is moving to can not
@@ -78,9 +114,10 @@ DXV_HD void ray_shear(Ray& r)
     const float dkz = sel3(r.dx, r.dy, r.dz, kz);
     if (dkz < 0.0f) { const int t = kx; kx = ky; ky = t; }
     r.kx = kx; r.ky = ky; r.kz = kz;
-    r.Sx = sel3(r.dx, r.dy, r.dz, kx) / dkz;
-    r.Sy = sel3(r.dx, r.dy, r.dz, ky) / dkz;
-    r.Sz = 1.0f / dkz;
+    const RcpRefined byDkz = rcp_refined(dkz);
+    r.Sx = div_by(sel3(r.dx, r.dy, r.dz, kx), byDkz);
+    r.Sy = div_by(sel3(r.dx, r.dy, r.dz, ky), byDkz);
+    r.Sz = div_by(1.0f, byDkz);
 }
 // the same for a ray whose 1 / d is in place (finish_ray_reference): 1 / d[kz] is one of its three words -- the same operation on the
 // same operand, bit for bit -- so the third division is a select
@@ -95,8 +132,9 @@ DXV_HD void ray_shear_finished(Ray& r)
     const float dkz = sel3(r.dx, r.dy, r.dz, kz);
     if (dkz < 0.0f) { const int t = kx; kx = ky; ky = t; }
     r.kx = kx; r.ky = ky; r.kz = kz;
-    r.Sx = sel3(r.dx, r.dy, r.dz, kx) / dkz;
-    r.Sy = sel3(r.dx, r.dy, r.dz, ky) / dkz;
+    const RcpRefined byDkz = rcp_refined(dkz);
+    r.Sx = div_by(sel3(r.dx, r.dy, r.dz, kx), byDkz);
+    r.Sy = div_by(sel3(r.dx, r.dy, r.dz, ky), byDkz);
     r.Sz = sel3(r.ivx, r.ivy, r.ivz, kz);
 }
 
@@ -106,8 +144,9 @@ DXV_HD void ray_shear_finished(Ray& r)
 DXV_HD void finish_ray_reference(Ray& r, float lenKnown = -1.0f)
 {
     const float len = lenKnown >= 0.0f ? lenKnown : __builtin_sqrtf((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz);
-    r.dx = r.ox / len; r.dy = r.oy / len; r.dz = r.oz / len;
-    r.ivx = 1.0f / r.dx; r.ivy = 1.0f / r.dy; r.ivz = 1.0f / r.dz;
+    const RcpRefined byLen = rcp_refined(len);
+    r.dx = div_by(r.ox, byLen); r.dy = div_by(r.oy, byLen); r.dz = div_by(r.oz, byLen);
+    r.ivx = div_by(1.0f, rcp_refined(r.dx)); r.ivy = div_by(1.0f, rcp_refined(r.dy)); r.ivz = div_by(1.0f, rcp_refined(r.dz));
     r.nox = -(r.ox * r.ivx); r.noy = -(r.oy * r.ivy); r.noz = -(r.oz * r.ivz);
     r.kz = -1;   // shear constants are set up by the first triangle test (most rays never need them)
 }

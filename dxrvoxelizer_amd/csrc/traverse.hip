@@ -1039,6 +1039,68 @@ hipError_t launch_far_check(const VoxelizeParams& p, unsigned long long* out, hi
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Test hook (dxv_debug_division_check): the ray set-up's scale-free divisions (dxv_math.h: rcp_refined / div_by) against the IEEE
+// quotient `/` the host computes, for EVERY voxel origin of an N^3 grid: origin (grids whose side is no power of two divide by N), the
+// cube-map point (u, v), direction, 1 / direction, the three shear constants -- 14 words per voxel, compared bit for bit.
+// out[0] voxels, out[1] voxels with a differing word (must be 0), out[2 + k]: id of the first 6.  Not a product path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_division_check(uint32_t N, unsigned long long* out)
+{
+    const uint32_t ix = blockIdx.x * 256u + threadIdx.x, iy = blockIdx.y, iz = blockIdx.z;      // (one grid row per (y, z): no 64-bit index arithmetic)
+    if (ix >= N) return;
+    const uint64_t id = ((uint64_t)iz * N + iy) * N + ix;
+    // the product's own code
+    Ray r;
+    ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
+    uint32_t face;
+    float u, v, rho;
+    dm_ray_point(r.ox, r.oy, r.oz, face, u, v, rho);
+    finish_ray_reference(r, rho);
+    ray_shear_finished(r);
+    // the same with IEEE quotients
+    const float fn = (float)N;
+    float ox, oy, oz;
+    if ((N & (N - 1u)) == 0u) { ox = r.ox; oy = r.oy; oz = r.oz; }      // (a power of two multiplies by an exact reciprocal: no division there)
+    else {
+        ox = ((float)ix + 0.5f) / fn * 2.0f - 1.0f;
+        oy = -(((float)iy + 0.5f) / fn * 2.0f - 1.0f);
+        oz = ((float)iz + 0.5f) / fn * 2.0f - 1.0f;
+    }
+    const float ax = __builtin_fabsf(ox), ay = __builtin_fabsf(oy), az = __builtin_fabsf(oz);
+    float wu, wv;
+    if (ax >= ay && ax >= az) { wu = oy / ax; wv = oz / ax; }
+    else if (ay >= az) { wu = oz / ay; wv = ox / ay; }
+    else { wu = ox / az; wv = oy / az; }
+    const float len = __builtin_sqrtf((ox * ox + oy * oy) + oz * oz);
+    const float dx = ox / len, dy = oy / len, dz = oz / len;
+    const float ivx = 1.0f / dx, ivy = 1.0f / dy, ivz = 1.0f / dz;
+    int kz = 0;
+    float m = abs_(dx);
+    if (abs_(dy) > m) { kz = 1; m = abs_(dy); }
+    if (abs_(dz) > m) { kz = 2; }
+    int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+    const float dkz = sel3(dx, dy, dz, kz);
+    if (dkz < 0.0f) { const int t = kx; kx = ky; ky = t; }
+    const float Sx = sel3(dx, dy, dz, kx) / dkz, Sy = sel3(dx, dy, dz, ky) / dkz, Sz = 1.0f / dkz;
+    auto ne = [](float a, float b) { return __builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, b); };
+    const bool bad = ne(ox, r.ox) || ne(oy, r.oy) || ne(oz, r.oz) || ne(wu, u) || ne(wv, v) || ne(dx, r.dx) || ne(dy, r.dy) || ne(dz, r.dz) ||
+                     ne(ivx, r.ivx) || ne(ivy, r.ivy) || ne(ivz, r.ivz) || ne(Sx, r.Sx) || ne(Sy, r.Sy) || ne(Sz, r.Sz) || kz != r.kz;
+    // (the count of voxels: one add per grid SLICE -- an add per wave on one word was 90 % of this kernel's time)
+    if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x == 0u) atomicAdd(out, (unsigned long long)N * N);
+    const unsigned long long mb = __ballot(bad);
+    if (mb && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(mb)) atomicAdd(out + 1, (unsigned long long)__builtin_popcountll(mb));
+    if (bad) {
+        const unsigned long long slot = atomicAdd(out + 8, 1ull);
+        if (slot < 6ull) out[2 + slot] = id;
+    }
+}
+hipError_t launch_division_check(uint32_t N, unsigned long long* out, hipStream_t s)
+{
+    k_division_check<<<dim3((N + 255u) / 256u, N, N), dim3(256), 0, s>>>(N, out);
+    return hipGetLastError();
+}
+
 // The rays whose LDS column was too small in k_voxelize (a few per million: DESIGN.md), one per
 // lane with a column of kRedoStack entries -- enough for any tree the builder makes (height <= 62).
 // Plain binary walk, leaves tested where they are met; same voxel as every other walk.

@@ -269,6 +269,13 @@ class Voxelizer:
         return {"live_voxels": int(out[0]), "live_bricks": int(out[1]), "queued_bricks": int(out[2]), "violations": int(out[3]),
                 "duplicates": int(out[4]), "first": [int(v) for v in out[5:5 + int(min(out[3], 11))]]}
 
+    def division_check(self, n_first, n_last):
+        """dxv_debug_division_check: (voxel origins checked, origins where a set-up word differs from the IEEE quotient's, first ids) over
+        every even grid size in [n_first, n_last]."""
+        out = np.zeros(8, np.uint64)
+        self._check(self._lib.dxv_debug_division_check(self._ctx, int(n_first), int(n_last), out.ctypes.data_as(C.c_void_p)))
+        return int(out[0]), int(out[1]), [int(v) for v in out[2:2 + int(min(out[1], 6))]]
+
     def far_check(self, gridDim, z0=0, nz=None, lists_mip=False):
         """dxv_debug_far_check: dict with bricks, dead_bricks (the brick test of the brick-box launches calls them dead), rays_walked
         (their rays, walked through the LBVH), violations (rays among them that hit something: must be 0) and the first voxel ids."""

@@ -379,6 +379,13 @@ DXV_API int dxv_debug_list_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, u
  * disagreements (must be 0), out[2] = all hits, out[3 + 2k], out[4 + 2k] = voxel id and triangle slot of the first 15. */
 DXV_API int dxv_debug_class_check(dxv_ctx* ctx, uint32_t grid_dim, uint32_t z0, uint32_t nz, uint64_t out[34]);
 
+/* Test hook: the ray set-up divides with a scale-free sequence that shares the denominator's reciprocal (csrc/dxv_math.h: div_by) where the
+ * canonical rules say `/`; for the operands a voxel origin produces the two are the same bits.  Checked here for EVERY voxel origin of
+ * every even grid size n_first, n_first + 2, ... n_last (<= 2048): origin, cube-map point, direction, 1 / direction, shear constants, 14
+ * words per voxel against IEEE quotients computed beside them.  out[0] = voxels checked, out[1] = voxels with a differing word (must be
+ * 0), out[2 + k] = id of the first 6 (of the grid they occurred in).  All grids up to 2048^3: 2.2 x 10^12 voxels, about a minute. */
+DXV_API int dxv_debug_division_check(dxv_ctx* ctx, uint32_t n_first, uint32_t n_last, uint64_t out[8]);
+
 /* Test hook: the brick test of the launches over the brick box (tree walks, plan = 0; option farmap): for every 4^3-voxel brick of slices
  * [z0, z0 + nz) the test the kernel makes, and for every voxel of a brick it calls dead a plain LBVH walk.  lists_mip = 0: against
  * the far-radius map of the triangles' own footprints (what a scene without lists uses; made if need be), 1: against the max-mip of

@@ -1505,3 +1505,22 @@ def test_deferred_list_verdict_and_queued_refit_frames(dxv, orc, bunny):
     assert np.array_equal(v.Grid(), (w.UpdateVertices(pose(4)), w.Voxelize(128), w.Grid())[2])
     assert v.list_check(128)[1] == 0
     v.close(); w.close()
+
+
+def test_ray_setup_divisions_equal_ieee_quotients_for_every_voxel_origin(dxv):
+    """The ray set-up's divisions (origin of grids whose side is no power of two, cube-map point, direction, 1 / direction, shear) run as a
+    scale-free sequence that shares the denominator's refined reciprocal (csrc/dxv_math.h: div_by) -- the canonical rules, the oracle and
+    the host-side checks say `/`.  Equal bit for bit for EVERY voxel origin of EVERY even grid size up to 2048 -- 2.2 x 10^12 origins, 14
+    words each -- exhaustively on the device (20 s; tools/division_check_all.py leaves the same as a record in the evidence run)."""
+    v = dxv.Voxelizer(0)
+    try:
+        total = 0
+        for lo in range(2, 2049, 256):
+            hi = min(lo + 254, 2048)
+            checked, differing, first = v.division_check(lo, hi)
+            assert differing == 0, (lo, hi, differing, first)
+            assert checked == sum(n ** 3 for n in range(lo, hi + 1, 2))
+            total += checked
+        assert total == 8 * (1024 * 1025 // 2) ** 2              # sum of (2k)^3, k = 1 .. 1024
+    finally:
+        v.close()

@@ -33,6 +33,7 @@ python tools/refit_loop.py bunny16 512 30 >> $OUT/refit_loop.jsonl 2>&1
 python tools/init_times.py torus1m 512 3 > $OUT/init_times.jsonl 2>&1
 python tools/init_times.py bunny 256 3 >> $OUT/init_times.jsonl 2>&1
 python tools/obj_ingest_vs_reference.py 5 > $OUT/obj_ingest_vs_reference.jsonl 2> $OUT/obj_ingest_vs_reference.err
+python tools/division_check_all.py > $OUT/division_check_all.jsonl 2>&1
 python tools/ab_option.py farmap 0,1 --meshes torus1m,bunny16,dragon9,bunny --grid 512 --set lists=0 > $OUT/ab_tree_walk_brick_test.jsonl 2>&1
 tools/micro/sort_check time 0 8 10 > $OUT/sort_times.jsonl 2>&1
 python tools/cpu_baseline.py > $OUT/cpu_baseline.jsonl 2>&1
