@@ -184,7 +184,7 @@ DXV_HD void dm_ray_point(float ox, float oy, float oz, uint32_t& face, float& u,
     else { face = oz < 0.0f ? 5u : 4u; a = az; nb = ox; nc = oy; }
     const RcpRefined byA = rcp_refined(a);
     u = div_by(nb, byA); v = div_by(nc, byA);
-    rho = __builtin_sqrtf((ox * ox + oy * oy) + oz * oz);
+    rho = sqrt_in_range((ox * ox + oy * oy) + oz * oz);
 }
 
 // The first step of a ray through the lists -- its texel, its cell inside the texel, and whether it has any candidate at

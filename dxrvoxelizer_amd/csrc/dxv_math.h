@@ -58,6 +58,23 @@ DXV_HD float div_by(float a, const RcpRefined& d)
 #endif
 }
 
+// sqrtf(x), correctly rounded, for x = |o|^2 of a voxel origin (in [2^-21, 4]): the compiler's sequence scales tiny operands up and back
+// and passes 0 / inf through -- sixteen instructions; in range it is v_sqrt_f32 (1 ulp) and the choice between it and its two neighbours
+// by the sign of their residuals, nine instructions, the same bits (dxv_debug_division_check compares this word too).
+DXV_HD float sqrt_in_range(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DXV_IEEE_SETUP_DIVISIONS)
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u), su = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
+    const float ed = __builtin_fmaf(-sd, s, x), eu = __builtin_fmaf(-su, s, x);
+    s = ed <= 0.0f ? sd : s;
+    s = eu > 0.0f ? su : s;
+    return s;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // Ray generation: Content/Shaders/DXRVoxelizer.hlsl:44-53 (generateRay), :64-67 (un-flatten).
 // ------------------------------------------------------------------------------------------
@@ -75,7 +92,7 @@ DXV_HD void ray_origin(uint32_t N, uint32_t ix, uint32_t iy, uint32_t iz, float&
     const float fn = (float)N;
     if ((N & (N - 1u)) == 0u) {
         // power-of-two grid: x / N == x * (1/N) exactly (both are exact scalings), no divisions
-        const float rn = 1.0f / fn;
+        const float rn = div_by(1.0f, rcp_refined(fn));
         ox = ((float)ix + 0.5f) * rn * 2.0f - 1.0f;
         oy = -(((float)iy + 0.5f) * rn * 2.0f - 1.0f);
         oz = ((float)iz + 0.5f) * rn * 2.0f - 1.0f;
@@ -143,7 +160,7 @@ DXV_HD void ray_shear_finished(Ray& r)
 // dm_ray_point: the same expression), else negative
 DXV_HD void finish_ray_reference(Ray& r, float lenKnown = -1.0f)
 {
-    const float len = lenKnown >= 0.0f ? lenKnown : __builtin_sqrtf((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz);
+    const float len = lenKnown >= 0.0f ? lenKnown : sqrt_in_range((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz);
     const RcpRefined byLen = rcp_refined(len);
     r.dx = div_by(r.ox, byLen); r.dy = div_by(r.oy, byLen); r.dz = div_by(r.oz, byLen);
     r.ivx = div_by(1.0f, rcp_refined(r.dx)); r.ivy = div_by(1.0f, rcp_refined(r.dy)); r.ivz = div_by(1.0f, rcp_refined(r.dz));

@@ -1042,7 +1042,7 @@ hipError_t launch_far_check(const VoxelizeParams& p, unsigned long long* out, hi
 // ---------------------------------------------------------------------------------------------
 // Test hook (dxv_debug_division_check): the ray set-up's scale-free divisions (dxv_math.h: rcp_refined / div_by) against the IEEE
 // quotient `/` the host computes, for EVERY voxel origin of an N^3 grid: origin (grids whose side is no power of two divide by N), the
-// cube-map point (u, v), direction, 1 / direction, the three shear constants -- 14 words per voxel, compared bit for bit.
+// cube-map point (u, v) and start radius, direction, 1 / direction, the three shear constants -- 15 words per voxel, compared bit for bit.
 // out[0] voxels, out[1] voxels with a differing word (must be 0), out[2 + k]: id of the first 6.  Not a product path.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_division_check(uint32_t N, unsigned long long* out)
@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_division_check(uint32_t N, unsigned lon
     if (dkz < 0.0f) { const int t = kx; kx = ky; ky = t; }
     const float Sx = sel3(dx, dy, dz, kx) / dkz, Sy = sel3(dx, dy, dz, ky) / dkz, Sz = 1.0f / dkz;
     auto ne = [](float a, float b) { return __builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, b); };
-    const bool bad = ne(ox, r.ox) || ne(oy, r.oy) || ne(oz, r.oz) || ne(wu, u) || ne(wv, v) || ne(dx, r.dx) || ne(dy, r.dy) || ne(dz, r.dz) ||
+    const bool bad = ne(ox, r.ox) || ne(oy, r.oy) || ne(oz, r.oz) || ne(wu, u) || ne(wv, v) || ne(len, rho) || ne(dx, r.dx) || ne(dy, r.dy) || ne(dz, r.dz) ||
                      ne(ivx, r.ivx) || ne(ivy, r.ivy) || ne(ivz, r.ivz) || ne(Sx, r.Sx) || ne(Sy, r.Sy) || ne(Sz, r.Sz) || kz != r.kz;
     // (the count of voxels: one add per grid SLICE -- an add per wave on one word was 90 % of this kernel's time)
     if (blockIdx.x == 0u && blockIdx.y == 0u && threadIdx.x == 0u) atomicAdd(out, (unsigned long long)N * N);
