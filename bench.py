@@ -23,6 +23,7 @@ config.frames_in_flight_2/3 are the figures with the reference's FrameCount = 3 
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -319,10 +320,14 @@ def main():
         vox.SyncAll()
         lib_ev = (frames != 1) if lib_events is None else bool(lib_events)
         vox.set_option("events", 1 if lib_ev else 0)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if per_step else 2)]
+        for e in evs:                            # (torch creates the HIP event at its first record: not inside the region)
+            e.record(stream)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if per_step else 2)]
+        gc_was_on = gc.isenabled()
+        gc.disable()                             # (a collector pause between the opening event and the first launch would be charged to the steps)
         t0 = time.perf_counter()
         evs[0].record(stream)
         for k in range(steps):
@@ -333,6 +338,8 @@ def main():
             evs[1].record(stream)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0            # this rank's K steps; the closing barrier (tens of us of RCCL) is not part of any
+        if gc_was_on:
+            gc.enable()
         if use_dist:                             # rank's work: the maximum over ranks is taken by reduce_max below
             dist.barrier()
         vox.SyncAll()                            # deferred kernel status (stack overflow) is an error
