@@ -17,7 +17,10 @@ tag = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(os.environ.get("DXV
 v = dxv.Voxelizer(0)
 opts = sys.argv[4] if len(sys.argv) > 4 else ""
 for kv in filter(None, opts.split(",")):
-    v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    if kv.split("=")[0] == "texels":                                  # (the reference's texel image beside the grid: dxv_enable_texels)
+        v.EnableTexels(bool(int(kv.split("=")[1])))
+    else:
+        v.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 vb, ib, _ = make_mesh(mesh)
 v.InitFromArrays(vb, ib, gridDim=N)
 v.PrepareLaunchInterleaved(N, 3, 8, 4)
