@@ -784,7 +784,9 @@ static __device__ unsigned long long g_dxvPhase[kPhaseSlots * 16u];
 // round with their results unused: what one of the scan's load instructions costs
 // (split at the ray's first step: the work-queue kernel makes that step for all 64 lanes of a brick at once and collects the brick
 // it asked for in advance behind it -- k_voxelize_queue, traverse.hip)
-template <class Stack, int ABL = 0>
+// HITLDS: the closest hit's V, W, det and index live in column words cap .. cap + 3 (leaf_reference_deferred_lds); best.t and best.leaf are
+// all of `best` that is meaningful then (best.leaf == -1: miss), bestDet is untouched.
+template <class Stack, int ABL = 0, bool HITLDS = false>
 DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRayStart& start, const TriPos* tris, const Stack& stk, int cap, Hit& best,
                                     float& bestDet)
 {
@@ -934,7 +936,8 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
                 while (k < qn && (((uint32_t)stk.get(2 * k + 1) - rc) & 0x00008000u) == 0u) ++k;      // r0 beyond the closest hit so far
                 if (!wave_any(k < qn)) break;
                 if (k < qn) {
-                    leaf_reference_deferred(r, tris, stk.get(2 * k), best, bestDet);
+                    if (HITLDS) leaf_reference_deferred_lds(r, tris, stk.get(2 * k), best.t, best.leaf, stk, cap);
+                    else leaf_reference_deferred(r, tris, stk.get(2 * k), best, bestDet);
                     bound = (rho + best.t) * 1.001f + 1e-4f;
                     rc = dm_radial_word(near, bound);
                     ++k;

@@ -112,6 +112,30 @@ DXV_HD void leaf_reference_deferred(Ray& r, const TriPos* tris, int32_t leaf, Hi
     const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
     if (t < best.t || (t == best.t && k < best.k)) { best.t = t; best.b1 = V; best.b2 = W; bestDet = det; best.k = k; best.leaf = tagged; }
 }
+// ... and with the closest hit's rarely read words -- the undivided V, W, their divisor det and the triangle's index (read only on an exact
+// tie of t) -- in the thread's LDS column (words hitAt .. hitAt + 3) instead of four vector registers held through the scan and the
+// triangle rounds: written when a hit is accepted, read once behind the walk (shade_reference_lds).  bestLeaf == -1: no hit yet.
+// Same tests, same comparisons, same winner as leaf_reference_deferred.
+template <class Stack>
+DXV_HD void leaf_reference_deferred_lds(Ray& r, const TriPos* tris, int32_t leaf, float& bestT, int32_t& bestLeaf, const Stack& stk, int hitAt)
+{
+    const TriPos tp = load_tri(tris, leaf);
+    const int32_t tagged = leaf | (int32_t)__builtin_bit_cast(uint32_t, tp.v1.w);
+    float lo[3], hi[3], tn;
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+    if (!(slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= bestT)) return;
+    float t, V, W, det;                                                 // (the caller has sheared the ray: ray_shear)
+    if (!tri_test<false, true>(r, tp.v0, tp.v1, tp.v2, t, V, W, &det)) return;
+    if (tn > t) return;
+    const uint32_t k = __builtin_bit_cast(uint32_t, tp.v0.w);
+    bool take = t < bestT;
+    if (!take && t == bestT) take = k < (uint32_t)stk.get(hitAt + 3);   // (t < kTMax strictly: an equal bestT is a hit's, its index is in the column)
+    if (take) {
+        bestT = t; bestLeaf = tagged;
+        stk.put(hitAt, __builtin_bit_cast(int32_t, V)); stk.put(hitAt + 1, __builtin_bit_cast(int32_t, W));
+        stk.put(hitAt + 2, __builtin_bit_cast(int32_t, det)); stk.put(hitAt + 3, (int32_t)k);
+    }
+}
 DXV_HD void finish_hit(Hit& best, float bestDet)
 {
     if (best.k != 0xffffffffu) { best.b1 = best.b1 / bestDet; best.b2 = best.b2 / bestDet; }
@@ -623,6 +647,24 @@ DXV_HD uint8_t shade_reference(const SceneView& sc, Ray& r, Hit& best, float bes
     const TriNrm tn = sc.triNrm[best.leaf];
     float nx, ny, nz;
     const bool in = predicate(r, tn.n0, tn.n1, tn.n2, best.b1, best.b2, nx, ny, nz);
+    if (in && texel) *texel = pack_texel(nx, ny, nz);
+    return in ? 1 : 0;
+}
+
+// shade_reference<4> for a hit whose barycentrics wait in the LDS column (leaf_reference_deferred_lds): the same decisions, the same divisions
+template <class Stack>
+DXV_HD uint8_t shade_reference_lds(const SceneView& sc, Ray& r, int32_t bestLeaf, const Stack& stk, int hitAt, uint32_t* texel)
+{
+    if (bestLeaf == -1) return 0;                                                // missMain
+    const uint32_t cls = (uint32_t)bestLeaf >> kClassShift;
+    const int32_t leaf = bestLeaf & (int32_t)((1u << kClassShift) - 1u);
+    if (cls != 0u && (!texel || cls != kClassIn)) return cls == kClassIn ? 1 : 0;
+    const float det = __builtin_bit_cast(float, stk.get(hitAt + 2));
+    const float b1 = __builtin_bit_cast(float, stk.get(hitAt)) / det, b2 = __builtin_bit_cast(float, stk.get(hitAt + 1)) / det;     // finish_hit
+    finish_ray_reference(r);                                            // the direction again (not kept through the scan)
+    const TriNrm tn = sc.triNrm[leaf];
+    float nx, ny, nz;
+    const bool in = predicate(r, tn.n0, tn.n1, tn.n2, b1, b2, nx, ny, nz);
     if (in && texel) *texel = pack_texel(nx, ny, nz);
     return in ? 1 : 0;
 }

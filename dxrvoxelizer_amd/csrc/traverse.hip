@@ -679,7 +679,17 @@ template <bool TEXELS>
 __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, QueueLens lens, ClearShare clr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ int32_t stack[16 * 64];
+    __shared__ int32_t stack[(TEXELS ? 20 : 16) * 64];     // per lane: 8 queued triangles of two words (TEXELS: then the closest hit's V, W, det, index)
+    // The kernel's arguments, ALL asked for here: left to itself the compiler loads each word where it is first used, and the start of a
+    // brick is then a chain of scalar-memory round trips each waited for before the next is asked for (the clear's share -> the sixteen
+    // queue lengths -> the queue's address -> [the brick's word] -> the scene's words in two more batches).  Named here they are one batch of
+    // loads behind one wait; only the brick's word itself is a second trip (-0.5 % on the full grid, -0.7 % on a rank's share).
+    asm volatile("" :: "s"(lens.len[0]), "s"(lens.len[1]), "s"(lens.len[2]), "s"(lens.len[3]), "s"(lens.len[4]), "s"(lens.len[5]), "s"(lens.len[6]), "s"(lens.len[7]),
+                 "s"(lens.heavy[0]), "s"(lens.heavy[1]), "s"(lens.heavy[2]), "s"(lens.heavy[3]), "s"(lens.heavy[4]), "s"(lens.heavy[5]), "s"(lens.heavy[6]),
+                 "s"(lens.heavy[7]), "s"(clr.blocks), "s"(clr.where), "s"(clr.live), "s"(gridDim.x), "s"(p.queueSlots), "s"(p.queueCap));
+    asm volatile("" :: "s"(p.N), "s"(p.z0), "s"(p.nz), "s"(p.zBlock), "s"(p.zPeriod), "s"(p.zShift), "s"(p.scene.dmCells), "s"(p.scene.dmEntries), "s"(p.scene.dmR),
+                 "s"(p.scene.dmCoop), "s"(p.scene.triPos), "s"(p.grid), "s"(p.scene.rootLo[0]), "s"(p.scene.rootLo[1]), "s"(p.scene.rootLo[2]),
+                 "s"(p.scene.rootHi[0]), "s"(p.scene.rootHi[1]), "s"(p.scene.rootHi[2]));
     uint32_t wg = blockIdx.x;
     if (clr.blocks) {
         // (clr.blocks is a multiple of 8: a brick workgroup's number keeps its residue mod 8 -- its XCD, its queue)
@@ -720,8 +730,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
     const uint32_t bx = w & 1023u, by = (w >> 10) & 1023u, bz = w >> 20;
     const uint32_t tid = threadIdx.x;
     uint32_t ix = bx * 4u + (tid & 3u), iy = by * 4u + ((tid >> 2) & 3u), lz = bz * 4u + (tid >> 4);
-    const bool inside = ix < N && iy < N && lz < nz;
-    ix = ix < N ? ix : N - 1u; iy = iy < N ? iy : N - 1u; lz = lz < nz ? lz : nz - 1u;
+    ix = ix < N ? ix : N - 1u; iy = iy < N ? iy : N - 1u; lz = lz < nz ? lz : nz - 1u;     // (lanes that hang over the grid's end trace a voxel of the grid and store nothing)
     const uint32_t iz = p.zBlock == nz ? p.z0 + lz : p.z0 + (lz >> p.zShift) * p.zPeriod + (lz & (p.zBlock - 1u));
     Ray r;
     ray_origin(N, ix, iy, iz, r.ox, r.oy, r.oz);
@@ -734,24 +743,31 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
 #if defined(DXV_PHASE_TIMES)
     { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0u) { unsigned long long* slot_ = g_dxvPhase + (size_t)(blockIdx.x & (kPhaseSlots - 1u)) * 16u; atomicAdd(slot_, now_ - tPhase0_); atomicAdd(slot_ + 6, 1ull); } }
 #endif
-    trace_reference_dm_from<StridedStack, 0>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
+    // (with the texel image on, the closest hit's V, W, det and index wait in the LDS column: four registers that cost that variant its
+    // seventh wave per SIMD; without it the allocator does better with them in registers: 68 against 74)
+    trace_reference_dm_from<StridedStack, 0, TEXELS>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
 #if defined(DXV_PHASE_TIMES)
     const unsigned long long tPhase5_ = __builtin_amdgcn_s_memrealtime();
 #endif
     uint32_t texel = 0;
-    const uint8_t occ = shade_reference<4, 0>(sc, r, best, bestDet, TEXELS ? &texel : nullptr);
+    const uint8_t occ = TEXELS ? shade_reference_lds(sc, r, best.leaf, stk, 16, &texel) : shade_reference<4, 0>(sc, r, best, bestDet, nullptr);
+    // the lane's voxel once more (nothing of it is kept through the body: with the texel image on, the lane's coordinates held across the
+    // scan cost the kernel its seventh wave per SIMD -- k_voxelize_queue does the same)
+    uint32_t lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     if (TEXELS || (N & 3u) != 0u) {
-        if (inside) {
-            const size_t id = ((size_t)lz * N + iy) * N + ix;
+        const uint32_t vx = bx * 4u + (lane & 3u), vy = by * 4u + ((lane >> 2) & 3u), vz = bz * 4u + (lane >> 4);
+        if (vx < N && vy < N && vz < nz) {
+            const size_t id = ((size_t)vz * N + vy) * N + vx;
             if (TEXELS) p.texels[id] = texel;
             if ((N & 3u) != 0u) p.grid[id] = occ;
         }
     }
     if ((N & 3u) == 0u) {
         const uint64_t m = __builtin_amdgcn_ballot_w64(occ != 0);
-        const uint32_t ry = by * 4u + (tid & 3u), rz = bz * 4u + ((tid >> 2) & 3u);
-        if (tid < 16u && rz < nz) {
-            const uint32_t nib = (uint32_t)(m >> (4u * tid)) & 15u;
+        const uint32_t ry = by * 4u + (lane & 3u), rz = bz * 4u + ((lane >> 2) & 3u);
+        if (lane < 16u && rz < nz) {
+            const uint32_t nib = (uint32_t)(m >> (4u * lane)) & 15u;
             *reinterpret_cast<uint32_t*>(p.grid + ((size_t)rz * N + ry) * N + bx * 4u) = (nib * 0x00204081u) & 0x01010101u;
         }
     }
