@@ -722,6 +722,9 @@ int dxv_set_option(dxv_ctx* c, const char* key, int64_t value)
     } else if (!strcmp(key, "prepared")) {
         if (value != 0 && value != 1) return fail(c, "option prepared: %lld not in {0,1}", (long long)value);
         c->optPrepared = (int)value;
+    } else if (!strcmp(key, "listedwaves")) {
+        if (value != 0 && (value < 8 || value > 32)) return fail(c, "option listedwaves: %lld not in {0,8..32}", (long long)value);
+        c->optListedWaves = (int)value;
     } else if (!strcmp(key, "coop")) {
         if (value != 0 && value != 1) return fail(c, "option coop: %lld not in {0,1}", (long long)value);
         c->optCoop = (int)value;

@@ -172,6 +172,7 @@ struct dxv_ctx {
     uint16_t* dFarMip = nullptr;
     uint32_t farR = 0, farCap = 0;   // the map it is on / was allocated for
     float farMs = 0.0f;
+    int optListedWaves = 0;          // workgroups per CU of the hardware-dispatched lists kernel (8 .. 32), or 0 = by grid and map (traverse.hip: listed_lds_pad)
     int optCoop = 1;                 // 1: the lists kernel scans a lone lane's long list with its whole wave (dxv_dirmap.h: trace_reference_dm_from)
     int optFarMap = 1;               // 1: tree walks and brick-box launches of the reference rule skip the bricks none of whose rays can reach a triangle
     int optPlan = 2;                 // work queue of the lists kernel (live bricks only, built on the device inside the stream): 0 = none (brick box

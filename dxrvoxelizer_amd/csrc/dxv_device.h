@@ -111,6 +111,8 @@ struct VoxelizeParams {
     const uint16_t* mip;    // max-mip of the lists' far radii (dxv_dirmap.h), what k_plan_bricks probes the bricks against
     uint32_t mipR;          // brick-box launches (k_voxelize, 4^3 bricks, reference rule): the map `mip` was made on -- every workgroup makes
                             // the queue's brick test itself and a brick that cannot hold a live ray is zeroed and left; 0: no test
+    uint32_t listedWaves;   // k_voxelize_listed without the texel image fits eight waves per SIMD (64 VGPRs, 32 workgroups per CU): 8 .. 32 = held at so many
+                            // workgroups per CU by LDS it does not use; 0: by grid and map (listed_lds_pad, traverse.hip; option listedwaves)
     uint32_t* liveMask;     // k_plan_bricks: one bit per brick of the partition, id (bz nbx + by) nbx + bx, set for every queued brick (or NULL):
                             // what the clear of a launch through a PREPARED queue reads (only the bricks nobody runs are zeroed)
 };

@@ -786,7 +786,8 @@ static __device__ unsigned long long g_dxvPhase[kPhaseSlots * 16u];
 // it asked for in advance behind it -- k_voxelize_queue, traverse.hip)
 // HITLDS: the closest hit's V, W, det and index live in column words cap .. cap + 3 (leaf_reference_deferred_lds); best.t and best.leaf are
 // all of `best` that is meaningful then (best.leaf == -1: miss), bestDet is untouched.
-template <class Stack, int ABL = 0, bool HITLDS = false>
+// HITLDS 2: nothing but best.t and best.leaf is kept at all (leaf_reference_min, shade_reference_again).
+template <class Stack, int ABL = 0, int HITLDS = 0>
 DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRayStart& start, const TriPos* tris, const Stack& stk, int cap, Hit& best,
                                     float& bestDet)
 {
@@ -936,7 +937,8 @@ DXV_HD void trace_reference_dm_from(Ray& r, const DirMapView& dm, const DirRaySt
                 while (k < qn && (((uint32_t)stk.get(2 * k + 1) - rc) & 0x00008000u) == 0u) ++k;      // r0 beyond the closest hit so far
                 if (!wave_any(k < qn)) break;
                 if (k < qn) {
-                    if (HITLDS) leaf_reference_deferred_lds(r, tris, stk.get(2 * k), best.t, best.leaf, stk, cap);
+                    if (HITLDS == 2) leaf_reference_min(r, tris, stk.get(2 * k), best.t, best.leaf);
+                    else if (HITLDS == 1) leaf_reference_deferred_lds(r, tris, stk.get(2 * k), best.t, best.leaf, stk, cap);
                     else leaf_reference_deferred(r, tris, stk.get(2 * k), best, bestDet);
                     bound = (rho + best.t) * 1.001f + 1e-4f;
                     rc = dm_radial_word(near, bound);

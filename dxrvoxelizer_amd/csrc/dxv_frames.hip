@@ -248,7 +248,7 @@ int launch_now(dxv_ctx* c, uint32_t frame, bool relaunch)
             f.usedLists = true; f.listEpochUsed = c->listEpoch;
             p.lists = 1u;
             p.ablate = (uint32_t)c->optAblate;
-            p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes; p.scene.dmCoop = (uint32_t)c->optCoop;
+            p.scene.dmCells = c->dListCells; p.scene.dmEntries = c->dListEntries; p.scene.dmR = c->listRes; p.scene.dmCoop = (uint32_t)c->optCoop; p.listedWaves = (uint32_t)c->optListedWaves;
             st = 16;                                                // no stack: the column is the queue of selected triangles (8 items of two words)
             if (c->optRegion == 6) p.regionBits = 9u;                  // larger XCD regions suit the lists (-4 %); an explicit option wins
             f.list_entries = c->listEntries; f.list_res = c->listRes;

@@ -136,6 +136,24 @@ DXV_HD void leaf_reference_deferred_lds(Ray& r, const TriPos* tris, int32_t leaf
         stk.put(hitAt + 2, __builtin_bit_cast(int32_t, det)); stk.put(hitAt + 3, (int32_t)k);
     }
 }
+// ... and with NOTHING of the closest hit kept but its t and its tagged slot: the triangle's index, needed on an exact tie of t only, is read
+// from the hit triangle's record then, and V, W, det -- needed for the few hits whose triangle has no class (shade_reference_again) -- are
+// computed again behind the walk from the same ray and the same record: the same bits.  Four registers less through scan and rounds.
+DXV_HD void leaf_reference_min(Ray& r, const TriPos* tris, int32_t leaf, float& bestT, int32_t& bestLeaf)
+{
+    const TriPos tp = load_tri(tris, leaf);
+    const int32_t tagged = leaf | (int32_t)__builtin_bit_cast(uint32_t, tp.v1.w);
+    float lo[3], hi[3], tn;
+    tri_box(tp.v0, tp.v1, tp.v2, lo, hi);
+    if (!(slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn) && tn <= bestT)) return;
+    float t, V, W, det;                                                 // (the caller has sheared the ray: ray_shear)
+    if (!tri_test<false, true>(r, tp.v0, tp.v1, tp.v2, t, V, W, &det)) return;
+    if (tn > t) return;
+    bool take = t < bestT;
+    if (!take && t == bestT)                                            // (t < kTMax strictly: an equal bestT is a hit's)
+        take = __builtin_bit_cast(uint32_t, tp.v0.w) < __builtin_bit_cast(uint32_t, tris[bestLeaf & (int32_t)((1u << kClassShift) - 1u)].v0.w);
+    if (take) { bestT = t; bestLeaf = tagged; }
+}
 DXV_HD void finish_hit(Hit& best, float bestDet)
 {
     if (best.k != 0xffffffffu) { best.b1 = best.b1 / bestDet; best.b2 = best.b2 / bestDet; }
@@ -667,6 +685,24 @@ DXV_HD uint8_t shade_reference_lds(const SceneView& sc, Ray& r, int32_t bestLeaf
     const bool in = predicate(r, tn.n0, tn.n1, tn.n2, b1, b2, nx, ny, nz);
     if (in && texel) *texel = pack_texel(nx, ny, nz);
     return in ? 1 : 0;
+}
+
+// shade_reference<4> for a hit of which only the tagged slot was kept (leaf_reference_min): the hit triangle is tested once more for its
+// barycentrics where they are needed
+DXV_HD uint8_t shade_reference_again(const SceneView& sc, Ray& r, int32_t bestLeaf)
+{
+    if (bestLeaf == -1) return 0;                                                // missMain
+    const uint32_t cls = (uint32_t)bestLeaf >> kClassShift;
+    if (cls != 0u) return cls == kClassIn ? 1 : 0;
+    const int32_t leaf = bestLeaf & (int32_t)((1u << kClassShift) - 1u);
+    finish_ray_reference(r);                                            // the direction again (not kept through the scan)
+    ray_shear_finished(r);
+    const TriPos tp = load_tri(sc.triPos, leaf);
+    float t, V, W, det = 1.0f;
+    (void)tri_test<false, true>(r, tp.v0, tp.v1, tp.v2, t, V, W, &det);         // (it hit before: the same operands)
+    const TriNrm tn = sc.triNrm[leaf];
+    float nx, ny, nz;
+    return predicate(r, tn.n0, tn.n1, tn.n2, V / det, W / det, nx, ny, nz) ? 1 : 0;
 }
 
 // returns occupancy; *texel (optional) = the R10G10B10A2_UNORM value of hlsl:84 or 0; *overflow set

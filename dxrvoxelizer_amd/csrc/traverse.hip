@@ -745,12 +745,12 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_listed(VoxelizeParams p, Que
 #endif
     // (with the texel image on, the closest hit's V, W, det and index wait in the LDS column: four registers that cost that variant its
     // seventh wave per SIMD; without it the allocator does better with them in registers: 68 against 74)
-    trace_reference_dm_from<StridedStack, 0, TEXELS>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
+    trace_reference_dm_from<StridedStack, 0, TEXELS ? 1 : 2>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
 #if defined(DXV_PHASE_TIMES)
     const unsigned long long tPhase5_ = __builtin_amdgcn_s_memrealtime();
 #endif
     uint32_t texel = 0;
-    const uint8_t occ = TEXELS ? shade_reference_lds(sc, r, best.leaf, stk, 16, &texel) : shade_reference<4, 0>(sc, r, best, bestDet, nullptr);
+    const uint8_t occ = TEXELS ? shade_reference_lds(sc, r, best.leaf, stk, 16, &texel) : shade_reference_again(sc, r, best.leaf);
     // the lane's voxel once more (nothing of it is kept through the body: with the texel image on, the lane's coordinates held across the
     // scan cost the kernel its seventh wave per SIMD -- k_voxelize_queue does the same)
     uint32_t lane;
@@ -803,6 +803,33 @@ static uint32_t queue_waves(bool texels)
     return c;
 }
 
+// Dynamic LDS a launch of k_voxelize_listed<false> asks for WITHOUT using it.  The kernel fits eight waves per SIMD (64 VGPRs, 4 KB of LDS per
+// single-wave workgroup: 32 workgroups per CU); how many it should run depends on how a brick's rays fall on the lists' map.  Where they
+// look into neighbouring texels (grid side >= 3/4 of the map's) the eighth wave is throughput: -9 % at 512^3, -12 % at 1024^3 against seven.
+// Where a brick is spread over many texels (256^3 on the 512 map) it is more lines in flight per load and slower bricks: +7 %.  Such a
+// launch is held at 28 workgroups per CU by LDS: the smallest pad that leaves so many, found once per value through the occupancy query
+// (26 .. 30 measure the same: the hardware fills SIMDs evenly; profiles/r06/ab_listed_workgroups_per_cu.jsonl).  Option listedwaves overrides.
+static uint32_t listed_lds_pad(const VoxelizeParams& p)
+{
+    if (p.texels) return 0u;                                           // (that variant holds 72 VGPRs: seven waves by itself)
+    const uint32_t want = p.listedWaves ? p.listedWaves : (4u * p.N >= 3u * p.scene.dmR ? 32u : 28u);
+    if (want >= 32u) return 0u;
+    static int cached[33] = {0};                                        // 0: not asked yet; -1: no pad
+    int& c = cached[want < 8u ? 8u : want];
+    if (c == 0) {
+        c = -1;
+        int perCu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_voxelize_listed<false>, 64, 0) == hipSuccess && perCu > (int)want) {
+            for (int pad = 64; pad <= 16384; pad += 64) {
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_voxelize_listed<false>, 64, (size_t)pad) != hipSuccess) break;
+                if (perCu <= (int)want) { c = pad; break; }
+            }
+        }
+        (void)hipGetLastError();
+    }
+    return c > 0 ? (uint32_t)c : 0u;
+}
+
 // rebuild: clear the grid and build the queue in front of the launch (a launch that may not rely on anything an earlier
 // launch left behind); else the caller vouches that the frame's grid and queue are those of the same launch made before
 // (same lists, partition and buffers: the kernel writes the same bricks every time) and only the queue heads are reset.
@@ -821,7 +848,7 @@ hipError_t launch_voxelize_queue(const VoxelizeParams& pin, bool rebuild, uint32
         // the queue as it stands, one workgroup per item of an XCD's equal share (listedLen = ceil(total / 8)) and per XCD
         if (wavesOut) *wavesOut = 8u * listedLen;
         if (p.texels) k_voxelize_listed<true><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens, ClearShare{nullptr, 0u, 0u});
-        else k_voxelize_listed<false><<<dim3(8u * listedLen), dim3(64), 0, s>>>(p, lens, ClearShare{nullptr, 0u, 0u});
+        else k_voxelize_listed<false><<<dim3(8u * listedLen), dim3(64), listed_lds_pad(p), s>>>(p, lens, ClearShare{nullptr, 0u, 0u});
         return hipGetLastError();
     }
     if (rebuild) {
@@ -885,7 +912,7 @@ hipError_t launch_voxelize_prepared(const VoxelizeParams& p, const uint32_t lens
     }
     const uint32_t wgs = 8u * listedLen + clr.blocks;
     if (p.texels) k_voxelize_listed<true><<<dim3(wgs), dim3(64), 0, s>>>(p, lens, clr);
-    else k_voxelize_listed<false><<<dim3(wgs), dim3(64), 0, s>>>(p, lens, clr);
+    else k_voxelize_listed<false><<<dim3(wgs), dim3(64), listed_lds_pad(p), s>>>(p, lens, clr);
     return hipGetLastError();
 }
 

@@ -338,6 +338,10 @@ DXV_API int dxv_get_stats(const dxv_ctx* ctx, dxv_stats* out);
  *   coop   0|1    the lists kernel: when at most two lanes of a wave are still scanning and the first has 24 entries or more ahead, the whole
  *                 wave scans that ray's list, one entry per lane and round (1, default) -- a brick is as long as its longest list, and a
  *                 short launch (a rank's share) cannot end before its longest brick; 0: every lane scans alone
+ *   listedwaves 0|8..32  the hardware-dispatched lists kernel (prepared and kept queues, no texel image) fits eight waves per SIMD: 32
+ *                 single-wave workgroups per CU.  0 (default): all 32 when the grid side is at least 3/4 of the lists' map side (a brick's rays
+ *                 fall on neighbouring texels: 512^3 -9 %, 1024^3 -12 % against seven waves), else 28 (256^3 on the 512 map: a brick is spread
+ *                 over many texels and the eighth wave costs 7 %); 8 .. 32: held at so many workgroups per CU by LDS the launch does not use
  *   farmap 0|1    launches over the brick box (tree walks -- lists = 0, dynamic first launches, scenes over the lists' caps -- and plan = 0):
  *                 every workgroup makes the queue's brick test itself and a brick none of whose rays can reach a triangle is zeroed and
  *                 left (1, default); the test reads the lists' max-mip or, for a scene without lists, a far-radius map of the triangles'

@@ -313,3 +313,44 @@ def test_prepare_launch_refuses_what_voxelize_refuses_and_warmup_is_explicit(dxv
         assert v.stats()["warmup_ms"] >= 0.0
     finally:
         v.close()
+
+
+def test_prepared_kernel_breaks_exact_ties_like_the_oracle_and_at_every_occupancy(dxv):
+    """The hardware-dispatched kernel keeps nothing of the closest hit but t and the triangle's slot: on an exact tie of t the incumbent's
+    index is read from its record, and the barycentrics of an unclassified hit are computed again behind the walk.  A sphere whose every
+    triangle is there TWICE -- the copies with negated normals, so the winner of each tie decides the voxel -- in both orders, against the
+    oracle; and the same grid at every value of option listedwaves (workgroups per CU held by unused LDS)."""
+    from dxrvoxelizer_amd import meshes
+    from oracle import orc
+    vb, ib = meshes.uv_sphere(48, 24, 0.7, (0.05, -0.03, 0.02))
+    V = len(vb)
+    flipped = vb.copy()
+    flipped[:, 3:6] *= -1.0
+    vb2 = np.concatenate([vb, flipped]).astype(np.float32)
+    N = 64
+    for first in (0, 1):
+        ib2 = np.concatenate([ib + (V if first else 0), ib + (0 if first else V)]).astype(np.uint32)
+        want = orc.Scene(vb2, ib2).voxelize(N)
+        assert (0 < int(want.sum()) < N ** 3) if first == 0 else int(want.sum()) == 0     # (the outward-normal copies first: a solid ball; the negated ones first: nothing)
+        v = dxv.Voxelizer(0)
+        try:
+            v.set_option("lists", 2)
+            v.InitFromArrays(vb2, ib2, gridDim=N)
+            v.Voxelize(N)                                      # (the frame's grid exists from the first launch on)
+            for waves in (0, 32, 28, 20, 8):
+                v.set_option("listedwaves", waves)
+                poison(v)
+                v.Voxelize(N)
+                st = v.stats()
+                assert st["plan_prepared"] == 1 and st["list_entries"] > 0
+                assert np.array_equal(v.Grid(), want), (first, waves)
+            with pytest.raises(Exception):
+                v.set_option("listedwaves", 7)
+            with pytest.raises(Exception):
+                v.set_option("listedwaves", 33)
+        finally:
+            v.close()
+    # the opposite-normal copy first or second must matter (else the tie never decided anything)
+    a = orc.Scene(vb2, np.concatenate([ib, ib + V]).astype(np.uint32)).voxelize(N)
+    b = orc.Scene(vb2, np.concatenate([ib + V, ib]).astype(np.uint32)).voxelize(N)
+    assert not np.array_equal(a, b)

@@ -31,8 +31,14 @@ def test_default_kernels_do_not_spill_and_keep_full_occupancy(dxvlib):
     # seven waves only because its loop holds nothing in vector registers through the body and reads the launch's parameters
     # anew for every brick -- written the obvious way it took 80 registers, 8 bytes of scratch and six waves)
     assert len(lists_box) == 1 and len(lists_queue) == 1 and len(lists_listed) == 1
-    for r in lists_box + lists_queue + lists_listed:
+    for r in lists_box + lists_queue:
         assert r["scratch"] == 0 and r["vgprs"] <= 72 and r["occupancy"] >= 7 and r["lds"] == 16 * 64 * 4
+    # (round 6: the hardware-dispatched form keeps nothing of the closest hit but t and the tagged slot -- 64 registers, EIGHT waves; with the
+    # texel image the hit's V, W, det, index wait in four more words of the LDS column -- 72 registers, seven waves; both without scratch)
+    assert lists_listed[0]["scratch"] == 0 and lists_listed[0]["vgprs"] <= 64 and lists_listed[0]["occupancy"] == 8 and lists_listed[0]["lds"] == 16 * 64 * 4
+    listed_texels = [v for k, v in res.items() if "k_voxelize_listedILb1EEE" in k]
+    assert len(listed_texels) == 1
+    assert listed_texels[0]["scratch"] == 0 and listed_texels[0]["vgprs"] <= 72 and listed_texels[0]["occupancy"] >= 7 and listed_texels[0]["lds"] == 20 * 64 * 4
     assert len(default_ref) == 1 and len(binary_ref) == 1 and len(default_par) == 1 and len(block_par) == 1
     assert block_par[0]["scratch"] == 0 and block_par[0]["occupancy"] >= 6
     for r in (default_ref[0], binary_ref[0]):
