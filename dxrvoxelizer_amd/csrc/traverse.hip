@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
             Hit best;
             float bestDet = 1.0f;
             const StridedStack stk{stack + tid, 64};
-            trace_reference_dm_from<StridedStack, 0>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
+            trace_reference_dm_from<StridedStack, 0, TEXELS ? 0 : 2>(r, dm, start, sc.triPos, stk, 16, best, bestDet);
             // The add for the brick AFTER the next one, here: vector memory answers in order, so an add asked for right in front of a
             // brick's first load makes that load wait for the add's 1.1 - 1.3 us instead of its own 0.8 -- asked for behind the scan,
             // it has the predicate, the stores and the next brick's ray set-up (nine divisions) to come back in.
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64, 6) void k_voxelize_queue(VoxelizeParams p)
                 }
             }
             uint32_t texel = 0;
-            const uint8_t occ = shade_reference<4, 0>(sc, r, best, bestDet, TEXELS ? &texel : nullptr);
+            const uint8_t occ = TEXELS ? shade_reference<4, 0>(sc, r, best, bestDet, &texel) : shade_reference_again(sc, r, best.leaf);
             // the lane's voxel once more (nothing of it was kept through the body)
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
             uint8_t* grid = pp->grid;
