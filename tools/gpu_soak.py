@@ -77,7 +77,7 @@ def main():
                     "dispatch": int(rng.choice([1, 1, 0, 2])), "planregion": int(rng.choice([0, 0, 6, 7, 8])),
                     "planheavy": int(rng.choice([0, 0, 0, 3, 65535])), "fuse": int(rng.choice([1, 1, 0])), "queueheads": int(rng.choice([8, 8, 8, 1, 2, 4])),
                     "prepared": int(rng.choice([1, 1, 1, 0])), "prepclear": int(rng.integers(0, 4)), "coop": int(rng.choice([1, 1, 0])),
-                    "farmap": int(rng.choice([1, 1, 0]))}
+                    "farmap": int(rng.choice([1, 1, 0])), "listedwaves": int(rng.choice([0, 0, 32, 28, 16, 8]))}
             for k, val in opts.items():
                 v.set_option(k, val)
             part = int(rng.integers(0, 3))
