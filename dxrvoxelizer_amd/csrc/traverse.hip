@@ -121,7 +121,7 @@ __global__ __launch_bounds__(B::threads, WALK == 4 ? 6 : 8) void k_voxelize(Voxe
 //    wave that finds nothing, a false negative cannot happen -- k_plan_check below is the exhaustive proof obligation);
 //  * layout: regions of 256 consecutive bricks of the Morton order (8 x 8 x 4 bricks) are dealt round-robin to eight
 //    queues, one per XCD (blocks b and b + 8 share one), so that an XCD's private L2 sees compact regions; a region's
-//    workgroup appends its live bricks to its queue with one atomic add (small partitions: runs of 64 bricks, one add per
+//    workgroup appends its live bricks to its queue with one atomic add (small partitions: runs of 128 bricks, one add per
 //    wave -- k_plan_bricks).  Queue memory (dxv_device.h): two headers -- eight heads per queue and the eight lengths, every
 //    word in a 256-byte line of its own; a build takes the one the last build left cleared -- and 8 x cap brick words
 //    (bx | by << 10 | bz << 20);
@@ -237,12 +237,14 @@ uint32_t plan_layout(VoxelizeParams& p)
 }
 // Run length by partition size.  Large partitions: 256 bricks (an XCD's L2 sees compact pieces of the grid, and with thousands of
 // runs per queue the eight queues end within 2 % of each other).  Small ones -- a 256^3 grid, a rank's share of 512^3 at 4 ranks
-// or more: 2^19 bricks or fewer -- take runs of 64: a queue of a few hundred runs of very different cost ends 10 - 20 % away
-// from its neighbours, and the launch ends with the longest.
+// or more: 2^19 bricks or fewer -- take shorter runs: a queue of a few hundred runs of very different cost ends 10 - 20 % away
+// from its neighbours, and the launch ends with the longest.  (Runs of 64 until round 6; since every XCD runs an equal share of all
+// eight queues -- queue_item -- their imbalance matters less than an XCD's locality: 128 is -3 % at 256^3 and -2 ... -3 % on a
+// rank's share of the 1 M-triangle meshes at 512^3, +1.5 % on dragon x9's: profiles/r06/ab_planregion_at_eight_waves.jsonl.)
 uint32_t plan_region_bits(uint32_t N, uint32_t nz)
 {
     const uint64_t nb = (uint64_t)((N + 3u) / 4u) * ((N + 3u) / 4u) * ((nz + 3u) / 4u);
-    return nb <= (1ull << 19) ? 6u : kPlanRegionBits;
+    return nb <= (1ull << 19) ? 7u : kPlanRegionBits;
 }
 // words of queue memory a partition needs (two headers + eight queues, each able to hold every run dealt to it in full, whatever
 // the run length)
